@@ -1,0 +1,180 @@
+"""Pins for the CPU oracle itself: independent PyTorch built-ins + analytic known-answer tests
+(SURVEY.md §4 / §8(c) 'Pins the new repo must create')."""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import dalle_oracle as do
+from oracle import vae_oracle as vo
+
+
+def small_cfg(S_img=16, d=64, H=2, L=2):
+    return do.DalleConfig(n_embd=d, text_vocab_size=50, image_vocab_size=13, text_seq_len=8,
+                          image_seq_len=S_img, n_layers=L, n_heads=H)
+
+
+def test_token_paths_bit_exact():
+    logits = np.zeros((2, 2, 2, 5), np.float32)
+    logits[0, 0, 1, 3] = 1.0
+    logits[1, 1, 0, 2] = 2.0
+    logits[1, 1, 0, 4] = 2.0           # tie -> smallest index
+    tok = do.image_tokens_from_logits(logits)
+    assert tok.dtype == np.int32 and tok.tolist() == [[0, 3, 0, 0], [0, 0, 2, 0]]
+    text = np.array([[1, 2, 3], [4, 5, 6]], np.int32)
+    seq = do.assemble_tokens(text, tok, 100)
+    assert seq.tolist() == [[1, 2, 3, 100, 103, 100, 100], [4, 5, 6, 100, 100, 102, 100]]
+    lab = do.shift_labels(seq, 999)
+    assert lab[:, -1].tolist() == [999, 999] and (lab[:, :-1] == seq[:, 1:]).all()
+    assert do.truncate_or_pad_label(np.array([7, 8]), 4, 9).tolist() == [7, 8, 9, 9]
+    assert do.truncate_or_pad_label(np.arange(10), 4, 9).tolist() == [0, 1, 2, 3]
+
+
+def test_eos_and_vocab():
+    cfg = do.DalleConfig(512, 50258, 512, 256, 1024, 6, 4)
+    assert cfg.total_tokens == 50771 and cfg.eos_token_id == 50770
+    assert do.n_params(cfg) == 71601747
+    cfg2 = do.DalleConfig(512, 50258, 512, 256, 16, 6, 4)
+    assert do.n_params(cfg2) == 71085651
+
+
+def test_layer_norm_matches_builtin():
+    x = torch.randn(3, 5, 64)
+    g, b = torch.randn(64), torch.randn(64)
+    assert torch.allclose(do.layer_norm(x, g, b), F.layer_norm(x, (64,), g, b, 1e-5), atol=1e-5)
+
+
+def test_attention_matches_sdpa_unscaled():
+    torch.manual_seed(0)
+    B, S, d, H = 2, 12, 64, 2
+    x = torch.randn(B, S, d)
+    wq, wk, wv, wo = (torch.randn(d, d) * 0.1 for _ in range(4))
+    ob = torch.randn(d)
+    got = do.attention(x, wq, wk, wv, wo, ob, H, do.attn_mask(S))
+    q = (x @ wq).view(B, S, H, -1).transpose(1, 2)
+    k = (x @ wk).view(B, S, H, -1).transpose(1, 2)
+    v = (x @ wv).view(B, S, H, -1).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(q, k, v, is_causal=True, scale=1.0)
+    ref = ref.transpose(1, 2).reshape(B, S, d) @ wo + ob
+    assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4)
+
+
+def test_causal_row0_attends_self_only():
+    S, d = 6, 64
+    x = torch.randn(1, S, d)
+    eye = torch.eye(d)
+    out = do.attention(x, eye, eye, eye, eye, torch.zeros(d), 1, do.attn_mask(S))
+    assert torch.allclose(out[0, 0], x[0, 0], atol=1e-5)
+
+
+def test_loss_matches_cross_entropy_and_uniform_kat():
+    logits = torch.randn(2, 7, 33)
+    labels = torch.randint(0, 33, (2, 7))
+    loss, lb = do.loss_fn(logits, labels)
+    ref = F.cross_entropy(logits.view(-1, 33), labels.view(-1))
+    assert torch.allclose(loss, ref, atol=1e-6)
+    loss_u, _ = do.loss_fn(torch.zeros(2, 7, 33), labels)
+    assert abs(float(loss_u) - math.log(33)) < 1e-6
+
+
+def test_forward_and_grads_finite_and_mean_over_all_positions():
+    cfg = small_cfg()
+    P = do.init_params(cfg, seed=3, perturb=0.02)
+    tok = np.random.default_rng(0).integers(0, cfg.total_tokens - 1, (2, cfg.total_seq_dim)).astype(np.int32)
+    loss, grads = do.loss_and_grads(P, tok, cfg)
+    assert np.isfinite(loss) and abs(loss - math.log(cfg.total_tokens)) < 0.5
+    assert all(np.isfinite(g).all() for g in grads.values())
+    assert set(grads) == set(P)
+
+
+def test_lr_schedule():
+    assert do.learning_rate(0, 1e-3, 100000) == 0.0
+    assert abs(do.learning_rate(1500, 1e-3, 100000) - 0.5e-3 * ((0.9 * 0.5 * (1 + math.cos(math.pi * 0.015))) + 0.1)) < 1e-9
+    assert abs(do.learning_rate(100000, 1e-3, 100000) - 1e-4) < 1e-10
+    assert abs(do.learning_rate(200000, 1e-3, 100000) - 1e-4) < 1e-10
+    assert abs(do.learning_rate(50000, 1e-3, 100000, lr_decay="linear") - 0.55e-3) < 1e-9
+
+
+def test_clip_and_adam():
+    g = OrderedDict(a=np.full((4,), 3.0, np.float32), b=np.full((9,), 0.0, np.float32))
+    c, gn = do.clip_by_global_norm(g, 1.0)
+    assert abs(gn - 6.0) < 1e-6 and np.allclose(c["a"], 0.5)
+    small = OrderedDict(a=np.full((4,), 0.1, np.float32))
+    c2, gn2 = do.clip_by_global_norm(small, 1.0)
+    assert np.allclose(c2["a"], 0.1)                     # below the threshold: untouched
+    p = OrderedDict(w=np.ones((3,), np.float32))
+    m = OrderedDict(w=np.zeros((3,), np.float32))
+    v = OrderedDict(w=np.zeros((3,), np.float32))
+    gg = OrderedDict(w=np.full((3,), 2.0, np.float32))
+    do.adam_step(p, gg, m, v, lr=0.1)
+    # no bias correction: m=.2, v=.004 -> upd = .2/(sqrt(.004)+1e-6)
+    exp = 1.0 - 0.1 * (0.2 / (math.sqrt(0.004) + 1e-6))
+    assert np.allclose(p["w"], exp, atol=1e-6)
+    assert do.use_weight_decay("layer_0/mlp/mlp_linear_1/kernel", 0.1)
+    assert not do.use_weight_decay("layer_0/mlp/mlp_linear_1/bias", 0.1)
+    assert not do.use_weight_decay("layer_0/norm_1/g", 0.1)
+
+
+# ------------------------------------------------------------------ VAE
+
+def vae_small():
+    return vo.VaeConfig(num_tokens=32, dimensions=16, convblocks=[[2, 8], [2, 16]])
+
+
+def test_vae_param_counts():
+    ex = vo.VaeConfig(512, 32, [[3, 64], [3, 128], [3, 256]])
+    assert vo.n_params(ex) == 8691267
+    coco = vo.VaeConfig(2048, 256, [[2, 128], [3, 256], [5, 512]])
+    assert vo.n_params(coco) == 53561987
+
+
+def test_conv_same_shapes_and_transpose_is_adjoint():
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 8, 3)
+    k = torch.randn(4, 4, 3, 5)
+    y = vo.conv2d_same(x, k, None, 2)
+    assert y.shape == (2, 4, 4, 5)
+    # conv_transpose with kernel [kh,kw,Cout=3,Cin=5] is the adjoint of the s2 conv with kernel [kh,kw,3,5]
+    z = torch.randn(2, 4, 4, 5)
+    zt = vo.conv2d_transpose_same(z, k, None)
+    assert zt.shape == (2, 8, 8, 3)
+    assert torch.allclose((y * z).sum(), (x * zt).sum(), rtol=1e-4, atol=1e-3)
+    y3 = vo.conv2d_same(x, torch.randn(3, 3, 3, 7), torch.randn(7), 1)
+    assert y3.shape == (2, 8, 8, 7)
+
+
+def test_gumbel_hard_is_onehot_of_argmax():
+    logits = torch.randn(2, 2, 2, 9)
+    u = torch.tensor(vo.synthetic_uniforms((2, 2, 2, 9)))
+    y = vo.gumbel_softmax(logits, u, 0.7, hard=True)
+    g = -torch.log(-torch.log(u))
+    idx = torch.argmax(logits + g, -1)
+    assert torch.equal(torch.argmax(y, -1), idx)
+    assert torch.allclose(y.sum(-1), torch.ones(2, 2, 2), atol=1e-6)
+    assert ((y - F.one_hot(idx, 9)).abs() < 1e-6).all()
+    ys = vo.gumbel_softmax(logits, u, 0.7, hard=False)
+    assert torch.allclose(ys, torch.softmax((logits + g) / 0.7, -1))
+
+
+def test_vae_forward_backward():
+    cfg = vae_small()
+    P = vo.init_params(cfg, bias_perturb=0.01)
+    img = vo.synthetic_images(2, 16)
+    u = vo.synthetic_uniforms((2, cfg.grid, cfg.grid, cfg.num_tokens))
+    loss, grads, out = vo.loss_and_grads(P, img, u, cfg, hard=True)
+    assert out.shape == img.shape and np.isfinite(loss)
+    assert all(np.isfinite(g).all() for g in grads.values())
+    Pt = OrderedDict((n, torch.tensor(a)) for n, a in P.items())
+    logits = vo.forward(Pt, torch.tensor(img), cfg, return_logits=True)
+    assert logits.shape == (2, cfg.grid, cfg.grid, cfg.num_tokens)
+
+
+def test_space_depth_roundtrip_and_temperature():
+    x = torch.randn(1, 4, 4, 3)
+    assert torch.equal(vo.depth_to_space(vo.space_to_depth(x, 2), 2), x)
+    p = dict(temp_anneal_steps=100, temp_start=1.0, temp=0.05)
+    assert vo.temperature(0, p) == 1.0 and abs(vo.temperature(50, p) - 0.525) < 1e-6
+    assert abs(vo.temperature(1000, p) - 0.05) < 1e-6
+    assert vo.temperature(5, {}) == 1.0
