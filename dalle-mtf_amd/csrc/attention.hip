@@ -1,0 +1,447 @@
+// attention.hip -- causal attention for the DALL-E block (reference call site
+// src/dalle_mtf/models.py:221-227,292-299; semantics SURVEY Appendix A.2/A.3):
+//   logits = q.k^T  UNSCALED (the 1/sqrt(k) factor is folded into Wq's initialiser), fp32,
+//   + (-1e10 where key > query), softmax over keys, . v          head dim fixed at 128.
+//
+// Design (gfx950, v_mfma_f32_32x32x16_bf16): never materialise [S,S].  Every kernel arranges the MFMA
+// operand roles so that the softmax row index is the LANE (accumulator column) and the reduction index
+// lives in the accumulator REGISTERS -> row max / row sum are 15 in-register ops + one half-wave
+// exchange, and P / dS feed the next MFMA as B-operands straight from registers (the contraction-slot
+// -> key mapping of the packed registers is matched by the way the V^T / K^T / Q^T / dO^T operand
+// fragments are fetched: two 8-byte LDS reads at key offsets 4h and 8+4h).
+//   fwd      : S^T = K Q^T ;  O^T += V^T P^T        (block = 128 queries, 64-key tiles)
+//   bwd dQ   : S^T = K Q^T ; dP^T = V dO^T ; dQ^T += K^T dS^T
+//   bwd dKdV : S = Q K^T ; dP = dO V^T ; dV^T += dO^T P ; dK^T += Q^T dS   (block = 128 keys, 32-query tiles)
+// Transposed operand copies (V^T, K^T, Q^T, dO^T as [B,H,128,S]) are produced by dmi_transpose_bf16_strided.
+// LDS tiles are padded (+8 / +4 elements per row) so all fragment reads are bank-conflict-free.
+#include "common.h"
+
+#define HD 128
+#define KP 136  // pitch (elements) of a natural [rows][128] tile  : 272 B
+#define TP 68   // pitch of a transposed [128][64] tile             : 136 B
+#define TP32 36 // pitch of a transposed [128][32] tile            :  72 B
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+__device__ __forceinline__ bf16x8 pack_bf8(const float* p) {
+  u32x4 v = {pack2bf(p[0], p[1]), pack2bf(p[2], p[3]), pack2bf(p[4], p[5]), pack2bf(p[6], p[7])};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// natural tile: ROWS x 128 bf16 from a row-major matrix (row stride ld), rows clamped to [0, nrows-1]
+template <int ROWS>
+__device__ __forceinline__ void load_nat_regs(u32x4* r, const bf16_t* __restrict__ g, int64_t ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+    int gr = row0 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    r[i] = *(const u32x4*)(g + (int64_t)gr * ld + 8 * ch);
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_nat_lds(const u32x4* r, bf16_t* lds, int tid) {
+#pragma unroll
+  for (int i = 0; i < ROWS / 16; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, ch = c & 15;
+    *(u32x4*)(lds + row * KP + 8 * ch) = r[i];
+  }
+}
+// transposed tile: 128 rows (d) x COLS (positions) from T[128][S] (row stride S), cols >= S zero-filled
+template <int COLS>
+__device__ __forceinline__ void load_tr_regs(u32x4* r, const bf16_t* __restrict__ g, int S, int col0, int tid) {
+  constexpr int CPR = COLS / 8;  // chunks per row
+#pragma unroll
+  for (int i = 0; i < 128 * CPR / 256; ++i) {
+    const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
+    const int col = col0 + 8 * ch;
+    r[i] = (col < S) ? *(const u32x4*)(g + (int64_t)row * S + col) : u32x4{0, 0, 0, 0};
+  }
+}
+template <int COLS, int PITCH>
+__device__ __forceinline__ void store_tr_lds(const u32x4* r, bf16_t* lds, int tid) {
+  constexpr int CPR = COLS / 8;
+#pragma unroll
+  for (int i = 0; i < 128 * CPR / 256; ++i) {
+    const int c = tid + 256 * i, row = c / CPR, ch = c % CPR;
+    u32x2* p = (u32x2*)(lds + row * PITCH + 8 * ch);  // rows are only 8-byte aligned
+    p[0] = u32x2{r[i][0], r[i][1]};
+    p[1] = u32x2{r[i][2], r[i][3]};
+  }
+}
+
+// =====================================================================================
+// forward
+// =====================================================================================
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
+                                                          bf16_t* __restrict__ o, float* __restrict__ lse, int B,
+                                                          int H, int S) {
+  __shared__ __attribute__((aligned(16))) bf16_t sk[64 * KP];
+  __shared__ __attribute__((aligned(16))) bf16_t sv[128 * TP];
+  const int d = H * HD, ld3 = 3 * d;
+  const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
+  const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+  const int q0 = qt * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int qrow = q0 + wid * 32 + r;
+  const int qrow_c = qrow < S ? qrow : S - 1;
+  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vtb = vt + (int64_t)bh * HD * S;
+
+  bf16x8 qf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qb + (int64_t)qrow_c * ld3 + 16 * kk + 8 * h);
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m = -1e30f, l = 0.f;
+
+  const int qlast = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;
+  const int jmax = qlast / 64;
+  const int wave_qmin = q0 + wid * 32, wave_qmax = wave_qmin + 31;
+
+  u32x4 pk[4], pv[4];
+  load_nat_regs<64>(pk, kb, ld3, 0, S, tid);
+  load_tr_regs<64>(pv, vtb, S, 0, tid);
+  for (int j = 0; j <= jmax; ++j) {
+    __syncthreads();
+    store_nat_lds<64>(pk, sk, tid);
+    store_tr_lds<64, TP>(pv, sv, tid);
+    __syncthreads();
+    if (j < jmax) {
+      load_nat_regs<64>(pk, kb, ld3, 64 * (j + 1), S, tid);
+      load_tr_regs<64>(pv, vtb, S, 64 * (j + 1), tid);
+    }
+    if (64 * j > wave_qmax) continue;  // wave-uniform: tile entirely above the diagonal for this wave
+    f32x16 s0, s1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const bf16x8 a0 = *(const bf16x8*)(sk + r * KP + 16 * kk + 8 * h);
+      const bf16x8 a1 = *(const bf16x8*)(sk + (32 + r) * KP + 16 * kk + 8 * h);
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[kk], s0, 0, 0, 0);  // S^T[key][q]
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[kk], s1, 0, 0, 0);
+    }
+    if (64 * j + 63 > wave_qmin) {  // diagonal tile: additive -1e10 mask == probability exactly 0
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 64 * j + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (key > qrow) s0[e] = -1e30f;
+        if (key + 32 > qrow) s1[e] = -1e30f;
+      }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);
+    m = mn;
+    float p0[16], p1[16], rs = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      p0[e] = __expf(s0[e] - mn);
+      p1[e] = __expf(s1[e] - mn);
+      rs += p0[e] + p1[e];
+    }
+    l = l * alpha + rs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    bf16x8 pb[4];
+    pb[0] = pack_bf8(p0);
+    pb[1] = pack_bf8(p0 + 8);
+    pb[2] = pack_bf8(p1);
+    pb[3] = pack_bf8(p1 + 8);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {  // 16-key step: keys 16*ks + {4h..4h+3, 8+4h..8+4h+3}
+      const int base = 16 * ks + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t* vp = sv + (dt * 32 + r) * TP + base;
+        const bf16x8 a = cat4(*(const bf16x4*)vp, *(const bf16x4*)(vp + 8));
+        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[ks], oacc[dt], 0, 0, 0);  // O^T[d][q]
+      }
+    }
+  }
+  l += __shfl_xor(l, 32, 64);
+  if (qrow < S) {
+    const float inv = 1.f / l;
+    bf16_t* op = o + ((int64_t)b * S + qrow) * d + hh * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int dd = dt * 32 + 8 * q4 + 4 * h;
+        *(u32x2*)(op + dd) = u32x2{pack2bf(oacc[dt][4 * q4] * inv, oacc[dt][4 * q4 + 1] * inv),
+                                   pack2bf(oacc[dt][4 * q4 + 2] * inv, oacc[dt][4 * q4 + 3] * inv)};
+      }
+    if (h == 0) lse[(int64_t)bh * S + qrow] = m + __logf(l);
+  }
+}
+
+extern "C" int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16_t* o, float* lse, int B, int H,
+                                 int S, void* stream) {
+  DMI_REQUIRE(qkv && vt && o && lse, "attention_fwd: null pointer");
+  DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_fwd: S must be a multiple of 8 (S=%d)", S);
+  attn_fwd_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream>>>(qkv, vt, o, lse, B, H, S);
+  DMI_CHECK_LAUNCH("attention_fwd");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// backward
+// =====================================================================================
+// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
+                                                         float* __restrict__ delta, int B, int H, int S) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= (int64_t)B * S) return;
+  const int d = H * HD;
+  const int b = (int)(row / S), s = (int)(row % S);
+  for (int c0 = 0; c0 < d / 8; c0 += 64) {
+    const int c = c0 + lane;
+    float acc = 0.f;
+    if (c < d / 8) {
+      float fo[8], fd[8];
+      unpack8(*(const u32x4*)(o + row * d + c * 8), fo);
+      unpack8(*(const u32x4*)(d_o + row * d + c * 8), fd);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += fo[j] * fd[j];
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((lane & 15) == 0 && c < d / 8) delta[((int64_t)b * H + c / 16) * S + s] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kt,
+                                                             const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                             const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
+                                                             int B, int H, int S) {
+  __shared__ __attribute__((aligned(16))) bf16_t sk[64 * KP];
+  __shared__ __attribute__((aligned(16))) bf16_t sv[64 * KP];
+  __shared__ __attribute__((aligned(16))) bf16_t skt[128 * TP];
+  const int d = H * HD, ld3 = 3 * d;
+  const int qt = gridDim.x - 1 - blockIdx.x;
+  const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+  const int q0 = qt * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int qrow = q0 + wid * 32 + r;
+  const int qrow_c = qrow < S ? qrow : S - 1;
+  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* ktb = kt + (int64_t)bh * HD * S;
+  const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
+
+  bf16x8 qf[8], dof[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    qf[kk] = *(const bf16x8*)(qb + (int64_t)qrow_c * ld3 + 16 * kk + 8 * h);
+    dof[kk] = *(const bf16x8*)(dob + (int64_t)qrow_c * d + 16 * kk + 8 * h);
+  }
+  const float lse_q = lse[(int64_t)bh * S + qrow_c];
+  const float delta_q = delta[(int64_t)bh * S + qrow_c];
+
+  f32x16 dq[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
+
+  const int qlast = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;
+  const int jmax = qlast / 64;
+  const int wave_qmax = q0 + wid * 32 + 31;
+  for (int j = 0; j <= jmax; ++j) {
+    __syncthreads();
+    {
+      u32x4 t[4];
+      load_nat_regs<64>(t, kb, ld3, 64 * j, S, tid);
+      store_nat_lds<64>(t, sk, tid);
+      load_nat_regs<64>(t, vb, ld3, 64 * j, S, tid);
+      store_nat_lds<64>(t, sv, tid);
+      load_tr_regs<64>(t, ktb, S, 64 * j, tid);
+      store_tr_lds<64, TP>(t, skt, tid);
+    }
+    __syncthreads();
+    if (64 * j > wave_qmax) continue;
+#pragma unroll
+    for (int kt2 = 0; kt2 < 2; ++kt2) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const bf16x8 ka = *(const bf16x8*)(sk + (kt2 * 32 + r) * KP + 16 * kk + 8 * h);
+        const bf16x8 va = *(const bf16x8*)(sv + (kt2 * 32 + r) * KP + 16 * kk + 8 * h);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], s, 0, 0, 0);     // S^T[key][q]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kk], dp, 0, 0, 0);  // dP^T[key][q]
+      }
+      float ds[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int key = 64 * j + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const float p = (key > qrow) ? 0.f : __expf(s[e] - lse_q);
+        ds[e] = p * (dp[e] - delta_q);
+      }
+      bf16x8 dsb[2];
+      dsb[0] = pack_bf8(ds);
+      dsb[1] = pack_bf8(ds + 8);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int base = kt2 * 32 + 16 * s2 + 4 * h;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const bf16_t* kp = skt + (dt * 32 + r) * TP + base;
+          const bf16x8 a = cat4(*(const bf16x4*)kp, *(const bf16x4*)(kp + 8));
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb[s2], dq[dt], 0, 0, 0);  // dQ^T[d][q]
+        }
+      }
+    }
+  }
+  if (qrow < S) {
+    bf16_t* op = dqkv + ((int64_t)b * S + qrow) * ld3 + hh * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int dd = dt * 32 + 8 * q4 + 4 * h;
+        *(u32x2*)(op + dd) = u32x2{pack2bf(dq[dt][4 * q4], dq[dt][4 * q4 + 1]), pack2bf(dq[dt][4 * q4 + 2], dq[dt][4 * q4 + 3])};
+      }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qt,
+                                                              const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ dot,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              bf16_t* __restrict__ dqkv, int B, int H, int S) {
+  __shared__ __attribute__((aligned(16))) bf16_t sv[128 * KP];   // resident V rows of this block's keys
+  __shared__ __attribute__((aligned(16))) bf16_t sq[32 * KP];
+  __shared__ __attribute__((aligned(16))) bf16_t sdo[32 * KP];
+  __shared__ __attribute__((aligned(16))) bf16_t sqt[128 * TP32];
+  __shared__ __attribute__((aligned(16))) bf16_t sdot[128 * TP32];
+  __shared__ float slse[32], sdelta[32];
+  const int d = H * HD, ld3 = 3 * d;
+  const int ktile = blockIdx.x;
+  const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+  const int key0 = ktile * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int krow = key0 + wid * 32 + r;
+  const int krow_c = krow < S ? krow : S - 1;
+  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
+  const bf16_t* kb = qb + d;
+  const bf16_t* vb = qb + 2 * d;
+  const bf16_t* qtb = qt + (int64_t)bh * HD * S;
+  const bf16_t* dotb = dot + (int64_t)bh * HD * S;
+  const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
+
+  bf16x8 kf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kb + (int64_t)krow_c * ld3 + 16 * kk + 8 * h);
+  {
+    u32x4 t[8];
+    load_nat_regs<128>(t, vb, ld3, key0, S, tid);
+    store_nat_lds<128>(t, sv, tid);
+  }
+  f32x16 dv[4], dk[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dv[i][e] = dk[i][e] = 0.f;
+
+  const int wave_kmin = key0 + wid * 32;
+  const int nqi = (S + 31) / 32;
+  for (int qi = key0 / 32; qi < nqi; ++qi) {
+    __syncthreads();
+    {
+      u32x4 t[2];
+      load_nat_regs<32>(t, qb, ld3, 32 * qi, S, tid);
+      store_nat_lds<32>(t, sq, tid);
+      load_nat_regs<32>(t, dob, d, 32 * qi, S, tid);
+      store_nat_lds<32>(t, sdo, tid);
+      load_tr_regs<32>(t, qtb, S, 32 * qi, tid);
+      store_tr_lds<32, TP32>(t, sqt, tid);
+      load_tr_regs<32>(t, dotb, S, 32 * qi, tid);
+      store_tr_lds<32, TP32>(t, sdot, tid);
+      if (tid < 32) {
+        const int qq = 32 * qi + tid;
+        slse[tid] = (qq < S) ? lse[(int64_t)bh * S + qq] : 1e30f;  // rows past the end get probability 0
+        sdelta[tid] = (qq < S) ? delta[(int64_t)bh * S + qq] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (32 * qi + 31 < wave_kmin) continue;  // every query of the tile precedes every key of this wave
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const bf16x8 qa = *(const bf16x8*)(sq + r * KP + 16 * kk + 8 * h);
+      const bf16x8 da = *(const bf16x8*)(sdo + r * KP + 16 * kk + 8 * h);
+      const bf16x8 vf = *(const bf16x8*)(sv + (wid * 32 + r) * KP + 16 * kk + 8 * h);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);   // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf, dp, 0, 0, 0);     // dP[q][key]
+    }
+    float pv[16], ds[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ql = (e & 3) + 8 * (e >> 2) + 4 * h;
+      const int qg = 32 * qi + ql;
+      const float p = (krow > qg) ? 0.f : __expf(s[e] - slse[ql]);
+      pv[e] = p;
+      ds[e] = p * (dp[e] - sdelta[ql]);
+    }
+    bf16x8 pb[2], dsb[2];
+    pb[0] = pack_bf8(pv);
+    pb[1] = pack_bf8(pv + 8);
+    dsb[0] = pack_bf8(ds);
+    dsb[1] = pack_bf8(ds + 8);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int base = 16 * s2 + 4 * h;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16_t* p1 = sdot + (dt * 32 + r) * TP32 + base;
+        const bf16_t* p2 = sqt + (dt * 32 + r) * TP32 + base;
+        const bf16x8 a1 = cat4(*(const bf16x4*)p1, *(const bf16x4*)(p1 + 8));
+        const bf16x8 a2 = cat4(*(const bf16x4*)p2, *(const bf16x4*)(p2 + 8));
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb[s2], dv[dt], 0, 0, 0);   // dV^T[d][key]
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb[s2], dk[dt], 0, 0, 0);  // dK^T[d][key]
+      }
+    }
+  }
+  if (krow < S) {
+    bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
+    bf16_t* ovp = okp + d;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int dd = dt * 32 + 8 * q4 + 4 * h;
+        *(u32x2*)(okp + dd) = u32x2{pack2bf(dk[dt][4 * q4], dk[dt][4 * q4 + 1]), pack2bf(dk[dt][4 * q4 + 2], dk[dt][4 * q4 + 3])};
+        *(u32x2*)(ovp + dd) = u32x2{pack2bf(dv[dt][4 * q4], dv[dt][4 * q4 + 1]), pack2bf(dv[dt][4 * q4 + 2], dv[dt][4 * q4 + 3])};
+      }
+  }
+}
+
+extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
+                                 const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
+                                 uint16_t* dqkv, int B, int H, int S, void* stream) {
+  DMI_REQUIRE(qkv && qt && kt && o && d_o && dot && lse && delta && dqkv, "attention_bwd: null pointer");
+  DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_bwd: S must be a multiple of 8 (S=%d)", S);
+  hipStream_t st = (hipStream_t)stream;
+  attn_delta_kernel<<<dim3((unsigned)cdiv64((int64_t)B * S, 4)), dim3(256), 0, st>>>(o, d_o, delta, B, H, S);
+  DMI_CHECK_LAUNCH("attention_delta");
+  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, st>>>(qkv, kt, d_o, lse, delta, dqkv, B, H, S);
+  DMI_CHECK_LAUNCH("attention_bwd_dq");
+  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, st>>>(qkv, qt, d_o, dot, lse, delta, dqkv, B, H, S);
+  DMI_CHECK_LAUNCH("attention_bwd_dkv");
+  return DMI_OK;
+}

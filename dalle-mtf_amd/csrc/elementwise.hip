@@ -1,0 +1,672 @@
+// elementwise.hip -- HBM-bound kernels of the DALL-E train step (SURVEY.md §2.2 K1,K2,K7-K10).
+// All loads/stores are 16 B per lane (8 bf16 / 4 fp32), one wave64 per row where rows are short,
+// wave-shuffle reductions, deterministic two-stage reductions for gradients of shared parameters.
+#include "common.h"
+#include <stdarg.h>
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local char g_err[512] = "ok";
+void dmi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dmi_last_error_string(void) { return g_err; }
+extern "C" int dmi_version(void) { return 100; }
+
+// =====================================================================================
+// K1 embedding   (src/dalle_mtf/models.py:186-219)
+// =====================================================================================
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ tokens,
+                                                        const bf16_t* __restrict__ wte,
+                                                        const bf16_t* __restrict__ wpe, bf16_t* __restrict__ x,
+                                                        int64_t rows, int S, int d, int vocab) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  int tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  const int s = (int)(row % S);
+  const u32x4* a = (const u32x4*)(wte + (int64_t)tok * d);
+  const u32x4* p = (const u32x4*)(wpe + (int64_t)s * d);
+  u32x4* o = (u32x4*)(x + row * d);
+  for (int c = lane; c < d / 8; c += 64) {
+    float fa[8], fp[8];
+    unpack8(a[c], fa);
+    unpack8(p[c], fp);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fa[j] += fp[j];
+    o[c] = pack8(fa);
+  }
+}
+
+extern "C" int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
+                             int64_t rows, int S, int d, int vocab, void* stream) {
+  DMI_REQUIRE(tokens && wte && wpe && x, "embed_fwd: null pointer");
+  DMI_REQUIRE(d % 8 == 0 && rows > 0 && S > 0, "embed_fwd: d %% 8 != 0 or empty (d=%d rows=%lld)", d, (long long)rows);
+  embed_fwd_kernel<<<dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream>>>(tokens, wte, wpe, x, rows, S, d, vocab);
+  DMI_CHECK_LAUNCH("embed_fwd");
+  return DMI_OK;
+}
+
+// dwpe[s, :] = sum_b dx[b, s, :]      (one wave per position; deterministic)
+__global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const bf16_t* __restrict__ dx, float* __restrict__ dwpe,
+                                                            int B, int S, int d) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int s = blockIdx.x * 4 + wid;
+  if (s >= S) return;
+  for (int c = lane; c < d / 8; c += 64) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < B; ++b) {
+      float f[8];
+      unpack8(*(const u32x4*)(dx + ((int64_t)b * S + s) * d + c * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    float* o = dwpe + (int64_t)s * d + c * 8;
+    *(f32x4*)o = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+// dwte[tok, :] += dx[row, :]   (fp32 hardware atomics; scatter-add = gradient of gather, Appendix A.6)
+__global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int* __restrict__ tokens,
+                                                            const bf16_t* __restrict__ dx, float* __restrict__ dwte,
+                                                            int64_t rows, int d, int vocab) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  int tok = tokens[row];
+  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+  float* dst = dwte + (int64_t)tok * d;
+  for (int c = lane; c < d / 8; c += 64) {
+    float f[8];
+    unpack8(*(const u32x4*)(dx + row * d + c * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dst + c * 8 + j, f[j]);
+  }
+}
+
+extern "C" int dmi_embed_bwd(const int32_t* tokens, const uint16_t* dx, float* dwte, float* dwpe, int B, int S,
+                             int d, int vocab, void* stream) {
+  DMI_REQUIRE(tokens && dx && dwte && dwpe, "embed_bwd: null pointer");
+  DMI_REQUIRE(d % 8 == 0 && B > 0 && S > 0, "embed_bwd: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  embed_bwd_wpe_kernel<<<dim3((S + 3) / 4), dim3(256), 0, st>>>(dx, dwpe, B, S, d);
+  DMI_CHECK_LAUNCH("embed_bwd_wpe");
+  const int64_t rows = (int64_t)B * S;
+  embed_bwd_wte_kernel<<<dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st>>>(tokens, dx, dwte, rows, d, vocab);
+  DMI_CHECK_LAUNCH("embed_bwd_wte");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// K2 LayerNorm (src/dalle_mtf/models.py:373-389, layers.py:30-33): biased variance of the
+// centred row, eps inside rsqrt.  One wave per row, row cached in registers (d <= 512*NC).
+// =====================================================================================
+template <int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ g,
+                                                     const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= rows) return;
+  const int nch = d / 8;
+  float v[NC][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      unpack8(*(const u32x4*)(x + row * d + c * 8), v[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sum += v[i][j];
+    }
+  }
+  const float mu = wave_sum(sum) / (float)d;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[i][j] -= mu;
+        sq += v[i][j] * v[i][j];
+      }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(sq) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float fg[8], fb[8], o[8];
+      unpack8(*(const u32x4*)(g + c * 8), fg);
+      unpack8(*(const u32x4*)(b + c * 8), fb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rs * fg[j] + fb[j];
+      *(u32x4*)(y + row * d + c * 8) = pack8(o);
+    }
+  }
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+}
+
+extern "C" int dmi_layernorm_fwd(const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y, float* mean,
+                                 float* rstd, int64_t rows, int d, float eps, void* stream) {
+  DMI_REQUIRE(x && g && b && y && mean && rstd, "layernorm_fwd: null pointer");
+  DMI_REQUIRE(d % 8 == 0 && d <= 4096 && rows > 0, "layernorm_fwd: unsupported d=%d (need d%%8==0, d<=4096)", d);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv64(rows, 4)), blk(256);
+  if (d <= 512) ln_fwd_kernel<1><<<grid, blk, 0, st>>>(x, g, b, y, mean, rstd, rows, d, eps);
+  else if (d <= 1024) ln_fwd_kernel<2><<<grid, blk, 0, st>>>(x, g, b, y, mean, rstd, rows, d, eps);
+  else if (d <= 2048) ln_fwd_kernel<4><<<grid, blk, 0, st>>>(x, g, b, y, mean, rstd, rows, d, eps);
+  else ln_fwd_kernel<8><<<grid, blk, 0, st>>>(x, g, b, y, mean, rstd, rows, d, eps);
+  DMI_CHECK_LAUNCH("layernorm_fwd");
+  return DMI_OK;
+}
+
+// ---- generic deterministic partial reduce: out[c] = sum_{p<P} part[p*ncols + c]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int P, int ncols) {
+  __shared__ float sm[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < ncols)
+    for (int p = grp; p < P; p += 4) acc += part[(int64_t)p * ncols + c];
+  sm[grp][cl] = acc;
+  __syncthreads();
+  if (grp == 0 && c < ncols) out[c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+}
+
+#define LN_BWD_RPB 64  // rows per block (16 per wave)
+extern "C" int64_t dmi_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
+  return cdiv64(rows, LN_BWD_RPB) * 2 * (int64_t)d * 4;
+}
+
+// dx = rstd * (dy*g - mean_j(dy*g) - xhat * mean_j(dy*g*xhat)) (+ dres);  partial dg/db per block.
+template <int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                     const bf16_t* __restrict__ g, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
+                                                     bf16_t* __restrict__ dx, float* __restrict__ part,
+                                                     int64_t rows, int d) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [4][2][d]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nch = d / 8;
+  float ag[NC][8], ab[NC][8], fg[NC][8];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ag[i][j] = ab[i][j] = 0.f;
+    if (c < nch) unpack8(*(const u32x4*)(g + c * 8), fg[i]);
+  }
+  const int64_t r0 = (int64_t)blockIdx.x * LN_BWD_RPB;
+  for (int it = 0; it < LN_BWD_RPB / 4; ++it) {
+    const int64_t row = r0 + wid + 4 * it;
+    if (row >= rows) break;
+    const float mu = mean[row], rs = rstd[row];
+    float fy[NC][8], xh[NC][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float fx[8];
+        unpack8(*(const u32x4*)(dy + row * d + c * 8), fy[i]);
+        unpack8(*(const u32x4*)(x + row * d + c * 8), fx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (fx[j] - mu) * rs;
+          ab[i][j] += fy[i][j];
+          ag[i][j] += fy[i][j] * xh[i][j];
+          fy[i][j] *= fg[i][j];  // dy*g
+          s1 += fy[i][j];
+          s2 += fy[i][j] * xh[i][j];
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (fy[i][j] - s1 - xh[i][j] * s2);
+        if (dres) {
+          float fr[8];
+          unpack8(*(const u32x4*)(dres + row * d + c * 8), fr);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += fr[j];
+        }
+        *(u32x4*)(dx + row * d + c * 8) = pack8(o);
+      }
+    }
+  }
+  // cross-wave combine, one partial row per block
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sm[(wid * 2 + 0) * d + c * 8 + j] = ag[i][j];
+        sm[(wid * 2 + 1) * d + c * 8 + j] = ab[i][j];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * d; idx += 256) {
+    const int which = idx / d, col = idx % d;
+    float s = (sm[(0 * 2 + which) * d + col] + sm[(1 * 2 + which) * d + col]) +
+              (sm[(2 * 2 + which) * d + col] + sm[(3 * 2 + which) * d + col]);
+    part[(int64_t)blockIdx.x * 2 * d + idx] = s;
+  }
+}
+
+// out layout of the reduce: [dg(d) | db(d)] -> two destination pointers
+__global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ dg,
+                                                            float* __restrict__ db, int P, int d) {
+  __shared__ float sm[4][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  float acc = 0.f;
+  if (c < 2 * d)
+    for (int p = grp; p < P; p += 4) acc += part[(int64_t)p * 2 * d + c];
+  sm[grp][cl] = acc;
+  __syncthreads();
+  if (grp == 0 && c < 2 * d) {
+    const float s = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+    if (c < d) dg[c] = s;
+    else db[c - d] = s;
+  }
+}
+
+extern "C" int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, const float* mean,
+                                 const float* rstd, const uint16_t* dres, uint16_t* dx, float* dg, float* db,
+                                 void* workspace, int64_t rows, int d, void* stream) {
+  DMI_REQUIRE(dy && x && g && mean && rstd && dx && dg && db && workspace, "layernorm_bwd: null pointer");
+  DMI_REQUIRE(d % 8 == 0 && d <= 2048 && rows > 0, "layernorm_bwd: unsupported d=%d (need d%%8==0, d<=2048)", d);
+  hipStream_t st = (hipStream_t)stream;
+  const int P = (int)cdiv64(rows, LN_BWD_RPB);
+  const size_t shm = (size_t)4 * 2 * d * sizeof(float);
+  float* part = (float*)workspace;
+  dim3 grid(P), blk(256);
+  if (d <= 512) ln_bwd_kernel<1><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
+  else if (d <= 1024) ln_bwd_kernel<2><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
+  else ln_bwd_kernel<4><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
+  DMI_CHECK_LAUNCH("layernorm_bwd");
+  ln_bwd_finish_kernel<<<dim3((2 * d + 63) / 64), blk, 0, st>>>(part, dg, db, P, d);
+  DMI_CHECK_LAUNCH("layernorm_bwd_finish");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// column sum (bias gradients)
+// =====================================================================================
+#define COLSUM_RPB 256
+extern "C" int64_t dmi_colsum_workspace_bytes(int64_t M, int N) { return cdiv64(M, COLSUM_RPB) * (int64_t)N * 4; }
+
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ Y, int ldy, float* __restrict__ part,
+                                                     int64_t M, int N) {
+  __shared__ float sm[4][64][8];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int cg = blockIdx.x * 64 + cl;  // group of 8 columns
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_RPB;
+  const int64_t r1 = (r0 + COLSUM_RPB < M) ? r0 + COLSUM_RPB : M;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (cg * 8 < N) {
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      float f[8];
+      unpack8(*(const u32x4*)(Y + r * ldy + cg * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sm[rl][cl][j] = acc[j];
+  __syncthreads();
+  if (rl == 0 && cg * 8 < N) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      part[(int64_t)blockIdx.y * N + cg * 8 + j] = (sm[0][cl][j] + sm[1][cl][j]) + (sm[2][cl][j] + sm[3][cl][j]);
+  }
+}
+
+extern "C" int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int N, void* workspace, void* stream) {
+  DMI_REQUIRE(Y && out && workspace, "colsum: null pointer");
+  DMI_REQUIRE(N % 8 == 0 && ldy % 8 == 0 && M > 0, "colsum: N,ldy must be multiples of 8");
+  hipStream_t st = (hipStream_t)stream;
+  const int P = (int)cdiv64(M, COLSUM_RPB);
+  colsum_kernel<<<dim3((N / 8 + 63) / 64, P), dim3(256), 0, st>>>(Y, ldy, (float*)workspace, M, N);
+  DMI_CHECK_LAUNCH("colsum");
+  reduce_partials_kernel<<<dim3((N + 63) / 64), dim3(256), 0, st>>>((const float*)workspace, out, P, N);
+  DMI_CHECK_LAUNCH("colsum_reduce");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// batched bf16 transpose: element (b,h,r,c) at in + b*sb + h*sh + r*sr + c  ->  out[((b*nh+h)*C + c)*R + r]
+// =====================================================================================
+// Rv = valid input rows, R = output row pitch (>= Rv; rows in [Rv, R) are written as zeros)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                        int nh, int Rv, int R, int C, int64_t sb, int64_t sh, int64_t sr) {
+  __shared__ unsigned t[64][33];
+  const int bh = blockIdx.z, b = bh / nh, h = bh % nh;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const bf16_t* src = in + b * sb + h * sh;
+  bf16_t* dst = out + (int64_t)bh * C * R;
+  const int tid = threadIdx.x;
+  {
+    const int chunk = tid & 7, rp = tid >> 3;
+    const int ra = r0 + 2 * rp, c = c0 + 8 * chunk;
+    u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+    if (c < C) {
+      if (ra < Rv) va = *(const u32x4*)(src + (int64_t)ra * sr + c);
+      if (ra + 1 < Rv) vb = *(const u32x4*)(src + (int64_t)(ra + 1) * sr + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned lo = (va[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+      const unsigned hi = (vb[j >> 1] >> ((j & 1) * 16)) & 0xffffu;
+      t[8 * chunk + j][rp] = lo | (hi << 16);
+    }
+  }
+  __syncthreads();
+  {
+    const int orow = tid >> 2, seg = tid & 3;
+    const int c = c0 + orow, r = r0 + 16 * seg;
+    if (c < C) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int rr = r + 8 * q;
+        if (rr < R) {
+          u32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = t[orow][8 * seg + 4 * q + i];
+          *(u32x4*)(dst + (int64_t)c * R + rr) = v;
+        }
+      }
+    }
+  }
+}
+
+int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int Rv, int Rp, int C,
+                         int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride, void* stream) {
+  DMI_REQUIRE(in && out, "transpose: null pointer");
+  DMI_REQUIRE(Rp % 8 == 0 && Rp >= Rv && C % 8 == 0 && in_r_stride % 8 == 0 && in_h_stride % 8 == 0 && in_b_stride % 8 == 0,
+              "transpose: R, C and strides must be multiples of 8 (R=%d C=%d)", Rp, C);
+  transpose_kernel<<<dim3((C + 63) / 64, (Rp + 63) / 64, nb * nh), dim3(256), 0, (hipStream_t)stream>>>(
+      in, out, nh, Rv, Rp, C, in_b_stride, in_h_stride, in_r_stride);
+  DMI_CHECK_LAUNCH("transpose");
+  return DMI_OK;
+}
+extern "C" int dmi_transpose_bf16_strided(const uint16_t* in, uint16_t* out, int nb, int nh, int R, int C,
+                                          int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride,
+                                          void* stream) {
+  return dmi_transpose_padded(in, out, nb, nh, R, R, C, in_b_stride, in_h_stride, in_r_stride, stream);
+}
+extern "C" int dmi_transpose_bf16(const uint16_t* in, uint16_t* out, int batch, int R, int C, void* stream) {
+  return dmi_transpose_bf16_strided(in, out, batch, 1, R, C, (int64_t)R * C, 0, C, stream);
+}
+
+// =====================================================================================
+// integer paths (bit-exact): label shift (models.py:407-410), token assembly (model_fns.py:76-77,118-119)
+// =====================================================================================
+__global__ void shift_labels_kernel(const int* __restrict__ tokens, int* __restrict__ labels, int B, int S, int eos) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * S) return;
+  const int s = (int)(i % S);
+  labels[i] = (s == S - 1) ? eos : tokens[i + 1];
+}
+extern "C" int dmi_shift_labels(const int32_t* tokens, int32_t* labels, int B, int S, int eos, void* stream) {
+  DMI_REQUIRE(tokens && labels && B > 0 && S > 0, "shift_labels: bad args");
+  const int64_t n = (int64_t)B * S;
+  shift_labels_kernel<<<dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream>>>(tokens, labels, B, S, eos);
+  DMI_CHECK_LAUNCH("shift_labels");
+  return DMI_OK;
+}
+
+// one wave per (b, p): argmax over C fp32 logits, first max on ties (tf.math.argmax), + text_vocab
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const int* __restrict__ text,
+                                                              const float* __restrict__ logits, int* __restrict__ out,
+                                                              int B, int T, int P, int C, int text_vocab) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + wid;
+  const int S = T + P;
+  if (idx >= (int64_t)B * S) return;
+  const int b = (int)(idx / S), s = (int)(idx % S);
+  if (s < T) {
+    if (lane == 0) out[idx] = text[(int64_t)b * T + s];
+    return;
+  }
+  const float* row = logits + ((int64_t)b * P + (s - T)) * C;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int c = lane; c < C; c += 64) {
+    const float v = row[c];
+    if (v > best || (v == best && c < bi)) {
+      best = v;
+      bi = c;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (lane == 0) out[idx] = (bi == 0x7fffffff ? 0 : bi) + text_vocab;
+}
+extern "C" int dmi_assemble_tokens(const int32_t* text, const float* vae_logits, int32_t* tokens_out, int B, int T,
+                                   int P, int C, int text_vocab, void* stream) {
+  DMI_REQUIRE(text && vae_logits && tokens_out && B > 0 && T >= 0 && P > 0 && C > 0, "assemble_tokens: bad args");
+  const int64_t n = (int64_t)B * (T + P);
+  assemble_tokens_kernel<<<dim3((unsigned)cdiv64(n, 4)), dim3(256), 0, (hipStream_t)stream>>>(text, vae_logits, tokens_out, B, T, P, C, text_vocab);
+  DMI_CHECK_LAUNCH("assemble_tokens");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// K7 cross entropy over bf16 logits (models.py:348-359; mtf softmax_cross_entropy_with_logits A.5)
+// one 256-thread block per row; pass 1 online max/sum; pass 2 (L2-resident re-read) writes dz in place.
+// =====================================================================================
+__global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__ z, int ldz,
+                                                            const int* __restrict__ labels,
+                                                            float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                            int V, float dz_scale) {
+  __shared__ float sm_m[4], sm_s[4];
+  const int64_t row = blockIdx.x;
+  bf16_t* zr = z + row * ldz;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nch = (V + 7) / 8;
+  float m = -INFINITY, s = 0.f;
+  for (int c = tid; c < nch; c += 256) {
+    float f[8];
+    unpack8(*(const u32x4*)(zr + c * 8), f);
+    float cm = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (c * 8 + j >= V) f[j] = -INFINITY;
+      cm = fmaxf(cm, f[j]);
+    }
+    if (cm > m) {
+      s *= __expf(m - cm);
+      m = cm;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += __expf(f[j] - m);
+  }
+  // wave then block combine of (m, s)
+  float wm = wave_max(m);
+  s *= (m == -INFINITY) ? 0.f : __expf(m - wm);
+  s = wave_sum(s);
+  if (lane == 0) {
+    sm_m[wid] = wm;
+    sm_s[wid] = s;
+  }
+  __syncthreads();
+  const float bm = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+  float bs = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) bs += sm_s[w] * __expf(sm_m[w] - bm);
+  const float lse = bm + __logf(bs);
+  const int label = labels[row];
+  if (tid == 0) {
+    const float zl = (label >= 0 && label < V) ? bf2f(zr[label]) : 0.f;
+    loss_rows[row] = lse - zl;
+    if (lse_out) lse_out[row] = lse;
+  }
+  if (dz_scale == 0.f) return;
+  __syncthreads();  // tid 0 read z[label] before anyone overwrites it
+  for (int c = tid; c < nch; c += 256) {
+    float f[8];
+    unpack8(*(const u32x4*)(zr + c * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = c * 8 + j;
+      float p = (col < V) ? __expf(f[j] - lse) : 0.f;
+      if (col == label) p -= 1.f;
+      f[j] = p * dz_scale;
+    }
+    *(u32x4*)(zr + c * 8) = pack8(f);
+  }
+}
+extern "C" int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, float* loss_rows, float* lse,
+                                 int64_t M, int V, float dz_scale, void* stream) {
+  DMI_REQUIRE(z && labels && loss_rows, "cross_entropy: null pointer");
+  DMI_REQUIRE(ldz % 8 == 0 && ldz >= ((V + 7) / 8) * 8 && M > 0 && V > 0, "cross_entropy: ldz must be a multiple of 8 and >= round_up(V,8)");
+  cross_entropy_kernel<<<dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
+  DMI_CHECK_LAUNCH("cross_entropy");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// reductions + optimizer (src/optimizers.py:11-16, 82-89, 154-177)
+// =====================================================================================
+__device__ __forceinline__ float block_sum_256(float x, float* sm) {
+  x = wave_sum(x);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, int64_t n, float scale,
+                                                      float* __restrict__ out) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) acc += x[i];
+  const float t = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) out[0] = t * scale;
+}
+extern "C" int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream) {
+  DMI_REQUIRE(x && out && n > 0, "sum_f32: bad args");
+  sum_f32_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream>>>(x, n, scale, out);
+  DMI_CHECK_LAUNCH("sum_f32");
+  return DMI_OK;
+}
+
+#define SUMSQ_BLOCKS 2048
+extern "C" int64_t dmi_sumsq_workspace_bytes(int64_t n) { (void)n; return SUMSQ_BLOCKS * 4; }
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  const int64_t n4 = n / 4;
+  const f32x4* g4 = (const f32x4*)g;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const f32x4 v = g4[i];
+    acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = g[n4 * 4 + threadIdx.x];
+    acc += v * v;
+  }
+  const float t = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+extern "C" int dmi_sumsq(const float* g, int64_t n, float* out, void* workspace, void* stream) {
+  DMI_REQUIRE(g && out && workspace && n > 0, "sumsq: bad args");
+  DMI_REQUIRE(((uintptr_t)g & 15) == 0, "sumsq: g must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  sumsq_kernel<<<dim3(SUMSQ_BLOCKS), dim3(256), 0, st>>>(g, n, (float*)workspace);
+  DMI_CHECK_LAUNCH("sumsq");
+  sum_f32_kernel<<<dim3(1), dim3(256), 0, st>>>((const float*)workspace, SUMSQ_BLOCKS, 1.0f, out);
+  DMI_CHECK_LAUNCH("sumsq_finish");
+  return DMI_OK;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   bf16_t* __restrict__ pb, int64_t n,
+                                                   const float* __restrict__ gnorm_sq, float clip, float lr, float b1,
+                                                   float b2, float eps, float wd, float gscale) {
+  float mult = gscale;
+  if (gnorm_sq != nullptr && clip > 0.f) {
+    const float gn = sqrtf(gnorm_sq[0]) * gscale;  // norm of the scaled gradient
+    mult = gscale * (clip / fmaxf(gn, clip));
+  }
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 pv = ((f32x4*)p)[i], gv = ((const f32x4*)g)[i], mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * mult;
+      mv[j] = b1 * mv[j] + (1.f - b1) * gg;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+      float upd = mv[j] / (sqrtf(vv[j]) + eps);
+      upd += wd * pv[j];
+      pv[j] -= lr * upd;
+    }
+    ((f32x4*)p)[i] = pv;
+    ((f32x4*)m)[i] = mv;
+    ((f32x4*)v)[i] = vv;
+    if (pb) *(u32x2*)(pb + i * 4) = u32x2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    const float gg = g[i] * mult;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    float pp = p[i];
+    pp -= lr * (mm / (sqrtf(vv) + eps) + wd * pp);
+    p[i] = pp;
+    m[i] = mm;
+    v[i] = vv;
+    if (pb) pb[i] = f2bf(pp);
+  }
+}
+extern "C" int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
+                             const float* gnorm_sq, float clip, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float grad_scale, void* stream) {
+  DMI_REQUIRE(p && g && m && v && n > 0, "adam_step: bad args");
+  DMI_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0,
+              "adam_step: buffers must be 16-byte aligned");
+  int64_t blocks = cdiv64(n / 4 + 1, 256);
+  if (blocks > 4096) blocks = 4096;
+  adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  DMI_CHECK_LAUNCH("adam_step");
+  return DMI_OK;
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = f2bf(in[i]);
+}
+extern "C" int dmi_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void* stream) {
+  DMI_REQUIRE(in && out && n > 0, "cast: bad args");
+  int64_t blocks = cdiv64(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  cast_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(in, out, n);
+  DMI_CHECK_LAUNCH("cast");
+  return DMI_OK;
+}

@@ -1,0 +1,221 @@
+"""ctypes binding of libdalle_hip.so (include/dalle_hip.h).
+
+Thin plumbing only: torch tensors supply device memory and the current HIP stream; every
+function below forwards raw pointers + sizes to the C ABI and raises on a non-zero status.
+There is NO CPU fallback: if the library is missing or a GPU is absent the call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdalle_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "dalle_hip.h")
+
+GEMM_BIAS, GEMM_RELU, GEMM_RESIDUAL, GEMM_RELU_MASK, GEMM_OUT_F32 = 1, 2, 4, 8, 16
+
+_lib = None
+
+
+class DalleHipError(RuntimeError):
+    pass
+
+
+def declared_symbols():
+    """Every dmi_* function the public header declares."""
+    txt = open(HEADER_PATH).read()
+    return sorted(set(re.findall(r"\b(dmi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DalleHipError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the product path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    P, I, L64, F = c_void_p, c_int, c_int64, c_float
+    sig = {
+        "dmi_last_error_string": (c_char_p, []),
+        "dmi_version": (I, []),
+        "dmi_get_option": (I, [c_char_p]),
+        "dmi_set_option": (I, [c_char_p, I]),
+        "dmi_embed_fwd": (I, [P, P, P, P, L64, I, I, I, P]),
+        "dmi_embed_bwd": (I, [P, P, P, P, I, I, I, I, P]),
+        "dmi_layernorm_fwd": (I, [P, P, P, P, P, P, L64, I, F, P]),
+        "dmi_layernorm_bwd_workspace_bytes": (L64, [L64, I]),
+        "dmi_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L64, I, P]),
+        "dmi_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, I, P, P, P, P]),
+        "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
+        "dmi_gemm_tn": (I, [P, I, P, I, P, I, I, I, P, P]),
+        "dmi_colsum_workspace_bytes": (L64, [L64, I]),
+        "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
+        "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
+        "dmi_transpose_bf16_strided": (I, [P, P, I, I, I, I, L64, L64, L64, P]),
+        "dmi_attention_fwd": (I, [P, P, P, P, I, I, I, P]),
+        "dmi_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+        "dmi_shift_labels": (I, [P, P, I, I, I, P]),
+        "dmi_cross_entropy": (I, [P, I, P, P, P, L64, I, F, P]),
+        "dmi_sum_f32": (I, [P, L64, F, P, P]),
+        "dmi_assemble_tokens": (I, [P, P, P, I, I, I, I, I, P]),
+        "dmi_sumsq_workspace_bytes": (L64, [L64]),
+        "dmi_sumsq": (I, [P, L64, P, P, P]),
+        "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P]),
+        "dmi_cast_f32_bf16": (I, [P, P, L64, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    # optional (VAE) entry points are declared by dalle_hip.vae when present
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise DalleHipError(f"{what}: status {rc}: {lib().dmi_last_error_string().decode()}")
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise DalleHipError("dalle_hip ops need CUDA(HIP) tensors; there is no CPU fallback")
+
+
+def set_option(name: str, value: int):
+    _check(lib().dmi_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name: str) -> int:
+    return lib().dmi_get_option(name.encode())
+
+
+# ------------------------------------------------------------------ wrappers (torch tensors in/out)
+
+def embed_fwd(tokens, wte, wpe, x, S, d, vocab):
+    _dev(tokens, wte, wpe, x)
+    _check(lib().dmi_embed_fwd(_p(tokens), _p(wte), _p(wpe), _p(x), tokens.numel(), S, d, vocab, _stream()), "embed_fwd")
+
+
+def embed_bwd(tokens, dx, dwte, dwpe, B, S, d, vocab):
+    _dev(tokens, dx, dwte, dwpe)
+    _check(lib().dmi_embed_bwd(_p(tokens), _p(dx), _p(dwte), _p(dwpe), B, S, d, vocab, _stream()), "embed_bwd")
+
+
+def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps=1e-5):
+    _dev(x, g, b, y, mean, rstd)
+    _check(lib().dmi_layernorm_fwd(_p(x), _p(g), _p(b), _p(y), _p(mean), _p(rstd), rows, d, eps, _stream()), "layernorm_fwd")
+
+
+def layernorm_bwd_workspace_bytes(rows, d):
+    return lib().dmi_layernorm_bwd_workspace_bytes(rows, d)
+
+
+def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, ws, rows, d):
+    _dev(dy, x, g, mean, rstd, dx, dg, db, ws)
+    _check(lib().dmi_layernorm_bwd(_p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dg), _p(db),
+                                   _p(ws), rows, d, _stream()), "layernorm_bwd")
+
+
+def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None, relu_src=None):
+    _dev(A, Bt, C)
+    _check(lib().dmi_gemm_nt(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _p(residual),
+                             _p(relu_src), _stream()), "gemm_nt")
+
+
+def gemm_tn_workspace_bytes(M, I, J):
+    return lib().dmi_gemm_tn_workspace_bytes(M, I, J)
+
+
+def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws):
+    _dev(X, dY, dW, ws)
+    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), M, I, J, _p(ws), _stream()), "gemm_tn")
+
+
+def colsum_workspace_bytes(M, N):
+    return lib().dmi_colsum_workspace_bytes(M, N)
+
+
+def colsum(Y, ldy, out, M, N, ws):
+    _dev(Y, out, ws)
+    _check(lib().dmi_colsum(_p(Y), ldy, _p(out), M, N, _p(ws), _stream()), "colsum")
+
+
+def transpose(inp, out, batch, R, C):
+    _dev(inp, out)
+    _check(lib().dmi_transpose_bf16(_p(inp), _p(out), batch, R, C, _stream()), "transpose")
+
+
+def transpose_strided(inp_ptr, out, nb, nh, R, C, sb, sh, sr):
+    """inp_ptr: raw device address (int) of element (0,0,0,0)."""
+    _dev(out)
+    _check(lib().dmi_transpose_bf16_strided(inp_ptr, _p(out), nb, nh, R, C, sb, sh, sr, _stream()), "transpose_strided")
+
+
+def attention_fwd(qkv, vt, o, lse, B, H, S):
+    _dev(qkv, vt, o, lse)
+    _check(lib().dmi_attention_fwd(_p(qkv), _p(vt), _p(o), _p(lse), B, H, S, _stream()), "attention_fwd")
+
+
+def attention_bwd(qkv, qt, kt, o, d_o, dot, lse, delta, dqkv, B, H, S):
+    _dev(qkv, qt, kt, o, d_o, dot, lse, delta, dqkv)
+    _check(lib().dmi_attention_bwd(_p(qkv), _p(qt), _p(kt), _p(o), _p(d_o), _p(dot), _p(lse), _p(delta), _p(dqkv),
+                                   B, H, S, _stream()), "attention_bwd")
+
+
+def shift_labels(tokens, labels, B, S, eos):
+    _dev(tokens, labels)
+    _check(lib().dmi_shift_labels(_p(tokens), _p(labels), B, S, eos, _stream()), "shift_labels")
+
+
+def cross_entropy(z, ldz, labels, loss_rows, lse, M, V, dz_scale):
+    _dev(z, labels, loss_rows)
+    _check(lib().dmi_cross_entropy(_p(z), ldz, _p(labels), _p(loss_rows), _p(lse), M, V, dz_scale, _stream()), "cross_entropy")
+
+
+def sum_f32(x, n, scale, out):
+    _dev(x, out)
+    _check(lib().dmi_sum_f32(_p(x), n, scale, _p(out), _stream()), "sum_f32")
+
+
+def assemble_tokens(text, vae_logits, tokens_out, B, T, P, C, text_vocab):
+    _dev(text, vae_logits, tokens_out)
+    _check(lib().dmi_assemble_tokens(_p(text), _p(vae_logits), _p(tokens_out), B, T, P, C, text_vocab, _stream()), "assemble_tokens")
+
+
+def sumsq_workspace_bytes(n):
+    return lib().dmi_sumsq_workspace_bytes(n)
+
+
+def sumsq(g, n, out, ws):
+    _dev(g, out, ws)
+    _check(lib().dmi_sumsq(_p(g), n, _p(out), _p(ws), _stream()), "sumsq")
+
+
+def adam_step(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, wd, grad_scale=1.0):
+    _dev(p, g, m, v)
+    _check(lib().dmi_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(gnorm_sq), clip, lr, beta1, beta2, eps,
+                               wd, grad_scale, _stream()), "adam_step")
+
+
+def cast_f32_bf16(inp, out, n):
+    _dev(inp, out)
+    _check(lib().dmi_cast_f32_bf16(_p(inp), _p(out), n, _stream()), "cast_f32_bf16")

@@ -1,0 +1,125 @@
+/* dalle_hip.h -- C ABI of libdalle_hip.so: the drop-in boundary for the DALL-E train-step hot path
+ * on MI355X (gfx950).  SURVEY.md §8(b): the reference (EleutherAI/DALLE-mtf) has NO FFI boundary;
+ * its arithmetic lives in mesh_tensorflow / tensorflow ops.  Each entry point below replaces one
+ * implicit third-party op of SURVEY.md §2.2 (K-rows) at the reference call site cited.
+ *
+ * Conventions (all entry points):
+ *   - raw DEVICE pointers + explicit sizes; the caller (PyTorch host code) owns every buffer incl.
+ *     workspace; nothing is allocated, freed or synchronised inside; everything is enqueued on the
+ *     hipStream_t passed last (as void*), so calls are stream-ordered and re-entrant.
+ *   - return 0 on success, negative dmi_status otherwise; dmi_last_error_string() is thread-local.
+ *   - "bf16" = raw uint16 bfloat16 bits.  Matrices are row-major with explicit leading dimensions.
+ *   - weights keep the reference layout [in, out]; the fwd GEMM consumes the
+ *     [out, in] bf16 copy produced by dmi_transpose_bf16 / dmi_adam_step.
+ */
+#ifndef DALLE_HIP_H
+#define DALLE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  DMI_OK = 0,
+  DMI_ERR_INVALID = -1,   /* bad size / alignment / null pointer */
+  DMI_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch */
+  DMI_ERR_UNSUPPORTED = -3
+} dmi_status;
+
+const char* dmi_last_error_string(void);
+int dmi_version(void);
+/* 1 if the kernel variant is compiled in / selected: name in {"glds","tn_trread"} */
+int dmi_get_option(const char* name);
+int dmi_set_option(const char* name, int value);
+
+/* ---- K1  embedding: mtf.gather(wte, tokens) + wpe[0..S)   src/dalle_mtf/models.py:186-219 ---- */
+int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
+                  int64_t rows /*B*S*/, int S, int d, int vocab, void* stream);
+/* backward: dwpe[s] = sum_b dx[b,s] (deterministic), dwte[tok] += dx (fp32 atomics; dwte must be
+ * zeroed by the caller).  gradient of mtf.gather = scatter-add. */
+int dmi_embed_bwd(const int32_t* tokens, const uint16_t* dx, float* dwte, float* dwpe,
+                  int B, int S, int d, int vocab, void* stream);
+
+/* ---- K2  LayerNorm eps=1e-5 biased variance   models.py:373-389, layers.py:30-33 ---- */
+int dmi_layernorm_fwd(const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y,
+                      float* mean, float* rstd, int64_t rows, int d, float eps, void* stream);
+/* dx_out = LNbwd(dy) (+ dres if non-null); dg/db fp32 [d] written (not accumulated).
+ * workspace: dmi_layernorm_bwd_workspace_bytes(rows, d). */
+int64_t dmi_layernorm_bwd_workspace_bytes(int64_t rows, int d);
+int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, const float* mean,
+                      const float* rstd, const uint16_t* dres, uint16_t* dx, float* dg, float* db,
+                      void* workspace, int64_t rows, int d, void* stream);
+
+/* ---- K3/K5/K6/K7  dense layers: mtf einsum / mtf.layers.dense   models.py:242-244,303-311,320-321,369,393
+ * C[M,N] = A[M,K] . Bt[N,K]^T  (both operands K-contiguous), bf16 in, fp32 accumulate on MFMA.
+ * flags: DMI_GEMM_*;  bias bf16 [N];  residual bf16 [M,ldc] added;  relu_src bf16 [M,ldc]: C *= (relu_src>0).
+ * K % 64 == 0, N % 8 == 0.  Output bf16 (or fp32 with DMI_GEMM_OUT_F32). */
+#define DMI_GEMM_BIAS 1
+#define DMI_GEMM_RELU 2
+#define DMI_GEMM_RESIDUAL 4
+#define DMI_GEMM_RELU_MASK 8
+#define DMI_GEMM_OUT_F32 16
+int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc,
+                int M, int N, int K, int flags, const uint16_t* bias, const uint16_t* residual,
+                const uint16_t* relu_src, void* stream);
+/* weight gradient: dW[I,J] (fp32, ld = J) = sum_m X[m,I] * dY[m,J]; deterministic split over m.
+ * workspace: dmi_gemm_tn_workspace_bytes(M, I, J). */
+int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J);
+int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, int M, int I, int J,
+                void* workspace, void* stream);
+/* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
+int64_t dmi_colsum_workspace_bytes(int64_t M, int N);
+int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int N, void* workspace, void* stream);
+/* batched bf16 transpose: in [batch, R, C] -> out [batch, C, R] */
+int dmi_transpose_bf16(const uint16_t* in, uint16_t* out, int batch, int R, int C, void* stream);
+/* strided form: element (b,h,r,c) read at in + b*in_b_stride + h*in_h_stride + r*in_r_stride + c,
+ * written at out[((b*nh + h)*C + c)*R + r]   (per-head transposes of q/k/v/d_o for the attention kernels) */
+int dmi_transpose_bf16_strided(const uint16_t* in, uint16_t* out, int nb, int nh, int R, int C,
+                               int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride, void* stream);
+
+/* ---- K4  causal attention, UNSCALED logits, fp32 softmax   models.py:221-227,292-299 (Appendix A.2/A.3)
+ * qkv [B*S, 3*H*128] bf16 = the QKV projection output, row = [q | k | v] x [H, 128] (heads-major, A.1);
+ * vt = v transposed per head [B,H,128,S] (dmi_transpose_bf16_strided);  o [B*S, H*128] bf16;  lse [B,H,S] fp32.
+ * head dim is fixed at 128 (README.md:164 "n_embd / n_heads should equal 128"); S % 8 == 0. */
+int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16_t* o, float* lse,
+                      int B, int H, int S, void* stream);
+/* backward.  d_o [B*S, H*128] bf16; qt / kt / dot = per-head transposed copies [B,H,128,S] of q, k, d_o.
+ * delta [B,H,S] fp32 scratch.  dqkv [B*S, 3*H*128] bf16 in the qkv layout (what the QKV dgrad/wgrad GEMMs consume). */
+int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
+                      const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
+                      uint16_t* dqkv, int B, int H, int S, void* stream);
+
+/* ---- K7/K8  cross entropy over bf16 logits, labels = shift(tokens)   models.py:348-359,407-410
+ * logits z [M, ldz] bf16 (ldz >= V, pad columns must hold a large negative value).
+ * labels[t] = tokens[t+1], last = eos (bit-exact int path).  loss_rows[M] fp32 = lse - z[label];
+ * if dz_scale != 0: z is overwritten IN PLACE by dz = (softmax(z) - onehot(label)) * dz_scale. */
+int dmi_shift_labels(const int32_t* tokens, int32_t* labels, int B, int S, int eos, void* stream);
+int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, float* loss_rows, float* lse,
+                      int64_t M, int V, float dz_scale, void* stream);
+/* out[0] = scale * sum(x[0..n))  deterministic single-block reduce (loss mean; grad-norm finish) */
+int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream);
+
+/* ---- K10  image-token indexing   src/model_fns.py:76-77,118-119 (bit-exact)
+ * tokens_out[b, 0:T] = text[b]; tokens_out[b, T + p] = argmax_c logits[b, p, c] (first max) + text_vocab */
+int dmi_assemble_tokens(const int32_t* text, const float* vae_logits, int32_t* tokens_out,
+                        int B, int T, int P, int C, int text_vocab, void* stream);
+
+/* ---- K9  clip_by_global_norm + AdamWeightDecayOptimizer   src/optimizers.py:11-16,82-89,154-177
+ * sumsq: out[0] = sum g^2 (deterministic two-stage; workspace dmi_sumsq_workspace_bytes(n)).
+ * adam: mult = clip>0 ? clip/max(sqrt(*gnorm_sq),clip) : 1;  g*=mult; m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;
+ *       p -= lr*(m/(sqrt(v)+eps) + wd*p)   (NO bias correction); p_bf16 (optional) = bf16(p).
+ * tf_adam=1 switches to tf.train.AdamOptimizer semantics (bias-corrected lr_t passed as lr, eps as given,
+ * grad_scale multiplies g first: CrossShardOptimizer mean) -- src/model_fns_tf.py:58-61. */
+int64_t dmi_sumsq_workspace_bytes(int64_t n);
+int dmi_sumsq(const float* g, int64_t n, float* out, void* workspace, void* stream);
+int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
+                  const float* gnorm_sq, float clip, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float grad_scale, void* stream);
+
+/* fp32 -> bf16 cast (initial weight export) */
+int dmi_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

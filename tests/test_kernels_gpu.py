@@ -1,0 +1,330 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point vs plain fp32 math on the SAME bf16-rounded
+inputs (so the only differences are accumulation order and the final bf16 rounding).
+Tolerances: bf16 outputs rtol 1.6e-2 (2 ulp of bf16) + small atol; fp32 outputs 2e-3 relative to the
+contraction's magnitude; integer paths bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import dalle_hip as dh  # noqa: E402  (path set up by conftest)
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} out of tol; max err {float(err.max()):.4g} " \
+                          f"at ref {float(ref.flatten()[err.argmax()]):.4g}; ref rms {float(ref.pow(2).mean().sqrt()):.4g}"
+
+
+def ws(nbytes):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=DEV)
+
+
+# ------------------------------------------------------------------ embedding
+
+def test_embed_fwd_bwd():
+    B, S, d, V = 3, 40, 512, 1000
+    g = torch.Generator().manual_seed(1)
+    tok = torch.randint(0, V, (B, S), generator=g, dtype=torch.int32)
+    tok[:, -7:] = 5  # repeated ids -> atomic collisions
+    wte, wpe = rnd(V, d, scale=0.02, seed=2), rnd(S, d, scale=0.01, seed=3)
+    x = torch.empty(B * S, d, dtype=torch.bfloat16, device=DEV)
+    dh.embed_fwd(tok.to(DEV), wte.to(DEV), wpe.to(DEV), x, S, d, V)
+    ref = wte.float()[tok.long()] + wpe.float()[None, :S]
+    close(x.view(B, S, d), ref, 8e-3, 1e-6, "embed_fwd")
+    dx = rnd(B * S, d, seed=4)
+    dwte = torch.zeros(V, d, dtype=torch.float32, device=DEV)
+    dwpe = torch.empty(S, d, dtype=torch.float32, device=DEV)
+    dh.embed_bwd(tok.to(DEV), dx.to(DEV), dwte, dwpe, B, S, d, V)
+    ref_wte = torch.zeros(V, d).index_add_(0, tok.view(-1).long(), dx.float())
+    close(dwte, ref_wte, 1e-5, 1e-5, "embed_bwd wte")
+    close(dwpe, dx.float().view(B, S, d).sum(0), 1e-5, 1e-5, "embed_bwd wpe")
+
+
+# ------------------------------------------------------------------ layernorm
+
+@pytest.mark.parametrize("rows,d", [(7, 512), (130, 1024), (66, 2048), (5, 256)])
+def test_layernorm_fwd_bwd(rows, d):
+    x, g, b = rnd(rows, d, seed=1), bf(1 + 0.1 * torch.randn(d)), bf(0.1 * torch.randn(d))
+    y = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    mean = torch.empty(rows, dtype=torch.float32, device=DEV)
+    rstd = torch.empty(rows, dtype=torch.float32, device=DEV)
+    dh.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), y, mean, rstd, rows, d)
+    xf = x.float().requires_grad_(True)
+    gf, bff = g.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = F.layer_norm(xf, (d,), gf, bff, 1e-5)
+    close(y, ref.detach(), 1e-2, 1e-2, "ln_fwd")
+    close(mean, x.float().mean(-1), 1e-5, 1e-5, "ln mean")
+    dy = rnd(rows, d, seed=5)
+    dres = rnd(rows, d, seed=6)
+    ref.backward(dy.float())
+    dx = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    dg = torch.empty(d, dtype=torch.float32, device=DEV)
+    db = torch.empty(d, dtype=torch.float32, device=DEV)
+    w = ws(dh.layernorm_bwd_workspace_bytes(rows, d))
+    dh.layernorm_bwd(dy.to(DEV), x.to(DEV), g.to(DEV), mean, rstd, dres.to(DEV), dx, dg, db, w, rows, d)
+    close(dx, xf.grad + dres.float(), 1.6e-2, 2e-2, "ln_bwd dx")
+    close(dg, gf.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln_bwd dg")
+    close(db, bff.grad, 1e-3, 1e-3 * math.sqrt(rows), "ln_bwd db")
+    dx2 = torch.empty_like(dx)
+    dh.layernorm_bwd(dy.to(DEV), x.to(DEV), g.to(DEV), mean, rstd, None, dx2, dg, db, w, rows, d)
+    close(dx2, xf.grad, 1.6e-2, 2e-2, "ln_bwd dx (no residual)")
+
+
+# ------------------------------------------------------------------ GEMMs
+
+def _gemm_ref(A, Bt, bias=None, relu=False, residual=None, relu_src=None):
+    C = A.float() @ Bt.float().t()
+    if bias is not None:
+        C = C + bias.float()
+    if relu:
+        C = torch.relu(C)
+    if residual is not None:
+        C = C + residual.float()
+    if relu_src is not None:
+        C = C * (relu_src.float() > 0)
+    return C
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1024, 512, 512), (257, 1160, 192)])
+def test_gemm_nt_plain(glds, M, N, K):
+    dh.set_option("glds", glds)
+    try:
+        A, Bt = rnd(M, K, seed=1), rnd(N, K, seed=2)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K)
+        close(C, _gemm_ref(A, Bt), 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt glds={glds}")
+    finally:
+        dh.set_option("glds", 1)
+
+
+@pytest.mark.parametrize("glds", [1, 0])
+def test_gemm_nt_epilogues(glds):
+    dh.set_option("glds", glds)
+    try:
+        M, N, K = 384, 640, 256
+        A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
+        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+        hsrc = torch.relu(rnd(M, N, seed=5))
+        Ad, Bd = A.to(DEV), Bt.to(DEV)
+        tol = dict(rtol=1.6e-2, atol=2e-2)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS, bias=bias.to(DEV))
+        close(C, _gemm_ref(A, Bt, bias), what="bias", **tol)
+        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RELU, bias=bias.to(DEV))
+        close(C, _gemm_ref(A, Bt, bias, relu=True), what="bias+relu", **tol)
+        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=bias.to(DEV), residual=res.to(DEV))
+        close(C, _gemm_ref(A, Bt, bias, residual=res), what="bias+residual", **tol)
+        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_RELU_MASK, relu_src=hsrc.to(DEV))
+        close(C, _gemm_ref(A, Bt, relu_src=hsrc), what="relu mask", **tol)
+        Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+        dh.gemm_nt(Ad, K, Bd, K, Cf, N, M, N, K, dh.GEMM_OUT_F32)
+        close(Cf, _gemm_ref(A, Bt), 1e-3, 1e-3, "f32 out")
+        # strided operands (lda > K): the QKV-style slices
+        A2 = rnd(M, 3 * K, seed=7)
+        dh.gemm_nt(A2.to(DEV)[:, K:], 3 * K, Bd, K, C, N, M, N, K)
+        close(C, _gemm_ref(A2[:, K:2 * K], Bt), what="strided A", **tol)
+    finally:
+        dh.set_option("glds", 1)
+
+
+@pytest.mark.parametrize("trread", [1, 0])
+@pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160)])
+def test_gemm_tn(trread, M, I, J):
+    dh.set_option("tn_trread", trread)
+    try:
+        X, dY = rnd(M, I, seed=1), rnd(M, J, seed=2)
+        dW = torch.full((I, J), 7.0, dtype=torch.float32, device=DEV)
+        w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
+        dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW, M, I, J, w)
+        ref = X.float().t() @ dY.float()
+        close(dW, ref, 2e-3, 2e-3 * math.sqrt(M), f"gemm_tn trread={trread}")
+    finally:
+        dh.set_option("tn_trread", 1)
+
+
+def test_colsum_and_transpose():
+    M, N = 1000, 520
+    Y = rnd(M, N, seed=1)
+    out = torch.empty(N, dtype=torch.float32, device=DEV)
+    dh.colsum(Y.to(DEV), N, out, M, N, ws(dh.colsum_workspace_bytes(M, N)))
+    close(out, Y.float().sum(0), 1e-4, 1e-3, "colsum")
+    X = rnd(3, 72, 200, seed=2)
+    T = torch.zeros(3, 200, 72, dtype=torch.bfloat16, device=DEV)
+    dh.transpose(X.to(DEV), T, 3, 72, 200)
+    assert torch.equal(T.cpu(), X.transpose(1, 2).contiguous()), "transpose"
+    # strided per-head transpose: qkv [B*S, 3d] -> vt [B,H,128,S]
+    B, S, H = 2, 48, 3
+    d = H * 128
+    qkv = rnd(B * S, 3 * d, seed=3).to(DEV)
+    vt = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
+    dh.transpose_strided(qkv.data_ptr() + 2 * d * 2, vt, B, H, S, 128, S * 3 * d, 128, 3 * d)
+    ref = qkv.cpu().view(B, S, 3, H, 128)[:, :, 2].permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(vt.cpu(), ref), "strided transpose"
+
+
+# ------------------------------------------------------------------ attention
+
+def _attn_ref(qkv, B, H, S):
+    d = H * 128
+    t = qkv.float().view(B, S, 3, H, 128)
+    q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))  # [B,H,S,128]
+    logits = q @ k.transpose(-1, -2)
+    mask = torch.triu(torch.ones(S, S, dtype=torch.bool), 1)
+    logits = logits.masked_fill(mask, float("-inf"))
+    lse = torch.logsumexp(logits, -1)
+    o = torch.softmax(logits, -1) @ v
+    return o.permute(0, 2, 1, 3).reshape(B * S, d), lse
+
+
+def _transposes(qkv, B, H, S):
+    d = H * 128
+    outs = []
+    for i in range(3):
+        t = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
+        dh.transpose_strided(qkv.data_ptr() + i * d * 2, t, B, H, S, 128, S * 3 * d, 128, 3 * d)
+        outs.append(t)
+    return outs
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 2, 384), (1, 1, 72)])
+def test_attention_fwd_bwd(B, H, S):
+    d = H * 128
+    # q small (the reference folds 1/sqrt(k) into Wq's init), k/v O(1): logits O(1)
+    g = torch.Generator().manual_seed(S)
+    qkv = torch.randn(B * S, 3, H, 128, generator=g)
+    qkv[:, 0] *= 0.12
+    qkv = qkv.view(B * S, 3 * d).to(torch.bfloat16)
+    qkv_d = qkv.to(DEV)
+    qt, kt, vt = _transposes(qkv_d, B, H, S)
+    o = torch.zeros(B * S, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(B, H, S, dtype=torch.float32, device=DEV)
+    dh.attention_fwd(qkv_d, vt, o, lse, B, H, S)
+    qr = qkv.float().requires_grad_(True)
+    o_ref, lse_ref = _attn_ref(qr, B, H, S)
+    close(lse, lse_ref.detach(), 2e-3, 2e-3, "attn lse")
+    close(o, o_ref.detach(), 1.6e-2, 1.5e-2, "attn fwd o")
+    d_o = rnd(B * S, d, seed=9)
+    o_ref.backward(d_o.float())
+    d_o_d = d_o.to(DEV)
+    dot = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
+    dh.transpose_strided(d_o_d.data_ptr(), dot, B, H, S, 128, S * d, 128, d)
+    delta = torch.zeros(B, H, S, dtype=torch.float32, device=DEV)
+    dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device=DEV)
+    dh.attention_bwd(qkv_d, qt, kt, o, d_o_d, dot, lse, delta, dqkv, B, H, S)
+    gref = qr.grad.view(B * S, 3, d)
+    got = dqkv.float().cpu().view(B * S, 3, d)
+    for i, nm in enumerate("qkv"):
+        scale = float(gref[:, i].abs().max())
+        close(got[:, i], gref[:, i], 3e-2, 2e-2 * scale, f"attn bwd d{nm}")
+
+
+def test_attention_row0_kat():
+    """causal mask: query 0 attends only to key 0 -> o[0] == v[0] exactly (bf16 round trip)."""
+    B, H, S = 1, 1, 128
+    qkv = rnd(S, 3 * 128, seed=11).to(DEV)
+    _, _, vt = _transposes(qkv, B, H, S)
+    o = torch.zeros(S, 128, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(1, 1, S, dtype=torch.float32, device=DEV)
+    dh.attention_fwd(qkv, vt, o, lse, B, H, S)
+    assert torch.equal(o[0].cpu(), qkv[0, 256:].cpu())
+
+
+# ------------------------------------------------------------------ cross entropy, labels, tokens
+
+def test_shift_labels_and_assemble_tokens_bit_exact():
+    from oracle import dalle_oracle as do
+    B, T, P, C = 3, 16, 9, 37
+    g = torch.Generator().manual_seed(3)
+    text = torch.randint(0, 100, (B, T), generator=g, dtype=torch.int32)
+    logits = torch.randn(B, P, C, generator=g)
+    logits[0, 0, 5] = logits[0, 0, 9] = 50.0     # tie -> first index
+    logits[1, 2, :] = 0.25                        # all equal -> 0
+    out = torch.zeros(B, T + P, dtype=torch.int32, device=DEV)
+    dh.assemble_tokens(text.to(DEV), logits.to(DEV), out, B, T, P, C, 100)
+    ref = do.assemble_tokens(text.numpy(), do.image_tokens_from_logits(logits.numpy().reshape(B, 3, 3, C)), 100)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    lab = torch.zeros_like(out)
+    dh.shift_labels(out, lab, B, T + P, 999)
+    assert np.array_equal(lab.cpu().numpy(), do.shift_labels(ref, 999))
+
+
+@pytest.mark.parametrize("M,V,ld", [(5, 1000, 1024), (64, 777, 784), (3, 50771, 50816)])
+def test_cross_entropy(M, V, ld):
+    g = torch.Generator().manual_seed(V)
+    z = torch.full((M, ld), -30000.0)
+    z[:, :V] = torch.randn(M, V, generator=g) * 2
+    z = z.to(torch.bfloat16)
+    labels = torch.randint(0, V, (M,), generator=g, dtype=torch.int32)
+    zd = z.to(DEV).clone()
+    loss_rows = torch.zeros(M, dtype=torch.float32, device=DEV)
+    lse = torch.zeros(M, dtype=torch.float32, device=DEV)
+    scale = 1.0 / 1234.0
+    dh.cross_entropy(zd, ld, labels.to(DEV), loss_rows, lse, M, V, scale)
+    zf = z.float()[:, :V].requires_grad_(True)
+    ref = F.cross_entropy(zf, labels.long(), reduction="none")
+    close(loss_rows, ref.detach(), 1e-4, 1e-4, "ce loss")
+    (ref.sum() * scale).backward()
+    close(zd[:, :V], zf.grad, 1e-2, 1e-7, "ce dz")
+    assert float(zd[:, V:].float().abs().max()) == 0.0 if ld > V else True
+    tot = torch.zeros(1, dtype=torch.float32, device=DEV)
+    dh.sum_f32(loss_rows, M, 1.0 / M, tot)
+    assert abs(float(tot) - float(ref.mean())) < 1e-4
+
+
+def test_uniform_logits_loss_is_log_v():
+    M, V, ld = 4, 512, 512
+    z = torch.zeros(M, ld, dtype=torch.bfloat16, device=DEV)
+    labels = torch.arange(M, dtype=torch.int32, device=DEV)
+    loss_rows = torch.zeros(M, dtype=torch.float32, device=DEV)
+    dh.cross_entropy(z, ld, labels, loss_rows, None, M, V, 0.0)
+    assert torch.allclose(loss_rows.cpu(), torch.full((M,), math.log(V)), atol=1e-5)
+
+
+# ------------------------------------------------------------------ optimizer
+
+def test_sumsq_adam_cast():
+    from oracle import dalle_oracle as do
+    from collections import OrderedDict
+    n = 100003
+    g = torch.Generator().manual_seed(0)
+    p, gr = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01
+    m, v = torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 1e-4
+    pad = (-n) % 4
+    pd, gd, md, vd = (torch.cat([t, torch.zeros(pad)]).to(DEV) for t in (p, gr, m, v))
+    out = torch.zeros(1, dtype=torch.float32, device=DEV)
+    dh.sumsq(gd, n, out, ws(dh.sumsq_workspace_bytes(n)))
+    assert abs(float(out) - float((gr.double() ** 2).sum())) < 1e-4 * float((gr.double() ** 2).sum())
+    pb = torch.zeros(n + pad, dtype=torch.bfloat16, device=DEV)
+    dh.adam_step(pd, gd, md, vd, pb, n, out, 1.0, 1e-3, 0.9, 0.999, 1e-6, 0.01, 1.0)
+    P = OrderedDict(w=p.numpy().copy()); G = OrderedDict(w=gr.numpy().copy())
+    Mm = OrderedDict(w=m.numpy().copy()); Vv = OrderedDict(w=v.numpy().copy())
+    Gc, gn = do.clip_by_global_norm(G, 1.0)
+    do.adam_step(P, Gc, Mm, Vv, 1e-3, 0.9, 0.999, 1e-6, 0.01)
+    assert np.allclose(pd.cpu().numpy()[:n], P["w"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(md.cpu().numpy()[:n], Mm["w"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(vd.cpu().numpy()[:n], Vv["w"], rtol=1e-5, atol=1e-9)
+    assert torch.equal(pb[:n].cpu(), pd[:n].cpu().to(torch.bfloat16))
+    c = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
+    dh.cast_f32_bf16(pd, c, n)
+    assert torch.equal(c.cpu(), pd[:n].cpu().to(torch.bfloat16))
