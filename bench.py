@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- headline metric of BASELINE.json: train tokens/sec (text+image) per node on the
+`dalle_example` transformer step (n_embd=512, 6 layers, 4 heads, seq 256+1024, bf16 compute),
+synthetic captions + synthetic image-token ids, B=32 per GPU (weak scaling), one process per GPU.
+
+A "step" = forward + backward + gradient all-reduce (RCCL, N>1) + global-norm clip + Adam, nothing skipped.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 (contract in the task
+statement) with two extra objects:
+  roofline     -- the vocabulary-projection GEMM launch (largest single launch of the step; kernel
+                  gemm_nt_kernel): algorithmic FLOPs 2*M*d*V per launch / mean launch duration measured live
+                  with HIP events on the launch stream inside the timed region, against the 2.5 PFLOP/s dense
+                  bf16 MFMA peak; plus the whole-step MFMA fraction (train FLOPs of SURVEY.md §8(d)).
+  cpu_baseline -- the CPU oracle (a restatement of the reference, NOT mesh-tensorflow, which cannot run
+                  here) timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "dalle-mtf_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+CFG = dict(n_embd=512, n_layers=6, n_heads=4, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256,
+           image_seq_len=1024)
+HP = dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0)
+PER_GPU_BATCH = 32
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def fwd_flops_per_token(d, L, S, V):
+    return L * (24 * d * d + 4 * S * d) + 2 * d * V
+
+
+def synth_tokens(B, T, P, text_vocab, image_vocab, seed):
+    rng = np.random.default_rng(seed)
+    pad = text_vocab - 1
+    out = np.full((B, T + P), pad, dtype=np.int32)
+    for b in range(B):
+        n = int(rng.integers(1, T + 1))
+        out[b, :n] = rng.integers(0, pad, size=n, dtype=np.int32)
+    out[:, T:] = rng.integers(0, image_vocab, size=(B, P), dtype=np.int32) + text_vocab
+    return out
+
+
+def cpu_baseline(budget_s=20.0):
+    """Oracle train step (fwd+bwd via autograd, clip, Adam) on the host cores; B=1, S=1280 sample."""
+    from oracle import dalle_oracle as do
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = do.DalleConfig(CFG["n_embd"], CFG["text_vocab_size"], CFG["image_vocab_size"], CFG["text_seq_len"],
+                         CFG["image_seq_len"], CFG["n_layers"], CFG["n_heads"])
+    P = do.init_params(cfg, seed=1234)
+    m = {k: np.zeros_like(v) for k, v in P.items()}
+    v = {k: np.zeros_like(v) for k, v in P.items()}
+    tokens = synth_tokens(1, cfg.text_seq_len, cfg.image_seq_len, cfg.text_vocab_size, cfg.image_vocab_size, 7)
+    do.train_step(P, m, v, tokens, cfg, 1, HP)  # warm-up (allocator, thread pool)
+    t0 = time.time()
+    n = 0
+    while True:
+        do.train_step(P, m, v, tokens, cfg, 2 + n, HP)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = (time.time() - t0) / n
+    S = cfg.total_seq_dim
+    return {"value": S / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of B=1 x S={S} (dalle_example weights, fp32 PyTorch-CPU oracle, "
+                      f"{torch.get_num_threads()} threads), {dt:.2f} s/step",
+            "note": "CPU restatement of the reference; the mesh-tensorflow reference itself cannot run here"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (weak scaling)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        # convenience: re-launch ourselves under torch.distributed.run
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), __file__] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pg = dist.group.WORLD
+
+    from src.dalle_mtf.engine import DalleEngine
+    B = args.batch
+    eng = DalleEngine(CFG["n_embd"], CFG["n_layers"], CFG["n_heads"], CFG["text_vocab_size"], CFG["image_vocab_size"],
+                      CFG["text_seq_len"], CFG["image_seq_len"], batch_size=B, global_batch_size=B * world, hparams=HP,
+                      process_group=pg, world_size=world)
+    eng.init_params(seed=1234)
+    if world > 1:
+        dist.broadcast(eng.p, src=0)
+        eng.refresh_compute_copies(cast=True)
+    S, T, P = eng.S, eng.T, eng.S - eng.T
+    batches = [torch.from_numpy(synth_tokens(B, T, P, CFG["text_vocab_size"], CFG["image_vocab_size"], 1000 * rank + i)).cuda()
+               for i in range(4)]
+    eng.global_step = 3000  # past warm-up so the update is non-trivial
+    evs = []
+    eng.event_hook = lambda: evs  # the engine records (start, end) events around the vocab-projection GEMM
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.train_step(batches[i % 4])
+    sync()
+    evs.clear()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(batches[i % 4])
+    sync()
+    dt = time.perf_counter() - t0
+    loss = float(eng.loss.item())
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        tokens_per_s = B * world * S * args.steps / dt
+        d, L, V = CFG["n_embd"], CFG["n_layers"], eng.V
+        train_flops_step_gpu = 3 * fwd_flops_per_token(d, L, S, V) * B * S
+        gemm_flops = 2.0 * B * S * d * V
+        k_ms = [a.elapsed_time(b) for a, b in evs]
+        k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
+        achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
+        out = {
+            "metric": "train tokens/sec (text+image) per node, dalle_example", "value": tokens_per_s, "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs/dalle_example.json transformer train step (n_embd=512, 6 layers, 4 heads, "
+                                   "seq 256+1024, V=50771), synthetic captions + synthetic image-token ids",
+                       "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
+                       "final_loss": loss},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (vocabulary projection M=B*S, N=50816, K=512)",
+                         "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": None,
+                         "launch_ms": k_avg, "launches_timed": len(k_ms),
+                         "step_mfma_frac": train_flops_step_gpu / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                         "step_tflops_per_gpu": train_flops_step_gpu / (ms * 1e-3) / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

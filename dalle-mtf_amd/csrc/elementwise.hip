@@ -100,6 +100,76 @@ extern "C" int dmi_embed_bwd(const int32_t* tokens, const uint16_t* dx, float* d
   return DMI_OK;
 }
 
+// Sorted scatter-add: positions are visited in token-id order (sorted_tok ascending, perm = source row).
+// One wave per chunk of 32 sorted positions accumulates each run of equal ids in registers; a run that
+// lies entirely inside the chunk is stored directly (single writer), only runs crossing a chunk border
+// use fp32 atomics -> the hot padding id costs n/32 atomics per column instead of n.
+#define EB_CH 32
+__global__ __launch_bounds__(256) void embed_bwd_wte_sorted_kernel(const int* __restrict__ sorted_tok,
+                                                                   const int* __restrict__ perm,
+                                                                   const bf16_t* __restrict__ dx,
+                                                                   float* __restrict__ dwte, int64_t n, int d,
+                                                                   int vocab) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t i0 = chunk * EB_CH;
+  if (i0 >= n) return;
+  const int64_t i1 = (i0 + EB_CH < n) ? i0 + EB_CH : n;
+  const int first_tok = sorted_tok[i0];
+  const bool head_open = (i0 > 0) && (sorted_tok[i0 - 1] == first_tok);
+  for (int c = lane; c < d / 8; c += 64) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cur = first_tok;
+    bool open = head_open;
+    for (int64_t i = i0; i < i1; ++i) {
+      const int t = sorted_tok[i];
+      if (t != cur) {
+        const int tc = cur < 0 ? 0 : (cur >= vocab ? vocab - 1 : cur);
+        float* dst = dwte + (int64_t)tc * d + c * 8;
+        if (open) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dst + j, acc[j]);
+        } else {
+          *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
+          *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        cur = t;
+        open = false;
+      }
+      float f[8];
+      unpack8(*(const u32x4*)(dx + (int64_t)perm[i] * d + c * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    const bool tail_open = (i1 < n) && (sorted_tok[i1] == cur);
+    const int tc = cur < 0 ? 0 : (cur >= vocab ? vocab - 1 : cur);
+    float* dst = dwte + (int64_t)tc * d + c * 8;
+    if (open || tail_open) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dst + j, acc[j]);
+    } else {
+      *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
+      *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    }
+  }
+}
+
+extern "C" int dmi_embed_bwd_sorted(const int32_t* sorted_tokens, const int32_t* perm, const uint16_t* dx, float* dwte,
+                                    float* dwpe, int B, int S, int d, int vocab, void* stream) {
+  DMI_REQUIRE(sorted_tokens && perm && dx && dwte && dwpe, "embed_bwd_sorted: null pointer");
+  DMI_REQUIRE(d % 8 == 0 && B > 0 && S > 0, "embed_bwd_sorted: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  embed_bwd_wpe_kernel<<<dim3((S + 3) / 4), dim3(256), 0, st>>>(dx, dwpe, B, S, d);
+  DMI_CHECK_LAUNCH("embed_bwd_wpe");
+  const int64_t n = (int64_t)B * S;
+  const int64_t chunks = cdiv64(n, EB_CH);
+  embed_bwd_wte_sorted_kernel<<<dim3((unsigned)cdiv64(chunks, 4)), dim3(256), 0, st>>>(sorted_tokens, perm, dx, dwte, n, d, vocab);
+  DMI_CHECK_LAUNCH("embed_bwd_wte_sorted");
+  return DMI_OK;
+}
+
 // =====================================================================================
 // K2 LayerNorm (src/dalle_mtf/models.py:373-389, layers.py:30-33): biased variance of the
 // centred row, eps inside rsqrt.  One wave per row, row cached in registers (d <= 512*NC).
@@ -530,7 +600,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__
   }
   if (dz_scale == 0.f) return;
   __syncthreads();  // tid 0 read z[label] before anyone overwrites it
-  for (int c = tid; c < nch; c += 256) {
+  for (int c = tid; c < ldz / 8; c += 256) {  // every column of the row incl. the pad: dz[pad] = 0
     float f[8];
     unpack8(*(const u32x4*)(zr + c * 8), f);
 #pragma unroll

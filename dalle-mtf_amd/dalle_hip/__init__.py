@@ -53,6 +53,7 @@ def _declare(L):
         "dmi_set_option": (I, [c_char_p, I]),
         "dmi_embed_fwd": (I, [P, P, P, P, L64, I, I, I, P]),
         "dmi_embed_bwd": (I, [P, P, P, P, I, I, I, I, P]),
+        "dmi_embed_bwd_sorted": (I, [P, P, P, P, P, I, I, I, I, P]),
         "dmi_layernorm_fwd": (I, [P, P, P, P, P, P, L64, I, F, P]),
         "dmi_layernorm_bwd_workspace_bytes": (L64, [L64, I]),
         "dmi_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L64, I, P]),
@@ -118,6 +119,12 @@ def embed_fwd(tokens, wte, wpe, x, S, d, vocab):
 def embed_bwd(tokens, dx, dwte, dwpe, B, S, d, vocab):
     _dev(tokens, dx, dwte, dwpe)
     _check(lib().dmi_embed_bwd(_p(tokens), _p(dx), _p(dwte), _p(dwpe), B, S, d, vocab, _stream()), "embed_bwd")
+
+
+def embed_bwd_sorted(sorted_tokens, perm, dx, dwte, dwpe, B, S, d, vocab):
+    _dev(sorted_tokens, perm, dx, dwte, dwpe)
+    _check(lib().dmi_embed_bwd_sorted(_p(sorted_tokens), _p(perm), _p(dx), _p(dwte), _p(dwpe), B, S, d, vocab, _stream()),
+           "embed_bwd_sorted")
 
 
 def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps=1e-5):

@@ -1,0 +1,429 @@
+"""DalleEngine -- sequences the HIP kernels of libdalle_hip into the DALL-E train step.
+
+Replaces, for the hot path, what the reference obtains from Mesh-TensorFlow's graph + lowering
+(src/model_fns.py:80-94,168-202 -> mtf.Graph / mtf.Lowering) and its optimizer
+(src/optimizers.py:19-104): forward (src/dalle_mtf/models.py:397-416), a hand-written backward,
+global-norm clip + Adam without bias correction, and the data-parallel gradient all-reduce that mtf
+inserts implicitly for `layout: batch_dim:data` -- here RCCL via
+torch.distributed, bucketed and overlapped with backward on the collective's own stream.
+
+PyTorch is plumbing only (device memory, streams, torch.distributed); all arithmetic runs in the
+hand-written kernels behind the C ABI.  There is no CPU fallback.
+
+Memory plan (HBM, per GPU): parameters live in ONE flat fp32 buffer (+ flat grads, Adam m, v) laid out in
+reverse-usage order [to_logits | layer_{L-1} .. layer_0 | wpe | wte] so finished gradients always form
+a contiguous prefix (= all-reduce buckets).  bf16 compute copies: `pb` (same offsets, natural [in,out]
+layout, written by the Adam kernel) and `pbt` ([out,in] copies of the GEMM weights for the forward).
+Activations needed by backward are kept in bf16 per layer (no recompute; 288 GB HBM).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+import dalle_hip as dh
+
+HEAD_DIM = 128
+ALIGN = 128  # elements
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class ParamLayout:
+    """Flat layout of the trainable variables.  Internal tensors fuse q|k|v into one [d, 3d] matrix and
+    pad the vocabulary axis of the output projection to a multiple of 128; `export`/`load` translate
+    to/from the reference's variable names and shapes."""
+
+    def __init__(self, n_embd, n_layers, n_heads, total_tokens, total_seq):
+        d, L, V, S = n_embd, n_layers, total_tokens, total_seq
+        self.d, self.L, self.V, self.S = d, L, V, S
+        self.Vp = _round_up(V, 128)
+        ent: List[Tuple[str, tuple]] = []
+        ent += [("to_logits/linear_out/kernel", (d, self.Vp)), ("to_logits/linear_out/bias", (self.Vp,)),
+                ("to_logits/layer_norm/g", (d,)), ("to_logits/layer_norm/b", (d,))]
+        for i in reversed(range(L)):
+            p = f"layer_{i}/"
+            ent += [(p + "mlp/mlp_linear_2/kernel", (4 * d, d)), (p + "mlp/mlp_linear_2/bias", (d,)),
+                    (p + "mlp/mlp_linear_1/kernel", (d, 4 * d)), (p + "mlp/mlp_linear_1/bias", (4 * d,)),
+                    (p + "norm_2/g", (d,)), (p + "norm_2/b", (d,)),
+                    (p + "attn/o", (d, d)), (p + "attn/compute_output_bias/o_b", (d,)),
+                    (p + "attn/qkv", (d, 3 * d)),
+                    (p + "norm_1/g", (d,)), (p + "norm_1/b", (d,))]
+        ent += [("positional_embedding/wpe", (S, d)), ("embedding/wte", (V, d))]
+        self.entries = ent
+        self.offset: Dict[str, int] = {}
+        self.shape: Dict[str, tuple] = {}
+        off = 0
+        for name, shp in ent:
+            self.offset[name] = off
+            self.shape[name] = shp
+            off += _round_up(int(np.prod(shp)), ALIGN)
+        self.total = off
+        # transposed ([out, in]) bf16 copies consumed by the forward GEMMs
+        self.t_offset: Dict[str, int] = {}
+        toff = 0
+        for name, shp in ent:
+            if len(shp) == 2 and ("kernel" in name or "attn/" in name):
+                self.t_offset[name] = toff
+                toff += _round_up(int(np.prod(shp)), ALIGN)
+        self.t_total = toff
+        # bucket boundaries (prefix ends) in element offsets: after head, after each layer, end
+        self.bucket_ends: List[int] = []
+        self.bucket_ends.append(self.offset[f"layer_{L-1}/mlp/mlp_linear_2/kernel"] if L > 0 else self.offset["positional_embedding/wpe"])
+        for i in reversed(range(L)):
+            nxt = f"layer_{i-1}/mlp/mlp_linear_2/kernel" if i > 0 else "positional_embedding/wpe"
+            self.bucket_ends.append(self.offset[nxt])
+        self.bucket_ends.append(self.total)
+
+    def numel(self, name):
+        return int(np.prod(self.shape[name]))
+
+
+class DalleEngine:
+    def __init__(self, n_embd, n_layers, n_heads, text_vocab_size, image_vocab_size, text_seq_len, image_seq_len,
+                 batch_size, global_batch_size=None, eos_token_id=None, hparams: Optional[dict] = None,
+                 device="cuda", process_group=None, world_size=1):
+        if not torch.cuda.is_available():
+            raise dh.DalleHipError("DalleEngine needs a HIP device (MI355X); there is no CPU fallback")
+        dh.lib()
+        assert n_embd % n_heads == 0, "n_state must be divisible by n_heads"
+        if n_embd // n_heads != HEAD_DIM:
+            raise dh.DalleHipError(f"attention kernels are built for head dim {HEAD_DIM} (n_embd/n_heads = {n_embd // n_heads}); "
+                                   "the reference README recommends exactly this ratio")
+        self.d, self.L, self.H = n_embd, n_layers, n_heads
+        self.text_vocab_size, self.image_vocab_size = text_vocab_size, image_vocab_size
+        self.T, self.S = text_seq_len, text_seq_len + image_seq_len
+        assert self.S % 8 == 0, "total sequence length must be a multiple of 8"
+        self.V = text_vocab_size + image_vocab_size + 1
+        self.eos = self.V - 1 if eos_token_id is None else eos_token_id
+        self.B = batch_size
+        self.B_global = global_batch_size or batch_size * world_size
+        self.M = self.B * self.S
+        self.dev = torch.device(device)
+        self.pg, self.world = process_group, world_size
+        self.hp = dict(hparams or {})
+        self.lay = ParamLayout(n_embd, n_layers, n_heads, self.V, self.S)
+        self.Vp = self.lay.Vp
+        n = self.lay.total
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        b16 = dict(dtype=torch.bfloat16, device=self.dev)
+        self.p = torch.zeros(n, **f32)
+        self.g = torch.zeros(n, **f32)
+        self.m = torch.zeros(n, **f32)
+        self.v = torch.zeros(n, **f32)
+        self.pb = torch.zeros(n, **b16)
+        self.pbt = torch.zeros(self.lay.t_total, **b16)
+        self.global_step = 0
+        self._alloc_activations()
+        self._pending = []  # async all-reduce handles
+
+    # ------------------------------------------------------------------ parameter access
+    def view(self, buf, name):
+        o = self.lay.offset[name]
+        return buf[o:o + self.lay.numel(name)].view(self.lay.shape[name])
+
+    def tview(self, name):
+        o = self.lay.t_offset[name]
+        r, c = self.lay.shape[name]
+        return self.pbt[o:o + r * c].view(c, r)
+
+    def load_reference_params(self, P: Dict[str, np.ndarray]):
+        """Load weights given under the reference's variable names/shapes."""
+        d, V = self.d, self.V
+        with torch.no_grad():
+            for name, shp in self.lay.entries:
+                dst = self.view(self.p, name)
+                if name.endswith("attn/qkv"):
+                    base = name[:-3]
+                    cat = np.concatenate([P[base + "q"], P[base + "k"], P[base + "v"]], axis=1)
+                    dst.copy_(torch.from_numpy(np.ascontiguousarray(cat)))
+                elif name == "to_logits/linear_out/kernel":
+                    dst.zero_()
+                    dst[:, :V].copy_(torch.from_numpy(np.ascontiguousarray(P[name])))
+                elif name == "to_logits/linear_out/bias":
+                    dst.fill_(-30000.0)   # pad logits can never win the softmax (and are masked in the CE kernel)
+                    dst[:V].copy_(torch.from_numpy(np.ascontiguousarray(P[name])))
+                else:
+                    dst.copy_(torch.from_numpy(np.ascontiguousarray(P[name])).view(shp))
+        self.refresh_compute_copies(cast=True)
+
+    def export_reference(self, buf=None) -> "OrderedDict[str, np.ndarray]":
+        """Inverse of load_reference_params for any flat buffer (params, grads, m, v)."""
+        buf = self.p if buf is None else buf
+        out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+        d, V = self.d, self.V
+        for name, shp in self.lay.entries:
+            a = self.view(buf, name).detach().float().cpu().numpy()
+            if name.endswith("attn/qkv"):
+                base = name[:-3]
+                out[base + "q"], out[base + "k"], out[base + "v"] = (np.ascontiguousarray(a[:, i * d:(i + 1) * d]) for i in range(3))
+            elif name == "to_logits/linear_out/kernel":
+                out[name] = np.ascontiguousarray(a[:, :V])
+            elif name == "to_logits/linear_out/bias":
+                out[name] = np.ascontiguousarray(a[:V])
+            else:
+                out[name] = a
+        return out
+
+    def init_params(self, seed=1234):
+        """Reference initialisers drawn with torch's generator on the host."""
+        g = torch.Generator().manual_seed(seed)
+        d, L, H = self.d, self.L, self.H
+        k = d // H
+        P = OrderedDict()
+
+        def nrm(shape, std):
+            return (torch.randn(*shape, generator=g) * std).numpy()
+        P["embedding/wte"] = nrm((self.V, d), 0.02)
+        P["positional_embedding/wpe"] = nrm((self.S, d), 0.01)
+        for i in range(L):
+            p = f"layer_{i}/"
+            P[p + "norm_1/g"], P[p + "norm_1/b"] = np.ones(d, np.float32), np.zeros(d, np.float32)
+            P[p + "attn/q"] = nrm((d, d), (d * k) ** -0.5)
+            P[p + "attn/k"] = nrm((d, d), d ** -0.5)
+            P[p + "attn/v"] = nrm((d, d), d ** -0.5)
+            P[p + "attn/o"] = nrm((d, d), (H * k) ** -0.5)
+            P[p + "attn/compute_output_bias/o_b"] = np.zeros(d, np.float32)
+            P[p + "norm_2/g"], P[p + "norm_2/b"] = np.ones(d, np.float32), np.zeros(d, np.float32)
+            P[p + "mlp/mlp_linear_1/kernel"], P[p + "mlp/mlp_linear_1/bias"] = nrm((d, 4 * d), 0.02), np.zeros(4 * d, np.float32)
+            P[p + "mlp/mlp_linear_2/kernel"], P[p + "mlp/mlp_linear_2/bias"] = nrm((4 * d, d), 0.02 / math.sqrt(L)), np.zeros(d, np.float32)
+        P["to_logits/layer_norm/g"], P["to_logits/layer_norm/b"] = np.ones(d, np.float32), np.zeros(d, np.float32)
+        P["to_logits/linear_out/kernel"], P["to_logits/linear_out/bias"] = nrm((d, self.V), 0.02), np.zeros(self.V, np.float32)
+        self.load_reference_params(P)
+
+    def refresh_compute_copies(self, cast=False):
+        """bf16 natural copy (if not already written by the Adam kernel) + [out,in] copies for the fwd GEMMs."""
+        if cast:
+            dh.cast_f32_bf16(self.p, self.pb, self.lay.total)
+        for name in self.lay.t_offset:
+            r, c = self.lay.shape[name]
+            dh.transpose(self.view(self.pb, name), self.tview(name), 1, r, c)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_activations(self):
+        M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
+        b16 = dict(dtype=torch.bfloat16, device=self.dev)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.tokens = torch.zeros(B, S, dtype=torch.int32, device=self.dev)
+        self.labels = torch.zeros(B, S, dtype=torch.int32, device=self.dev)
+        self.X = [torch.empty(M, d, **b16) for _ in range(L + 1)]       # residual stream entering layer l
+        self.xn1 = [torch.empty(M, d, **b16) for _ in range(L)]
+        self.qkv = [torch.empty(M, 3 * d, **b16) for _ in range(L)]
+        self.o = [torch.empty(M, d, **b16) for _ in range(L)]
+        self.lse = [torch.empty(B, H, S, **f32) for _ in range(L)]
+        self.x1 = [torch.empty(M, d, **b16) for _ in range(L)]
+        self.xn2 = [torch.empty(M, d, **b16) for _ in range(L)]
+        self.h = [torch.empty(M, 4 * d, **b16) for _ in range(L)]
+        self.stats = [[torch.empty(M, **f32) for _ in range(4)] for _ in range(L)]  # mean1, rstd1, mean2, rstd2
+        self.xnf = torch.empty(M, d, **b16)
+        self.statf = [torch.empty(M, **f32) for _ in range(2)]
+        self.z = torch.empty(M, Vp, **b16)
+        self.loss_rows = torch.empty(M, **f32)
+        self.loss = torch.zeros(1, **f32)
+        self.gnorm_sq = torch.zeros(1, **f32)
+        # scratch
+        self.tr = [torch.empty(B, H, HEAD_DIM, S, **b16) for _ in range(3)]  # vt (fwd) / qt, kt, dot (bwd)
+        self.dx = [torch.empty(M, d, **b16) for _ in range(2)]
+        self.dxn = torch.empty(M, d, **b16)
+        self.dh = torch.empty(M, 4 * d, **b16)
+        self.dqkv = torch.empty(M, 3 * d, **b16)
+        self.d_o = torch.empty(M, d, **b16)
+        self.delta = torch.empty(B, H, S, **f32)
+        wsz = max(dh.gemm_tn_workspace_bytes(M, d, Vp), dh.gemm_tn_workspace_bytes(M, 4 * d, d),
+                  dh.gemm_tn_workspace_bytes(M, d, 4 * d), dh.gemm_tn_workspace_bytes(M, d, 3 * d),
+                  dh.gemm_tn_workspace_bytes(M, d, d), dh.colsum_workspace_bytes(M, Vp),
+                  dh.layernorm_bwd_workspace_bytes(M, d), dh.sumsq_workspace_bytes(self.lay.total))
+        self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
+
+    # ------------------------------------------------------------------ forward
+    def _w(self, name):
+        return self.view(self.pb, name)
+
+    def forward(self, tokens: torch.Tensor, need_grad=True) -> torch.Tensor:
+        """tokens int32 [B,S] on device.  Returns the device scalar loss = mean over ALL B*S positions of
+        -log softmax(logits)[label] (src/dalle_mtf/models.py:348-359), labels = shift(tokens) (:407-410).
+        With need_grad the logits buffer is overwritten by dlogits (scaled by 1/(global B*S))."""
+        M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
+        assert tokens.shape == (B, S) and tokens.dtype == torch.int32
+        self.tokens.copy_(tokens)
+        dh.shift_labels(self.tokens, self.labels, B, S, self.eos)
+        dh.embed_fwd(self.tokens, self._w("embedding/wte"), self._w("positional_embedding/wpe"), self.X[0], S, d, self.V)
+        for l in range(L):
+            p = f"layer_{l}/"
+            x = self.X[l]
+            st = self.stats[l]
+            dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
+            dh.gemm_nt(self.xn1[l], d, self.tview(p + "attn/qkv"), d, self.qkv[l], 3 * d, M, 3 * d, d)
+            dh.transpose_strided(self.qkv[l].data_ptr() + 2 * d * 2, self.tr[0], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)
+            dh.attention_fwd(self.qkv[l], self.tr[0], self.o[l], self.lse[l], B, H, S)
+            dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
+                       bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
+            dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
+            dh.gemm_nt(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
+                       dh.GEMM_BIAS | dh.GEMM_RELU, bias=self._w(p + "mlp/mlp_linear_1/bias"))
+            dh.gemm_nt(self.h[l], 4 * d, self.tview(p + "mlp/mlp_linear_2/kernel"), 4 * d, self.X[l + 1], d, M, d, 4 * d,
+                       dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=self.x1[l])
+        dh.layernorm_fwd(self.X[L], self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), self.xnf,
+                         self.statf[0], self.statf[1], M, d)
+        hook = getattr(self, "event_hook", None)  # bench.py: HIP events around the largest single launch
+        if hook is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dh.gemm_nt(self.xnf, d, self.tview("to_logits/linear_out/kernel"), d, self.z, Vp, M, Vp, d, dh.GEMM_BIAS,
+                   bias=self._w("to_logits/linear_out/bias"))
+        if hook is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            hook().append((e0, e1))
+        nmb = self.hp.get("num_microbatches", 1) or 1
+        scale = 1.0 / (self.B_global * S * nmb) if need_grad else 0.0
+        dh.cross_entropy(self.z, Vp, self.labels, self.loss_rows, None, M, self.V, scale)
+        dh.sum_f32(self.loss_rows, M, 1.0 / (M * nmb), self.loss)
+        return self.loss
+
+    def logits(self) -> torch.Tensor:
+        """fp32 logits [B,S,V] of the last forward(need_grad=False) ("go to full precision", models.py:395)."""
+        return self.z.view(self.B, self.S, self.Vp)[:, :, :self.V].float()
+
+    # ------------------------------------------------------------------ backward
+    def _gv(self, name):
+        return self.view(self.g, name)
+
+    def _allreduce_bucket(self, idx):
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        lo = 0 if idx == 0 else self.lay.bucket_ends[idx - 1]
+        hi = self.lay.bucket_ends[idx]
+        self._pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def backward(self):
+        """Gradients of the last forward(need_grad=True) into the flat fp32 buffer; with world_size > 1 each
+        finished bucket is all-reduced (SUM) asynchronously -- the explicit form of mtf's implicit
+        all-reduce over the `data` mesh axis (src/model_fns.py:81-82,189)."""
+        M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
+        ws = self.ws
+        dz = self.z
+        # head
+        dh.gemm_tn(self.xnf, d, dz, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp, ws)
+        dh.colsum(dz, Vp, self._gv("to_logits/linear_out/bias"), M, Vp, ws)
+        dh.gemm_nt(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, d, M, d, Vp)
+        dxa, dxb = self.dx
+        dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
+                         self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)
+        self._allreduce_bucket(0)
+        for bi, l in enumerate(reversed(range(L))):
+            p = f"layer_{l}/"
+            st = self.stats[l]
+            # FFN
+            dh.colsum(dxa, d, self._gv(p + "mlp/mlp_linear_2/bias"), M, d, ws)
+            dh.gemm_tn(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d, ws)
+            dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
+                       relu_src=self.h[l])
+            dh.colsum(self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/bias"), M, 4 * d, ws)
+            dh.gemm_tn(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d, ws)
+            dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
+            dh.layernorm_bwd(self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
+                             self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"), ws, M, d)
+            # attention
+            dh.colsum(dxb, d, self._gv(p + "attn/compute_output_bias/o_b"), M, d, ws)
+            dh.gemm_tn(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d, ws)
+            dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
+            qkv = self.qkv[l]
+            dh.transpose_strided(qkv.data_ptr(), self.tr[0], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)          # q^T
+            dh.transpose_strided(qkv.data_ptr() + d * 2, self.tr[1], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)  # k^T
+            dh.transpose_strided(self.d_o.data_ptr(), self.tr[2], B, H, S, HEAD_DIM, S * d, HEAD_DIM, d)             # dO^T
+            dh.attention_bwd(qkv, self.tr[0], self.tr[1], self.o[l], self.d_o, self.tr[2], self.lse[l], self.delta,
+                             self.dqkv, B, H, S)
+            dh.gemm_tn(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, ws)
+            dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
+            dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
+                             self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"), ws, M, d)
+            self._allreduce_bucket(1 + bi)
+        gw = self._gv("embedding/wte")
+        gw.zero_()
+        # index plumbing only: visit positions in token-id order so equal ids reduce in registers
+        st, perm = torch.sort(self.tokens.view(-1), stable=True)
+        dh.embed_bwd_sorted(st, perm.to(torch.int32), dxa, gw, self._gv("positional_embedding/wpe"), B, S, d, self.V)
+        self._allreduce_bucket(L + 1)
+
+    def wait_grads(self):
+        for h in self._pending:
+            h.wait()
+        self._pending = []
+
+    # ------------------------------------------------------------------ optimizer
+    def learning_rate(self, step=None) -> float:
+        """src/optimizers.py:46-76 (cosine/linear decay to 0.1*lr, linear warm-up)."""
+        hp = self.hp
+        step = self.global_step if step is None else step
+        lr0 = hp["lr"]
+        end = hp.get("lr_decay_end") or hp["train_steps"]
+        decay = hp.get("lr_decay", "cosine") or "cosine"
+        warm = hp.get("warmup_steps", 3000)
+        warm = 3000 if warm is None else warm
+        f32 = np.float32
+        s = min(step, end)
+        if decay == "linear":
+            v = f32((lr0 - lr0 * 0.1) * (1.0 - s / end) + lr0 * 0.1)
+        elif decay == "cosine":
+            v = f32(lr0 * ((1.0 - 0.1) * 0.5 * (1.0 + math.cos(math.pi * s / end)) + 0.1))
+        else:
+            v = f32(lr0)
+        if warm > 0 and step < warm:
+            v = f32(v * f32(f32(step) / f32(warm)))
+        return float(v)
+
+    def optimizer_step(self):
+        """clip_by_global_norm (src/optimizers.py:11-16) + AdamWeightDecayOptimizer without bias correction
+        (src/optimizers.py:82-89,154-177) on the all-reduced gradients; refreshes the bf16 compute copies."""
+        self.wait_grads()
+        hp = self.hp
+        n = self.lay.total
+        clip = hp.get("gradient_clipping", 1.0)
+        lr = self.learning_rate()
+        b1 = hp.get("beta_1") or 0.9
+        b2 = hp.get("beta_2") or 0.999
+        eps = hp.get("epsilon") or 1e-6
+        wd = hp.get("weight_decay") or 0.0
+        gn = None
+        cl = 0.0
+        if clip is not None:
+            dh.sumsq(self.g, n, self.gnorm_sq, self.ws)
+            gn, cl = self.gnorm_sq, float(clip)
+        if not wd:
+            dh.adam_step(self.p, self.g, self.m, self.v, self.pb, n, gn, cl, lr, b1, b2, eps, 0.0)
+        else:
+            for name, _ in self.lay.entries:
+                o, k = self.lay.offset[name], _round_up(self.lay.numel(name), ALIGN)
+                use = ("norm" not in name) and ("bias" not in name) and not name.endswith("o_b")
+                dh.adam_step(self.p[o:o + k], self.g[o:o + k], self.m[o:o + k], self.v[o:o + k], self.pb[o:o + k], k, gn, cl,
+                             lr, b1, b2, eps, wd if use else 0.0)
+        self.refresh_compute_copies(cast=False)
+        self.global_step += 1
+        return lr
+
+    def train_step(self, tokens: torch.Tensor) -> torch.Tensor:
+        loss = self.forward(tokens, need_grad=True)
+        self.backward()
+        self.optimizer_step()
+        return loss
+
+    def grad_norm(self) -> float:
+        return float(torch.sqrt(self.gnorm_sq).item())
+
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        return {"p": self.p.detach().cpu(), "m": self.m.detach().cpu(), "v": self.v.detach().cpu(),
+                "global_step": self.global_step}
+
+    def load_state_dict(self, sd):
+        self.p.copy_(sd["p"]); self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.global_step = int(sd["global_step"])
+        self.refresh_compute_copies(cast=True)

@@ -1,0 +1,142 @@
+"""dalle_model_fn -- same (features, labels, mode, params) contract as the reference (src/model_fns.py:55-236):
+features = images [B,H,W,C] fp32 in [-1,1], labels = caption ids [B,text_seq_len] int32.
+VAE-encode -> argmax tokens -> concat with text (+text_vocab_size) -> DALLE forward -> (TRAIN) backward,
+gradient all-reduce over the data axis, clip + Adam -> EstimatorSpec(loss, train_op, host_call, hooks).
+
+The TF graph/session split becomes: the model is built once and cached on `params`; each call runs the
+forward eagerly and returns a spec whose train_op() runs backward + optimizer and returns the new
+global step.  predict raises NotImplementedError exactly like the reference (model_fns.py:135-136)."""
+import os
+
+import torch
+
+import dalle_hip as dh
+from .dalle_mtf import DALLE
+from .estimator import CheckpointSaverHook, EstimatorSpec, latest_checkpoint
+from .optimizers import get_optimizer
+from .utils import ModeKeys, create_host_call, get_graph_info, mode_to_str, parse_mesh_shape, scalar_summary
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank(), dist.group.WORLD
+    return 1, 0, None
+
+
+def load_vae_model(params, mode_str):
+    """reference model_fns.py:35-52: builds the DiscreteVAE from params['vae_params'] and resolves the checkpoint
+    (explicit vae_checkpoint_path or the latest under the VAE's model_path)."""
+    from .vae_tf import DiscreteVAE
+    vae_checkpoint_path = params.get("vae_checkpoint_path")
+    vae_params = params.get("vae_params")
+    assert vae_params is not None, "vae model config must be supplied"
+    if vae_checkpoint_path is None:
+        vae_checkpoint_path = latest_checkpoint(vae_params["model_path"])
+    if vae_checkpoint_path is None and not params.get("allow_random_vae"):
+        raise AssertionError("pretrained vae needed for training")
+    D = params["dataset"]["image_size"]
+    vae_model = DiscreteVAE(
+        num_tokens=vae_params["num_tokens"],
+        dim=vae_params.get("dim"),
+        hidden_dim=vae_params.get("hidden_dim"),
+        input_channels=vae_params.get("input_channels") or 3,
+        convblocks=vae_params.get("convblocks") or [(3, 64), (3, 128), (3, 256)],
+        stack_factor=vae_params.get("stack_factor") or 1,
+        dimensions=D,
+        batch_size=params[f"{mode_str}_batch_size"] // max(_dist_info()[0], 1),
+        mode="eval")
+    return vae_model, vae_checkpoint_path
+
+
+def initialize_vae_weights(vae, checkpoint_path):
+    """reference model_fns.py:11-32: restore every variable under scope 'vae' by name."""
+    if checkpoint_path is None:
+        vae.init_params()
+        return
+    sd = torch.load(checkpoint_path, map_location="cpu")
+    vae.load_reference_params(sd["vae_variables"])
+
+
+def _build(params, mode_str):
+    world, rank, pg = _dist_info()
+    mesh = parse_mesh_shape(params.get("mesh_shape"))
+    gbs = params[f"{mode_str}_batch_size"]
+    assert gbs % world == 0, f"{mode_str}_batch_size {gbs} must divide over {world} data-parallel ranks"
+    local_bs = gbs // world
+    state = {"world": world, "rank": rank}
+    if params.get("synthetic_image_tokens"):
+        image_seq_len = int(params["synthetic_image_tokens"])
+        state["vae"] = None
+    else:
+        vae, ckpt = load_vae_model(params, mode_str)
+        initialize_vae_weights(vae, ckpt)
+        # reference model_fns.py:68
+        image_seq_len = (vae.H // (2 ** len(vae.convblocks))) ** 2 // (vae.stack_factor ** 2)
+        state["vae"] = vae
+    model = DALLE(n_embd=params["n_embd"], text_vocab_size=params["text_vocab_size"],
+                  image_vocab_size=params["image_vocab_size"], text_seq_len=params["text_seq_len"],
+                  image_seq_len=image_seq_len, n_layers=params["n_layers"], n_heads=params["n_heads"],
+                  batch_size=local_bs, bf_16=params["bf_16"], mode=mode_str, params=params,
+                  process_group=pg, world_size=world, global_batch_size=gbs)
+    eng = model.engine
+    eng.hp["num_microbatches"] = 1  # tokens_per_mb_per_replica unset in every shipped config (model_fns.py:141-154)
+    params["num_microbatches"] = 1
+    ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
+    if ck is not None:
+        eng.load_state_dict(torch.load(ck, map_location="cpu")["dalle"])
+    else:
+        eng.init_params(seed=params.get("seed") or 1234)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(eng.p, src=0, group=pg)
+        eng.refresh_compute_copies(cast=True)
+    lr_fn, update_op = get_optimizer(eng, params)
+    if rank == 0:
+        get_graph_info(model.variables())
+    saver = CheckpointSaverHook(params.get("model_path"), params.get("steps_per_checkpoint"),
+                                lambda: {"dalle": eng.state_dict()}, max_to_keep=params.get("max_checkpoints") or 5,
+                                is_chief=(rank == 0))
+    state.update(model=model, lr_fn=lr_fn, update_op=update_op, saver=saver, image_seq_len=image_seq_len)
+    return state
+
+
+def dalle_model_fn(features, labels, mode, params):
+    mode_str = mode_to_str(mode)
+    if mode == ModeKeys.PREDICT:
+        raise NotImplementedError
+    assert mode in (ModeKeys.TRAIN, ModeKeys.EVAL)
+    key = f"_dalle_state_{mode_str}"
+    if params.get(key) is None:
+        if mode == ModeKeys.EVAL and params.get("_dalle_state_train") is not None and \
+                params["eval_batch_size"] == params["train_batch_size"]:
+            params[key] = params["_dalle_state_train"]
+        else:
+            params[key] = _build(params, mode_str)
+    st = params[key]
+    model, eng = st["model"], st["model"].engine
+    model.mode = mode_str
+    dev = eng.dev
+    B, T, P = eng.B, eng.T, st["image_seq_len"]
+    text = labels.to(device=dev, dtype=torch.int32).reshape(B, T)
+    tokens = torch.empty(B, T + P, dtype=torch.int32, device=dev)
+    if st["vae"] is not None:
+        # tokens = argmax(vae_logits, -1) (model_fns.py:72-77); + text_vocab_size; concat (model_fns.py:118-119)
+        vae_logits = st["vae"].forward(features.to(dev), return_logits=True)           # [B,g,g,T] fp32
+        dh.assemble_tokens(text, vae_logits.contiguous(), tokens, B, T, P, vae_logits.shape[-1], eng.text_vocab_size)
+    else:
+        img = features["image_tokens"] if isinstance(features, dict) else features
+        tokens[:, :T] = text
+        tokens[:, T:] = img.to(device=dev, dtype=torch.int32).reshape(B, P) + eng.text_vocab_size
+    loss, _loss_batch = model.forward({"tokens": tokens}, return_loss=True)
+    if mode == ModeKeys.EVAL:
+        return EstimatorSpec(mode=mode, loss=loss)
+    scalar_summary("loss", loss)
+    scalar_summary("lr", st["lr_fn"]())
+
+    def train_op():
+        eng.backward()
+        st["update_op"]()
+        return eng.global_step
+    return EstimatorSpec(mode=mode, loss=loss, train_op=train_op, host_call=create_host_call(params["model_path"])
+                         if params.get("model_path") else None, training_hooks=[st["saver"]])

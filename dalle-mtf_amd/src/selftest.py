@@ -1,0 +1,74 @@
+"""On-device self-check used by __graft_entry__.smoke() and tests/: one tiny DALL-E train step through the
+HIP engine vs the CPU oracle on identical weights and tokens.  The oracle is imported HERE (checker only)."""
+import math
+
+import numpy as np
+import torch
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=64, T=16, P=112, B=2, seed=0,
+                 steps=2, verbose=True, hp=None):
+    from oracle import dalle_oracle as do
+    from .dalle_mtf.engine import DalleEngine
+    cfg = do.DalleConfig(n_embd, text_vocab, image_vocab, T, P, n_layers, n_heads)
+    hp = dict(hp or dict(lr=1e-3, train_steps=1000, warmup_steps=2, gradient_clipping=1.0))
+    P0 = do.init_params(cfg, seed=1234 + seed, perturb=0.05)
+    rng = np.random.default_rng(seed)
+    text = do.synthetic_captions(B, T, text_vocab, seed=seed + 1)
+    img = do.synthetic_image_tokens(B, P, image_vocab, seed=seed + 2)
+    tokens = do.assemble_tokens(text, img, text_vocab)
+    eng = DalleEngine(n_embd, n_layers, n_heads, text_vocab, image_vocab, T, P, batch_size=B, hparams=hp)
+    eng.load_reference_params(P0)
+    tok_d = torch.from_numpy(tokens).cuda()
+    # oracle state
+    Po = {k: v.copy() for k, v in P0.items()}
+    m = {k: np.zeros_like(v) for k, v in P0.items()}
+    v = {k: np.zeros_like(v) for k, v in P0.items()}
+    report = {"steps": []}
+    for step in range(steps):
+        loss_o32, g32 = do.loss_and_grads(Po, tokens, cfg, bf16=False)
+        loss_o16, g16 = do.loss_and_grads(Po, tokens, cfg, bf16=True)
+        loss_h = float(eng.forward(tok_d, need_grad=True).item())
+        eng.backward()
+        eng.wait_grads()
+        gh = eng.export_reference(eng.g)
+        worst = max(((rel_l2(gh[k], g16[k]), k) for k in g16), key=lambda t: t[0])
+        worst32 = max(((rel_l2(gh[k], g32[k]), k) for k in g32), key=lambda t: t[0])
+        gn_h = math.sqrt(sum(float((gh[k].astype(np.float64) ** 2).sum()) for k in gh))
+        gn_o = math.sqrt(sum(float((g32[k].astype(np.float64) ** 2).sum()) for k in g32))
+        eng.global_step = step + 1  # past step 0 (lr(0) = 0 under warm-up)
+        lr = eng.optimizer_step()
+        # oracle update with the same schedule position
+        gc, _ = do.clip_by_global_norm(g32, hp.get("gradient_clipping", 1.0))
+        do.adam_step(Po, gc, m, v, do.learning_rate(step + 1, hp["lr"], hp["train_steps"], hp.get("warmup_steps", 3000)))
+        ph = eng.export_reference(eng.p)
+        pw = max(((float(np.abs(ph[k] - Po[k]).max()), k) for k in Po), key=lambda t: t[0])
+        rec = dict(step=step, loss_hip=loss_h, loss_oracle_fp32=loss_o32, loss_oracle_bf16=loss_o16,
+                   worst_grad_rel_l2_vs_bf16_oracle=worst, worst_grad_rel_l2_vs_fp32_oracle=worst32,
+                   grad_norm_hip=gn_h, grad_norm_oracle=gn_o, lr=lr, worst_param_abs_diff=pw)
+        report["steps"].append(rec)
+        if verbose:
+            print(rec, flush=True)
+    return report
+
+
+def check_report(report, loss_rtol=1e-2, grad_tol=6e-2, gn_rtol=3e-2):
+    for r in report["steps"]:
+        assert abs(r["loss_hip"] - r["loss_oracle_fp32"]) <= loss_rtol * abs(r["loss_oracle_fp32"]), r
+        assert r["worst_grad_rel_l2_vs_fp32_oracle"][0] <= grad_tol, r
+        assert abs(r["grad_norm_hip"] - r["grad_norm_oracle"]) <= gn_rtol * r["grad_norm_oracle"], r
+        # Adam's first steps move every weight by ~lr regardless of gradient size: |dp| <= 2.5*lr apart at most
+        assert r["worst_param_abs_diff"][0] <= 2.5 * r["lr"] + 1e-6, r
+
+
+def smoke_step():
+    rep = compare_step()
+    check_report(rep)
+    print("[smoke] DALL-E train step through libdalle_hip matches the CPU oracle:",
+          {k: rep["steps"][-1][k] for k in ("loss_hip", "loss_oracle_fp32", "grad_norm_hip", "grad_norm_oracle")})

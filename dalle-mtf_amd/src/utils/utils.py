@@ -1,0 +1,140 @@
+"""Host utilities mirroring src/utils/utils.py of the reference (config loading, mode strings, logging,
+scalar summaries) re-hosted on plain Python/PyTorch.  TPU-only pieces (simd_mesh_setup, utils.py:163-182)
+are out of scope."""
+import json
+import logging
+import os
+import sys
+from collections import defaultdict
+from shutil import rmtree
+from urllib.parse import urlparse
+
+__all__ = ["fetch_model_params", "yes_or_no", "mode_to_str", "remove_gs_or_filepath", "maybe_remove_gs_or_filepath",
+           "get_n_trainable_vars", "get_graph_info", "setup_logging", "scalar_summary", "ModeKeys", "SummaryWriter",
+           "parse_mesh_shape", "create_host_call"]
+
+_REPO_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+class ModeKeys:
+    """tf.estimator.ModeKeys stand-in (same string values)."""
+    TRAIN = "train"
+    EVAL = "eval"
+    PREDICT = "infer"
+
+
+def fetch_model_params(model):
+    """reference utils.py:13-17: a name under ./configs/ or a path ending in .json; missing keys read as None."""
+    model_path = model if model.endswith(".json") else f"./configs/{model}.json"
+    if not os.path.exists(model_path) and not model.endswith(".json"):
+        model_path = os.path.join(_REPO_ROOT, "configs", f"{model}.json")
+    with open(model_path) as f:
+        params = json.load(f)
+    return defaultdict(lambda: None, params)
+
+
+def yes_or_no(question):
+    while True:
+        reply = str(input(question + ' (y/n): ')).lower().strip()
+        if reply[:1] == 'y':
+            return True
+        if reply[:1] == 'n':
+            return False
+
+
+def mode_to_str(mode):
+    """reference utils.py:29-37."""
+    if mode == ModeKeys.PREDICT:
+        return "predict"
+    elif mode == ModeKeys.EVAL:
+        return "eval"
+    elif mode == ModeKeys.TRAIN:
+        return "train"
+    raise ValueError(f"Invalid mode {mode}")
+
+
+def remove_gs_or_filepath(path):
+    if urlparse(path).scheme == "gs":
+        raise ValueError("gs:// paths are not supported by the MI355X build; use a local model_path")
+    if os.path.exists(path):
+        rmtree(path)
+
+
+def maybe_remove_gs_or_filepath(path):
+    """reference utils.py:48-52 (interactive confirmation before deleting model_path)."""
+    if yes_or_no(f"Are you sure you want to remove '{path}' to start afresh?"):
+        remove_gs_or_filepath(path)
+    else:
+        sys.exit()
+
+
+def get_n_trainable_vars(variables):
+    """reference utils.py:55-69; `variables` maps name -> shape."""
+    total = 0
+    for shape in variables.values():
+        n = 1
+        for s in shape:
+            n *= int(s)
+        total += n
+    print(f"\n\nN PARAMS:\n{total:,}\n\n")
+    return total
+
+
+def get_graph_info(variables):
+    return get_n_trainable_vars(variables)
+
+
+def setup_logging(args, logdir="logs"):
+    """reference utils.py:184-195: file + stdout logger named after the config."""
+    os.makedirs(logdir, exist_ok=True)
+    name = os.path.splitext(os.path.basename(args.model))[0]
+    logger = logging.getLogger("dalle_mtf_amd")
+    logger.setLevel(logging.INFO)
+    logger.propagate = False
+    logger.handlers = [logging.FileHandler(f"{logdir}/{name}.log"), logging.StreamHandler(sys.stdout)]
+    return logger
+
+
+def parse_mesh_shape(mesh_shape: str):
+    """'data:16,model:2' -> {'data': 16, 'model': 2} (mtf.convert_to_shape, src/model_fns.py:81)."""
+    out = {}
+    for part in (mesh_shape or "").split(","):
+        if ":" in part:
+            k, v = part.split(":")
+            out[k.strip()] = int(v)
+    return out
+
+
+_SUMMARIES = {}
+
+
+def scalar_summary(name, x):
+    """reference utils.py:216-227: remember a named scalar (device tensor or float) for the host call."""
+    _SUMMARIES[name] = x
+    return x
+
+
+class SummaryWriter:
+    """Writes scalars as JSON lines under model_dir (TensorBoard event files need TensorFlow, absent here)."""
+
+    def __init__(self, model_dir):
+        os.makedirs(model_dir, exist_ok=True)
+        self.path = os.path.join(model_dir, "summaries.jsonl")
+
+    def scalars(self, step, **kv):
+        rec = {"step": int(step)}
+        for k, v in kv.items():
+            rec[k] = float(v.item() if hasattr(v, "item") else v)
+        with open(self.path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+
+
+def create_host_call(model_dir):
+    """reference utils.py:103-161: returns (fn, args) that writes the collected scalar summaries."""
+    if not _SUMMARIES:
+        return None
+    writer = SummaryWriter(model_dir)
+
+    def host_call_fn(global_step, **tensors):
+        writer.scalars(global_step, **{k: v for k, v in tensors.items() if "image" not in k})
+    return host_call_fn, dict(_SUMMARIES)

@@ -40,6 +40,12 @@ int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wp
 int dmi_embed_bwd(const int32_t* tokens, const uint16_t* dx, float* dwte, float* dwpe,
                   int B, int S, int d, int vocab, void* stream);
 
+/* same, visiting positions in token-id order: sorted_tokens ascending (stable), perm[i] = source row of
+ * sorted position i.  Runs of equal ids are reduced in registers; only runs crossing a 32-position chunk use
+ * atomics (the repeated padding id no longer serialises on one row).  dwte must be zeroed by the caller. */
+int dmi_embed_bwd_sorted(const int32_t* sorted_tokens, const int32_t* perm, const uint16_t* dx, float* dwte,
+                         float* dwpe, int B, int S, int d, int vocab, void* stream);
+
 /* ---- K2  LayerNorm eps=1e-5 biased variance   models.py:373-389, layers.py:30-33 ---- */
 int dmi_layernorm_fwd(const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y,
                       float* mean, float* rstd, int64_t rows, int d, float eps, void* stream);
