@@ -1,0 +1,85 @@
+"""Golden-vector tests: (CPU) the oracle reproduces the committed fixtures; (GPU) the HIP path matches them."""
+import os
+import sys
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg  # noqa: E402
+from oracle import dalle_oracle as do  # noqa: E402
+from oracle import vae_oracle as vo  # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "dalle_small.npz"))
+GV = np.load(os.path.join(HERE, "golden", "vae_small.npz"))
+
+
+def _case():
+    cfg = do.DalleConfig(**mg.DALLE_SMALL)
+    P = do.init_params(cfg, seed=77, perturb=0.05)
+    return cfg, P
+
+
+def test_oracle_reproduces_dalle_golden():
+    cfg, P = _case()
+    tokens = G["tokens"]
+    assert np.array_equal(do.shift_labels(tokens, cfg.eos_token_id), G["labels"])
+    loss, grads = do.loss_and_grads(P, tokens, cfg)
+    assert abs(loss - float(G["loss"])) < 2e-5
+    for k in G.files:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(grads[k[5:]], G[k], rtol=2e-4, atol=2e-6)
+    Pt = OrderedDict((k, torch.tensor(v)) for k, v in P.items())
+    _, lb, logits = do.forward(Pt, tokens, cfg, return_logits=True)
+    np.testing.assert_allclose(logits.numpy(), G["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lb.numpy(), G["loss_batch"], rtol=1e-4, atol=1e-5)
+    m = {k: np.zeros_like(v) for k, v in P.items()}
+    v = {k: np.zeros_like(v) for k, v in P.items()}
+    _, gnorm, lr = do.train_step(P, m, v, tokens, cfg, 1, mg.HP)
+    assert abs(gnorm - float(G["gnorm"])) < 1e-4 and abs(lr - float(G["lr"])) < 1e-9
+    np.testing.assert_allclose(P["layer_0/attn/q"], G["after:layer_0/attn/q"], rtol=1e-4, atol=1e-6)
+
+
+def test_oracle_reproduces_vae_golden():
+    cfg = vo.VaeConfig(num_tokens=32, dimensions=16, convblocks=[[2, 16], [2, 32]])
+    P = vo.init_params(cfg, seed=11, bias_perturb=0.02)
+    Pt = OrderedDict((k, torch.tensor(v)) for k, v in P.items())
+    logits = vo.forward(Pt, torch.tensor(GV["img"]), cfg, return_logits=True).numpy()
+    np.testing.assert_allclose(logits, GV["logits"], rtol=1e-4, atol=1e-5)
+    assert np.array_equal(do.image_tokens_from_logits(logits), GV["tokens"])
+    loss, grads, out = vo.loss_and_grads(P, GV["img"], GV["u"], cfg, hard=True)
+    assert abs(loss - float(GV["loss_hard"])) < 1e-5
+    np.testing.assert_allclose(out, GV["recon_hard"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_hip_matches_dalle_golden():
+    from src.dalle_mtf.engine import DalleEngine
+    cfg, P = _case()
+    c = mg.DALLE_SMALL
+    eng = DalleEngine(c["n_embd"], c["n_layers"], c["n_heads"], c["text_vocab_size"], c["image_vocab_size"],
+                      c["text_seq_len"], c["image_seq_len"], batch_size=2, hparams=dict(mg.HP))
+    eng.load_reference_params(P)
+    tok = torch.from_numpy(G["tokens"]).cuda()
+    eng.forward(tok, need_grad=False)
+    assert np.array_equal(eng.labels.cpu().numpy(), G["labels"])           # integer path: bit-exact
+    logits = eng.logits().cpu().numpy()
+    assert np.abs(logits - G["logits"]).max() <= 3e-2 * max(1.0, np.abs(G["logits"]).max())
+    loss = float(eng.forward(tok, need_grad=True).item())
+    assert abs(loss - float(G["loss"])) <= 1e-2 * float(G["loss"])
+    np.testing.assert_allclose(eng.loss_rows.cpu().numpy().reshape(2, -1), G["loss_batch"], rtol=5e-2, atol=5e-2)
+    eng.backward()
+    gh = eng.export_reference(eng.g)
+    for k in G.files:
+        if k.startswith("grad:"):
+            a, b = gh[k[5:]].astype(np.float64), G[k].astype(np.float64)
+            rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+            assert rel <= 6e-2, (k, rel)
+    eng.global_step = 1
+    eng.optimizer_step()
+    assert abs(eng.grad_norm() - float(G["gnorm"])) <= 3e-2 * float(G["gnorm"])
+    after = eng.export_reference(eng.p)
+    assert np.abs(after["layer_0/attn/q"] - G["after:layer_0/attn/q"]).max() <= 6.5 * float(G["lr"])
