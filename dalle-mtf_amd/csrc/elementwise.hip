@@ -247,8 +247,18 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float acc = 0.f;
-  if (c < ncols)
-    for (int p = grp; p < P; p += 4) acc += part[(int64_t)p * ncols + c];
+  if (c < ncols) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // 4 independent chains keep 4+ loads in flight
+    int p = grp;
+    for (; p + 12 < P; p += 16) {
+      a0 += part[(int64_t)p * ncols + c];
+      a1 += part[(int64_t)(p + 4) * ncols + c];
+      a2 += part[(int64_t)(p + 8) * ncols + c];
+      a3 += part[(int64_t)(p + 12) * ncols + c];
+    }
+    for (; p < P; p += 4) a0 += part[(int64_t)p * ncols + c];
+    acc = (a0 + a1) + (a2 + a3);
+  }
   sm[grp][cl] = acc;
   __syncthreads();
   if (grp == 0 && c < ncols) out[c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
@@ -349,8 +359,19 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restr
   const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float acc = 0.f;
-  if (c < 2 * d)
-    for (int p = grp; p < P; p += 4) acc += part[(int64_t)p * 2 * d + c];
+  if (c < 2 * d) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int p = grp;
+    const int64_t nc = 2 * (int64_t)d;
+    for (; p + 12 < P; p += 16) {
+      a0 += part[(int64_t)p * nc + c];
+      a1 += part[(int64_t)(p + 4) * nc + c];
+      a2 += part[(int64_t)(p + 8) * nc + c];
+      a3 += part[(int64_t)(p + 12) * nc + c];
+    }
+    for (; p < P; p += 4) a0 += part[(int64_t)p * nc + c];
+    acc = (a0 + a1) + (a2 + a3);
+  }
   sm[grp][cl] = acc;
   __syncthreads();
   if (grp == 0 && c < 2 * d) {

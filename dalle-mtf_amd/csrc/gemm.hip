@@ -16,20 +16,23 @@
 //
 // TN kernel (weight gradients): dW[I,J] = sum_m X[m,I] dY[m,J].  The contraction index is the ROW of both
 //   operands, so fragments are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose read) from
-//   natural-layout LDS tiles (pitch 320 B => conflict-free for the 2x32-lane service groups).
+//   natural-layout LDS tiles filled by LDS-DMA (XOR-swizzled on the source side => conflict-free).
 #include "common.h"
 #include <string.h>
 
 static int g_opt_glds = 1;
 static int g_opt_tn_trread = 1;
+static int g_opt_nt2 = 1;
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
   if (!strcmp(name, "tn_trread")) return g_opt_tn_trread;
+  if (!strcmp(name, "nt2")) return g_opt_nt2;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "glds")) { g_opt_glds = value; return 0; }
   if (!strcmp(name, "tn_trread")) { g_opt_tn_trread = value; return 0; }
+  if (!strcmp(name, "nt2")) { g_opt_nt2 = value; return 0; }
   return -1;
 }
 
@@ -211,6 +214,182 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
   }
 }
 
+// =====================================================================================
+// NT kernel v2: same tiling/swizzle as gemm_nt_kernel, with
+//  * LDS-DMA through a per-block buffer descriptor (buffer_load_dwordx4 ... lds): the 8 per-lane byte
+//    offsets are loop-invariant VGPRs, the K advance is one SGPR add -> no address VALU in the K-loop
+//    (v1 issued 3.6 VALU per MFMA, rocprofv3 PMC profiles/r01);
+//  * swizzled fragment offsets hoisted (4 VGPRs per operand) + immediates, stages unrolled x2;
+//  * bf16 epilogue staged through LDS (fp32, 32 rows at a time per wave) so every lane stores 16 B of one
+//    output row: full 128-B row segments instead of scattered 8-B pieces (the vocabulary projection was
+//    62 % store-wait with the direct epilogue).
+// =====================================================================================
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kb = blockIdx.y * a.k_per_split;
+  const int ke = (kb + a.k_per_split < a.K) ? kb + a.k_per_split : a.K;
+  const int nt = (ke - kb) / BK;
+
+  // per-block descriptors based at the tile origin (offsets stay < 2^31 even for the 4 GiB logits matrix)
+  const bf16_t* Ab = a.A + (int64_t)m0 * a.lda + kb;
+  const bf16_t* Bb = a.B + (int64_t)n0 * a.ldb + kb;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
+  int voa[4], vob[4];
+  {
+    const int chp = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int src_ch = chp ^ ((row >> 1) & 7);
+      int ra_ = m0 + row < a.M ? row : a.M - 1 - m0;   // clamp inside the matrix (results discarded)
+      int rb_ = n0 + row < a.N ? row : a.N - 1 - n0;
+      voa[i] = (ra_ * a.lda + 8 * src_ch) * 2;
+      vob[i] = (rb_ * a.ldb + 8 * src_ch) * 2;
+    }
+  }
+  // hoisted fragment byte offsets: chunk (2kk+h) ^ ((row>>1)&7); (row>>1)&7 == (r>>1)&7 for every tile row used
+  int offa[4], offb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    offa[kk] = lds_chunk_off(wm * 64 + r, kk * 2 + h);
+    offb[kk] = 16384 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stage = [&](int st, int soff) {
+    char* base = smem + st * 32768 + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ra, base + i * 4096, voa[i], soff);
+      glds16(rb, base + 16384 + i * 4096, vob[i], soff);
+    }
+  };
+  auto compute = [&](int st) {
+    const char* cur = smem + st * 32768;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
+        fb[i] = *(const bf16x8*)(cur + offb[kk] + i * 4096);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int t = 0;
+  for (; t + 2 <= nt; t += 2) {
+    if (t + 1 < nt) stage(1, (t + 1) * BK * 2);
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < nt) stage(0, (t + 2) * BK * 2);
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (t < nt) {  // odd tail (stage 0 holds it)
+    compute(0);
+    __syncthreads();
+  }
+
+  if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + r;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+          if (n >= a.N) continue;
+          float* cp = (float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n;
+          *(f32x4*)cp = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+    }
+  } else {
+    // wave-private fp32 staging: 32 rows x 64 cols, pitch 272 B (16-B aligned rows)
+    float* st = (float*)(smem + wid * 8704);
+    const int orow = lane >> 3, ocol = (lane & 7) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(f32x4*)(st + r * 68 + j * 32 + 8 * q + 4 * h) =
+              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + orow;
+        const int m = m0 + wm * 64 + i * 32 + row;
+        const int n = n0 + wn * 64 + ocol;
+        const f32x4 lo = *(const f32x4*)(st + row * 68 + ocol);
+        const f32x4 hi = *(const f32x4*)(st + row * 68 + ocol + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        if (m < a.M && n < a.N) {
+          const int64_t off = (int64_t)m * a.ldc + n;
+          if constexpr (FLAGS & DMI_GEMM_BIAS) {
+            float b[8];
+            unpack8(*(const u32x4*)(a.bias + n), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+          if constexpr (FLAGS & DMI_GEMM_RELU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
+            float b[8];
+            unpack8(*(const u32x4*)(a.residual + off), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += b[e];
+          }
+          if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+            float b[8];
+            unpack8(*(const u32x4*)(a.relu_src + off), b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
+          }
+          *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int nsplit, int64_t n4, int64_t stride4) {
@@ -228,7 +407,11 @@ template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
   const size_t shm = 65536;
-  if (g_opt_glds) {
+  if (g_opt_nt2 && g_opt_glds) {
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_done = true; }
+    gemm_nt2_kernel<FLAGS><<<grid, blk, shm, st>>>(a);
+  } else if (g_opt_glds) {
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_done = true; }
     gemm_nt_kernel<FLAGS, true><<<grid, blk, shm, st>>>(a);
@@ -244,8 +427,8 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
 static int check_nt(const void* A, int lda, const void* B, int ldb, const void* C, int ldc, int M, int N, int K) {
   DMI_REQUIRE(A && B && C, "gemm_nt: null pointer");
   DMI_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, "gemm_nt: need K%%64==0 and N%%8==0 (M=%d N=%d K=%d)", M, N, K);
-  DMI_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt: bad leading dimensions");
-  DMI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 7) == 0, "gemm_nt: operands must be 16-byte aligned");
+  DMI_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt: bad leading dimensions");
+  DMI_REQUIRE((((uintptr_t)A | (uintptr_t)B) & 15) == 0 && ((uintptr_t)C & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
   return DMI_OK;
 }
 
@@ -280,7 +463,6 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
 // TN weight-gradient GEMM
 // =====================================================================================
 #define TN_BKM 64      // rows of m per step
-#define TN_PITCH 160   // elements per LDS row (128 + 32 pad) = 320 B
 
 static int tn_splits(int M, int I, int J) {
   const int tiles = ((I + 127) / 128) * ((J + 127) / 128);
@@ -297,23 +479,64 @@ extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   const int64_t slabs = (s > 1) ? (int64_t)s * I * J * 4 : 0;
   const int64_t Mp = round_up64(M, 64);
   const int64_t tr = ((int64_t)I * Mp + (int64_t)J * Mp) * 2;  // fallback: transposed operand copies
-  return round_up64(slabs, 256) + round_up64(tr, 256) + 256;
+  const int64_t cs = ((int64_t)(M + 255) / 256) * J * 4 + (int64_t)s * J * 4;  // column-sum partials (bias gradient)
+  return round_up64(slabs, 256) + round_up64(tr, 256) + round_up64(cs, 256) + 256;
 }
 
 struct TnArgs {
   const bf16_t* X;
   const bf16_t* Y;
   float* C;
+  float* bias_part;  // [nsplit][J] column sums of Y (nullable)
   int M, I, J, ldx, ldy;
   int tiles_i, tiles_j;
   int m_per_split;  // multiple of TN_BKM
   int64_t slab_stride;
 };
 
+// Transposed fragment fetch through inline asm: hipcc orders the ds_read_tr16_b64 INTRINSIC behind every in-flight
+// LDS-DMA (it cannot prove they do not alias) and drains vmcnt(0) before it, which serialises load and compute.
+// An asm read is invisible to that bookkeeping; completion is waited for explicitly (lgkmcnt) by a statement that
+// names every destination "+v", so no consumer can be scheduled above it (cdna_hip_programming.md §5.7 form ii).
+struct TrFrag {
+  u32x2 x0a, x0b, x1a, x1b, y0a, y0b, y1a, y1b;  // {x|y}{i}{a: rows +0..3 | b: rows +4..7}
+};
+__device__ __forceinline__ void tr_issue(TrFrag& f, unsigned ax0, unsigned ax1, unsigned ay0, unsigned ay1) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %2, %9\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %4, %10\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:1024\n\t"
+      "ds_read_b64_tr_b16 %6, %11\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:1024"
+      : "=&v"(f.x0a), "=&v"(f.x0b), "=&v"(f.x1a), "=&v"(f.x1b), "=&v"(f.y0a), "=&v"(f.y0b), "=&v"(f.y1a), "=&v"(f.y1b)
+      : "v"(ax0), "v"(ax1), "v"(ay0), "v"(ay1)
+      : "memory");
+}
+__device__ __forceinline__ void tr_wait(TrFrag& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.x0a), "+v"(f.x0b), "+v"(f.x1a), "+v"(f.x1b), "+v"(f.y0a), "+v"(f.y0b), "+v"(f.y1a), "+v"(f.y1b)
+               :
+               : "memory");
+}
+__device__ __forceinline__ bf16x8 tr_cat(u32x2 a, u32x2 b) {
+  u32x4 v = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// v3: LDS-DMA staging (buffer_load_dwordx4 ... lds; rows past the split / matrix end read as 0 through the
+// descriptor's num_records), two stages x (X 64x128 | Y 64x128) bf16 = 64 KiB, ONE barrier per 64-row step.
+// LDS rows are 256 B (linear, as the DMA requires); the 16-B chunk index is XOR-ed with 4*(row&3) on the SOURCE
+// side so that the 2x32-lane service groups of ds_read_b64_tr_b16 (4 rows x 2 x 32 B) cover all 64 banks once.
+// row&3 is a per-lane constant of the fragment read ((l16>>2)), so the swizzle folds into 2 hoisted offsets.
+// Bias gradients (column sums of dY): blocks of the first row-tile issue one extra MFMA per k-step with an
+// all-ones A operand (D[i][j] = sum_k Y[k][j]).
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
-  __shared__ __attribute__((aligned(16))) bf16_t sx[TN_BKM * TN_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16_t sy[TN_BKM * TN_PITCH];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];  // [2 stages][X 16K | Y 16K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wid >> 1, wj = wid & 1;
   const int h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
 
@@ -322,7 +545,34 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   const int i0 = ti * 128, j0 = tj * 128;
   const int mb = blockIdx.y * a.m_per_split;
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
-  const int nt = (me - mb + TN_BKM - 1) / TN_BKM;
+  const int rows = me > mb ? me - mb : 0;
+  const int nt = (rows + TN_BKM - 1) / TN_BKM;
+
+  const int wx = (a.I - i0 < 128) ? a.I - i0 : 128, wy = (a.J - j0 < 128) ? a.J - j0 : 128;
+  const int64_t nbx = rows > 0 ? ((int64_t)(rows - 1) * a.ldx + wx) * 2 : 0;
+  const int64_t nby = rows > 0 ? ((int64_t)(rows - 1) * a.ldy + wy) * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)mb * a.ldx + i0), 0, (int)(nbx > 0x7fffffff ? 0x7fffffff : nbx), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (int64_t)mb * a.ldy + j0), 0, (int)(nby > 0x7fffffff ? 0x7fffffff : nby), 0x00020000);
+  // DMA: linear LDS chunk c = tid + 256 i -> row c>>4, physical chunk c&15 holds source chunk (c&15) ^ 4*(row&3)
+  int vox[4], voy[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 4) + 16 * i;
+    const int sch = (tid & 15) ^ (4 * (row & 3));
+    vox[i] = (8 * sch < wx) ? (row * a.ldx + 8 * sch) * 2 : 0x7ffffff0;  // columns past the width read as 0
+    voy[i] = (8 * sch < wy) ? (row * a.ldy + 8 * sch) * 2 : 0x7ffffff0;
+  }
+  const int stepx = TN_BKM * a.ldx * 2, stepy = TN_BKM * a.ldy * 2;
+  // fragment read offsets (bytes): row 8h + (l16>>2) [+16kk, +4], byte in row = (w*128 + i*64 + 32*(g4&1) + 8*(l16&3)) ^ 64*(row&3)
+  const int rr = l16 >> 2;
+  const int rowb = (8 * h + rr) * 256;
+  const int cb = 32 * (g4 & 1) + 8 * (l16 & 3);
+  int ofx[2], ofy[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    ofx[i] = rowb + ((wi * 128 + i * 64 + cb) ^ (64 * rr));
+    ofy[i] = 16384 + rowb + ((wj * 128 + i * 64 + cb) ^ (64 * rr));
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -331,50 +581,69 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x16 bacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+  const bool do_bias = (a.bias_part != nullptr) && (ti == 0);
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-  u32x4 rx[4], ry[4];
-  const int lrow = tid >> 4, lch = tid & 15;  // 16 chunks (of 8 cols) per 128-col row; rows lrow + 16 i
-  auto load_tiles = [&](int m_base) {
+  auto stage = [&](int st) {
+    char* base = smem_tn + st * 32768 + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m_base + lrow + 16 * i;
-      const bool ok = m < me;
-      const int ci = i0 + 8 * lch, cj = j0 + 8 * lch;
-      rx[i] = (ok && ci < a.I) ? *(const u32x4*)(a.X + (int64_t)m * a.ldx + ci) : u32x4{0, 0, 0, 0};
-      ry[i] = (ok && cj < a.J) ? *(const u32x4*)(a.Y + (int64_t)m * a.ldy + cj) : u32x4{0, 0, 0, 0};
+      glds16(rx, base + i * 4096, vox[i], 0);
+      glds16(ry, base + 16384 + i * 4096, voy[i], 0);
+      vox[i] += stepx;
+      voy[i] += stepy;
     }
   };
-  load_tiles(mb);
-  for (int t = 0; t < nt; ++t) {
-    __syncthreads();  // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(u32x4*)(sx + (lrow + 16 * i) * TN_PITCH + 8 * lch) = rx[i];
-      *(u32x4*)(sy + (lrow + 16 * i) * TN_PITCH + 8 * lch) = ry[i];
-    }
-    __syncthreads();
-    if (t + 1 < nt) load_tiles(mb + (t + 1) * TN_BKM);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
+  auto compute = [&](int st) {
+    const unsigned base = lds0 + st * 32768;
+    TrFrag f[2];
+    tr_issue(f[0], base + ofx[0], base + ofx[1], base + ofy[0], base + ofy[1]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fx[2], fy[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        // 16-lane group g4 fetches the 4(k) x 16(col) block: rows 16kk+8h+4q.., cols tile + 16*(g4&1)..
-        const int colx = wi * 64 + i * 32 + 16 * (g4 & 1) + 4 * (l16 & 3);
-        const int coly = wj * 64 + i * 32 + 16 * (g4 & 1) + 4 * (l16 & 3);
-        const int krow = 16 * kk + 8 * h + (l16 >> 2);
-        const bf16x4 x0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sx + krow * TN_PITCH + colx));
-        const bf16x4 x1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sx + (krow + 4) * TN_PITCH + colx));
-        const bf16x4 y0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sy + krow * TN_PITCH + coly));
-        const bf16x4 y1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4*)(sy + (krow + 4) * TN_PITCH + coly));
-        fx[i] = __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
-        fy[i] = __builtin_shufflevector(y0, y1, 0, 1, 2, 3, 4, 5, 6, 7);
+      TrFrag& c = f[kk & 1];
+      tr_wait(c);
+      if (kk < 3) {
+        const unsigned b2 = base + (kk + 1) * 4096;
+        tr_issue(f[(kk + 1) & 1], b2 + ofx[0], b2 + ofx[1], b2 + ofy[0], b2 + ofy[1]);  // overlaps the MFMAs below
       }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx[i], fy[j], acc[i][j], 0, 0, 0);  // D[i][j]
+      const bf16x8 fx0 = tr_cat(c.x0a, c.x0b), fx1 = tr_cat(c.x1a, c.x1b);
+      const bf16x8 fy0 = tr_cat(c.y0a, c.y0b), fy1 = tr_cat(c.y1a, c.y1b);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx0, fy0, acc[0][0], 0, 0, 0);  // D[i][j]
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx0, fy1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx1, fy0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx1, fy1, acc[1][1], 0, 0, 0);
+      if (do_bias) {  // wave (wi,wj) sums columns wj*64 + wi*32 ..  (wave-uniform branches)
+        if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fy0, bacc, 0, 0, 0);
+        else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fy1, bacc, 0, 0, 0);
+      }
+    }
+  };
+
+  if (nt > 0) {
+    // stages addressed with compile-time constants (x2 unroll): otherwise the compiler cannot prove the in-flight
+    // LDS-DMA does not alias the fragment reads and drains vmcnt(0) before them.
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 <= nt; t += 2) {
+      stage(1);
+      compute(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 2 < nt) stage(0);
+      compute(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (t < nt) {
+      compute(0);
+      __syncthreads();
     }
   }
   // store: reg e -> row i = (e&3) + 8*(e>>2) + 4h ; col j = lane&31
@@ -391,13 +660,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
         if (row < a.I) C[(int64_t)row * a.J + col] = acc[i][j][e];
       }
     }
+  if (do_bias && h == 0) {  // row 0 of D (reg 0 of the lower half-wave) holds the column sums
+    const int col = j0 + wj * 64 + wi * 32 + (lane & 31);
+    if (col < a.J) a.bias_part[(int64_t)blockIdx.y * a.J + col] = bacc[0];
+  }
 }
 
 int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int Rv, int Rp, int C,
                          int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride, void* stream);
 
-extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, int M, int I, int J,
-                           void* workspace, void* stream) {
+extern "C" int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int N, void* workspace, void* stream);
+
+extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias, int M,
+                           int I, int J, void* workspace, void* stream) {
   DMI_REQUIRE(X && dY && dW && workspace, "gemm_tn: null pointer");
   DMI_REQUIRE(M > 0 && I % 8 == 0 && J % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= I && ldy >= J,
               "gemm_tn: I, J, ldx, ldy must be multiples of 8 (M=%d I=%d J=%d)", M, I, J);
@@ -413,8 +688,19 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
     a.C = (nsplit > 1) ? slabs : dW;
     a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-    gemm_tn_kernel<<<dim3(a.tiles_i * a.tiles_j, nsplit), dim3(256), 0, st>>>(a);
+    // bias partials live behind the transposed-copy region of the workspace (unused in this mode)
+    float* bpart = (float*)((char*)workspace + slab_bytes);
+    a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
+    DMI_REQUIRE((int64_t)TN_BKM * (ldx > ldy ? ldx : ldy) * 2 < 0x7fffffff, "gemm_tn: leading dimension too large");
+    static bool attr_done = false;
+    const int shm = 65536;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
+    gemm_tn_kernel<<<dim3(a.tiles_i * a.tiles_j, nsplit), dim3(256), shm, st>>>(a);
     DMI_CHECK_LAUNCH("gemm_tn");
+    if (dbias && nsplit > 1) {
+      reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);
+      DMI_CHECK_LAUNCH("gemm_tn_bias_reduce");
+    }
   } else {
     // fallback: explicit transposes + split-K NT GEMM:  dW[I,J] = Xt[I,Mp] . dYt[J,Mp]^T
     const int Mp = (int)round_up64(M, 64);
@@ -438,6 +724,11 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
       // fewer effective splits than planned: zero the unused slabs so the reduce stays exact
       hipError_t e = hipMemsetAsync(slabs + (int64_t)ns * I * J, 0, (int64_t)(nsplit - ns) * I * J * 4, st);
       DMI_REQUIRE(e == hipSuccess, "gemm_tn: memset failed");
+    }
+    if (dbias) {
+      const int64_t tr_bytes = round_up64(((int64_t)I * Mp + (int64_t)J * Mp) * 2, 256);
+      rc = dmi_colsum(dY, ldy, dbias, M, J, (char*)workspace + slab_bytes + tr_bytes, stream);
+      if (rc) return rc;
     }
   }
   if (nsplit > 1) {

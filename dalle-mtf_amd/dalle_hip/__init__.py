@@ -59,7 +59,7 @@ def _declare(L):
         "dmi_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L64, I, P]),
         "dmi_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, I, P, P, P, P]),
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
-        "dmi_gemm_tn": (I, [P, I, P, I, P, I, I, I, P, P]),
+        "dmi_gemm_tn": (I, [P, I, P, I, P, P, I, I, I, P, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
         "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
@@ -152,9 +152,9 @@ def gemm_tn_workspace_bytes(M, I, J):
     return lib().dmi_gemm_tn_workspace_bytes(M, I, J)
 
 
-def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws):
-    _dev(X, dY, dW, ws)
-    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), M, I, J, _p(ws), _stream()), "gemm_tn")
+def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws, dbias=None):
+    _dev(X, dY, dW, ws, dbias)
+    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), M, I, J, _p(ws), _stream()), "gemm_tn")
 
 
 def colsum_workspace_bytes(M, N):

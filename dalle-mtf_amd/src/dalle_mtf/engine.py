@@ -311,8 +311,8 @@ class DalleEngine:
         ws = self.ws
         dz = self.z
         # head
-        dh.gemm_tn(self.xnf, d, dz, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp, ws)
-        dh.colsum(dz, Vp, self._gv("to_logits/linear_out/bias"), M, Vp, ws)
+        dh.gemm_tn(self.xnf, d, dz, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp, ws,
+                   dbias=self._gv("to_logits/linear_out/bias"))
         dh.gemm_nt(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, d, M, d, Vp)
         dxa, dxb = self.dx
         dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
@@ -322,18 +322,18 @@ class DalleEngine:
             p = f"layer_{l}/"
             st = self.stats[l]
             # FFN
-            dh.colsum(dxa, d, self._gv(p + "mlp/mlp_linear_2/bias"), M, d, ws)
-            dh.gemm_tn(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d, ws)
+            dh.gemm_tn(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d, ws,
+                       dbias=self._gv(p + "mlp/mlp_linear_2/bias"))
             dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
                        relu_src=self.h[l])
-            dh.colsum(self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/bias"), M, 4 * d, ws)
-            dh.gemm_tn(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d, ws)
+            dh.gemm_tn(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d, ws,
+                       dbias=self._gv(p + "mlp/mlp_linear_1/bias"))
             dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
             dh.layernorm_bwd(self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
                              self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"), ws, M, d)
             # attention
-            dh.colsum(dxb, d, self._gv(p + "attn/compute_output_bias/o_b"), M, d, ws)
-            dh.gemm_tn(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d, ws)
+            dh.gemm_tn(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d, ws,
+                       dbias=self._gv(p + "attn/compute_output_bias/o_b"))
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             qkv = self.qkv[l]
             dh.transpose_strided(qkv.data_ptr(), self.tr[0], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)          # q^T

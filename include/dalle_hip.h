@@ -69,9 +69,10 @@ int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C
                 int M, int N, int K, int flags, const uint16_t* bias, const uint16_t* residual,
                 const uint16_t* relu_src, void* stream);
 /* weight gradient: dW[I,J] (fp32, ld = J) = sum_m X[m,I] * dY[m,J]; deterministic split over m.
+ * dbias (nullable): fp32 [J] = sum_m dY[m, :] fused into the same pass (bias gradient of the dense layer).
  * workspace: dmi_gemm_tn_workspace_bytes(M, I, J). */
 int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J);
-int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, int M, int I, int J,
+int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias, int M, int I, int J,
                 void* workspace, void* stream);
 /* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
 int64_t dmi_colsum_workspace_bytes(int64_t M, int N);

@@ -105,22 +105,30 @@ def _gemm_ref(A, Bt, bias=None, relu=False, residual=None, relu_src=None):
     return C
 
 
-@pytest.mark.parametrize("glds", [1, 0])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1024, 512, 512), (257, 1160, 192)])
+VARIANTS = {"nt2": dict(nt2=1, glds=1), "glds": dict(nt2=0, glds=1), "regstage": dict(nt2=0, glds=0)}
+
+
+def _set_variant(v):
+    for k, val in VARIANTS[v].items():
+        dh.set_option(k, val)
+
+
+@pytest.mark.parametrize("glds", list(VARIANTS))
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1024, 512, 512), (257, 1160, 192), (130, 128, 448)])
 def test_gemm_nt_plain(glds, M, N, K):
-    dh.set_option("glds", glds)
+    _set_variant(glds)
     try:
         A, Bt = rnd(M, K, seed=1), rnd(N, K, seed=2)
         C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
         dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K)
         close(C, _gemm_ref(A, Bt), 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt glds={glds}")
     finally:
-        dh.set_option("glds", 1)
+        _set_variant("nt2")
 
 
-@pytest.mark.parametrize("glds", [1, 0])
+@pytest.mark.parametrize("glds", list(VARIANTS))
 def test_gemm_nt_epilogues(glds):
-    dh.set_option("glds", glds)
+    _set_variant(glds)
     try:
         M, N, K = 384, 640, 256
         A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
@@ -145,20 +153,25 @@ def test_gemm_nt_epilogues(glds):
         dh.gemm_nt(A2.to(DEV)[:, K:], 3 * K, Bd, K, C, N, M, N, K)
         close(C, _gemm_ref(A2[:, K:2 * K], Bt), what="strided A", **tol)
     finally:
-        dh.set_option("glds", 1)
+        _set_variant("nt2")
 
 
 @pytest.mark.parametrize("trread", [1, 0])
-@pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160)])
+@pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200)])
 def test_gemm_tn(trread, M, I, J):
     dh.set_option("tn_trread", trread)
     try:
         X, dY = rnd(M, I, seed=1), rnd(M, J, seed=2)
         dW = torch.full((I, J), 7.0, dtype=torch.float32, device=DEV)
         w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
-        dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW, M, I, J, w)
+        db = torch.full((J,), 3.0, dtype=torch.float32, device=DEV)
+        dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW, M, I, J, w, dbias=db)
         ref = X.float().t() @ dY.float()
         close(dW, ref, 2e-3, 2e-3 * math.sqrt(M), f"gemm_tn trread={trread}")
+        close(db, dY.float().sum(0), 1e-4, 1e-3 * math.sqrt(M), f"gemm_tn fused bias grad trread={trread}")
+        dW2 = torch.zeros_like(dW)
+        dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW2, M, I, J, w)          # without the bias output
+        assert torch.equal(dW2, dW), "gemm_tn must be deterministic and independent of the bias option"
     finally:
         dh.set_option("tn_trread", 1)
 

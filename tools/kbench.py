@@ -13,7 +13,7 @@ import dalle_hip as dh
 DEV = "cuda"
 
 
-def timeit(fn, iters=20, warm=3):
+def timeit(fn, iters=int(os.environ.get('KB_ITERS', '20')), warm=int(os.environ.get('KB_WARM', '3'))):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -38,21 +38,24 @@ def bench_gemm_nt(M, N, K, flags=0, tag=""):
     A, Bt = rb(M, K), rb(N, K, scale=0.05)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     bias, res = rb(N), rb(M, N)
-    for glds in (1, 0):
-        dh.set_option("glds", glds)
+    for name, opts in (("nt2", dict(nt2=1, glds=1)), ("glds", dict(nt2=0, glds=1)), ("regstage", dict(nt2=0, glds=0))):
+        for k, v in opts.items():
+            dh.set_option(k, v)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res))
-        print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} glds={glds}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+        print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+    dh.set_option("nt2", 1)
     dh.set_option("glds", 1)
 
 
 def bench_gemm_tn(M, I, J):
     X, dY = rb(M, I), rb(M, J)
     dW = torch.empty(I, J, dtype=torch.float32, device=DEV)
+    db = torch.empty(J, dtype=torch.float32, device=DEV)
     w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
     for tr in (1, 0):
         dh.set_option("tn_trread", tr)
         try:
-            t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w))
+            t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db))
             print(f"gemm_tn M={M} I={I} J={J} trread={tr}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
         except Exception as ex:  # noqa
             print("gemm_tn failed", tr, ex)
@@ -127,6 +130,12 @@ if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), flush=True)
     M = 32 * 1280
     which = sys.argv[1:] or ["gemm", "tn", "attn", "misc"]
+    if "pmc" in which:   # short list for counter collection
+        bench_gemm_nt(8192, 8192, 8192, 0, tag="[square]")
+        bench_gemm_nt(M, 50816, 512, 1, tag="[logits]")
+        bench_gemm_nt(M, 2048, 512, 3, tag="[ffn1]")
+        bench_gemm_tn(M, 2048, 512)
+        bench_attention(32, 4, 1280)
     if "gemm" in which:
         bench_gemm_nt(M, 1536, 512, tag="[qkv]")
         bench_gemm_nt(M, 512, 512, 5, tag="[outproj]")
