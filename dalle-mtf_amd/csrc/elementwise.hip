@@ -505,6 +505,9 @@ extern "C" int dmi_transpose_bf16_strided(const uint16_t* in, uint16_t* out, int
                                           void* stream) {
   return dmi_transpose_padded(in, out, nb, nh, R, R, C, in_b_stride, in_h_stride, in_r_stride, stream);
 }
+extern "C" int dmi_transpose_bf16_padded(const uint16_t* in, uint16_t* out, int R_valid, int R_pitch, int C, void* stream) {
+  return dmi_transpose_padded(in, out, 1, 1, R_valid, R_pitch, C, 0, 0, C, stream);
+}
 extern "C" int dmi_transpose_bf16(const uint16_t* in, uint16_t* out, int batch, int R, int C, void* stream) {
   return dmi_transpose_bf16_strided(in, out, batch, 1, R, C, (int64_t)R * C, 0, C, stream);
 }

@@ -452,6 +452,7 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
     case DMI_GEMM_BIAS | DMI_GEMM_RELU: return launch_nt<DMI_GEMM_BIAS | DMI_GEMM_RELU>(a, 1, st);
     case DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL: return launch_nt<DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL>(a, 1, st);
     case DMI_GEMM_RELU_MASK: return launch_nt<DMI_GEMM_RELU_MASK>(a, 1, st);
+    case DMI_GEMM_RESIDUAL: return launch_nt<DMI_GEMM_RESIDUAL>(a, 1, st);
     case DMI_GEMM_OUT_F32: return launch_nt<DMI_GEMM_OUT_F32>(a, 1, st);
     default:
       dmi_set_error("gemm_nt: unsupported flag combination %d", flags);

@@ -1,0 +1,306 @@
+// vae.hip -- data-movement and pointwise kernels of the discrete-VAE path (reference
+// src/vae_tf/models.py:81-163, src/vae_tf/layers.py:4-25).
+//
+// Round-1 lowering of the convolutions: every flavour the reference uses (tf.layers.conv2d 4x4 s2 / 3x3 s1 / 1x1
+// SAME, conv2d_transpose 4x4 s2 SAME; forward, input gradient, weight gradient) is an im2col gather with an
+// explicit tap list followed by the MFMA GEMMs of gemm.hip (NT for fwd / dgrad, TN for wgrad):
+//   conv s1/s2 fwd      : taps (ky-pad, kx-pad), stride s           -> Y = col(X) . W^T
+//   conv s1 dgrad       : taps (pad-ky, pad-kx) on dY               -> dX = col(dY) . Wd^T ,  Wd[ci][(k,co)]
+//   conv s2 dgrad / conv-transpose fwd : 4 output-parity classes, 2x2 taps each, then a pixel interleave
+//   wgrad               : dW[(k,ci)][co] = col(X)^T . dY   (TN GEMM; lands in the TF kernel layout)
+// Activations are NHWC bf16 matrices [B*H*W, C] with C % 8 == 0 (the 3-channel image / reconstruction are padded
+// to 8 channels with zeros), so every access is a 16-byte vector.
+#include "common.h"
+
+#define MAX_TAPS 16
+struct TapList {
+  int n;
+  int dy[MAX_TAPS];
+  int dx[MAX_TAPS];
+};
+
+// out[(b,oy,ox)][t*C + c] = x[b, oy*s + dy[t], ox*s + dx[t], c]   (0 outside the image); row pitch ldo >= n*C,
+// columns [n*C, ldo) are zero-filled (K padding for the GEMM).
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ out, TapList taps,
+                                                     int B, int H, int W, int C, int Ho, int Wo, int stride, int ldo) {
+  const int cpr = ldo / 8;  // chunks per output row
+  const int64_t total = (int64_t)B * Ho * Wo * cpr;
+  const int cc = C / 8;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(idx % cpr);
+    const int64_t m = idx / cpr;
+    const int t = ch / cc, c8 = ch % cc;
+    u32x4 v = {0, 0, 0, 0};
+    if (t < taps.n) {
+      const int ox = (int)(m % Wo);
+      const int oy = (int)((m / Wo) % Ho);
+      const int b = (int)(m / ((int64_t)Wo * Ho));
+      const int iy = oy * stride + taps.dy[t], ix = ox * stride + taps.dx[t];
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *(const u32x4*)(x + (((int64_t)b * H + iy) * W + ix) * C + c8 * 8);
+    }
+    *(u32x4*)(out + m * ldo + ch * 8) = v;
+  }
+}
+
+extern "C" int dmi_im2col(const uint16_t* x, uint16_t* out, int B, int H, int W, int C, int Ho, int Wo, int stride,
+                          int ntaps, const int* dy, const int* dx, int ldo, void* stream) {
+  DMI_REQUIRE(x && out && dy && dx, "im2col: null pointer");
+  DMI_REQUIRE(C % 8 == 0 && ldo % 8 == 0 && ntaps >= 1 && ntaps <= MAX_TAPS && ldo >= ntaps * C, "im2col: need C%%8==0, ldo%%8==0, ldo>=ntaps*C (C=%d ntaps=%d ldo=%d)", C, ntaps, ldo);
+  TapList t;
+  t.n = ntaps;
+  for (int i = 0; i < ntaps; ++i) { t.dy[i] = dy[i]; t.dx[i] = dx[i]; }
+  const int64_t total = (int64_t)B * Ho * Wo * (ldo / 8);
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 65536) blocks = 65536;
+  im2col_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(x, out, t, B, H, W, C, Ho, Wo, stride, ldo);
+  DMI_CHECK_LAUNCH("im2col");
+  return DMI_OK;
+}
+
+// out[a][t*Bn + b] = in[idx[t]][a][b], row pitch ldo >= nsel*Bn, tail zero-filled
+// (weight re-layouts: [k][ci][co] -> [ci][(k',co)] for dgrad / output-parity GEMMs)
+__global__ __launch_bounds__(256) void weight_gather_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, TapList sel,
+                                                            int A, int Bn, int ldo) {
+  const int64_t total = (int64_t)A * ldo;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int j = (int)(i % ldo);
+    const int a = (int)(i / ldo);
+    const int t = j / Bn, b = j % Bn;
+    out[i] = (t < sel.n) ? in[((int64_t)sel.dy[t] * A + a) * Bn + b] : (bf16_t)0;
+  }
+}
+extern "C" int dmi_weight_gather(const uint16_t* in, uint16_t* out, int A, int Bn, int nsel, const int* idx, int ldo, void* stream) {
+  DMI_REQUIRE(in && out && idx && nsel >= 1 && nsel <= MAX_TAPS && A > 0 && Bn > 0 && ldo >= nsel * Bn, "weight_gather: bad args");
+  TapList t;
+  t.n = nsel;
+  for (int i = 0; i < nsel; ++i) { t.dy[i] = idx[i]; t.dx[i] = 0; }
+  const int64_t total = (int64_t)A * ldo;
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 4096) blocks = 4096;
+  weight_gather_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(in, out, t, A, Bn, ldo);
+  DMI_CHECK_LAUNCH("weight_gather");
+  return DMI_OK;
+}
+
+// out[b, 2t+py, 2u+px, :] = in[p = py*2+px][b, t, u, :]
+__global__ __launch_bounds__(256) void pixel_interleave_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B,
+                                                               int Ht, int Wt, int C) {
+  const int cc = C / 8;
+  const int64_t per = (int64_t)B * Ht * Wt * cc;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < 4 * per; idx += (int64_t)gridDim.x * 256) {
+    const int p = (int)(idx / per);
+    const int64_t r = idx % per;
+    const int c8 = (int)(r % cc);
+    const int64_t m = r / cc;
+    const int u = (int)(m % Wt), t = (int)((m / Wt) % Ht), b = (int)(m / ((int64_t)Wt * Ht));
+    const int py = p >> 1, px = p & 1;
+    *(u32x4*)(out + ((((int64_t)b * 2 * Ht + 2 * t + py) * 2 * Wt) + 2 * u + px) * C + c8 * 8) = *(const u32x4*)(in + idx * 8);
+  }
+}
+extern "C" int dmi_pixel_interleave(const uint16_t* in4, uint16_t* out, int B, int Ht, int Wt, int C, void* stream) {
+  DMI_REQUIRE(in4 && out && C % 8 == 0, "pixel_interleave: bad args");
+  const int64_t total = 4 * (int64_t)B * Ht * Wt * (C / 8);
+  int64_t blocks = cdiv64(total, 256);
+  if (blocks > 65536) blocks = 65536;
+  pixel_interleave_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(in4, out, B, Ht, Wt, C);
+  DMI_CHECK_LAUNCH("pixel_interleave");
+  return DMI_OK;
+}
+
+// image fp32 [N, Cin] -> bf16 [N, Cp] (zero padded channels)
+__global__ __launch_bounds__(256) void pad_channels_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t N,
+                                                           int Cin, int Cp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * Cp; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Cp);
+    const int64_t n = i / Cp;
+    out[i] = c < Cin ? f2bf(in[n * Cin + c]) : (bf16_t)0;
+  }
+}
+extern "C" int dmi_pad_channels(const float* in, uint16_t* out, int64_t N, int Cin, int Cp, void* stream) {
+  DMI_REQUIRE(in && out && N > 0 && Cin <= Cp, "pad_channels: bad args");
+  int64_t blocks = cdiv64(N * Cp, 256);
+  if (blocks > 16384) blocks = 16384;
+  pad_channels_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(in, out, N, Cin, Cp);
+  DMI_CHECK_LAUNCH("pad_channels");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// Gumbel-softmax (src/vae_tf/layers.py:4-21): g = -log(-log u); y = softmax((logits + g)/T); hard: one-hot of the
+// argmax (first max), straight-through gradient.  One wave per row; T columns (T % 8 == 0).
+// Uniform noise is an INPUT (TF's Philox stream cannot be reproduced; parity is on identical noise).
+// =====================================================================================
+template <int NC>  // NC = ceil(T/8/64) chunks per lane
+__global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
+                                                         bf16_t* __restrict__ y, bf16_t* __restrict__ y_soft,
+                                                         int* __restrict__ index, int64_t M, int T, float inv_temp, int hard) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= M) return;
+  const int nch = T / 8;
+  float v[NC][8];
+  float mx = -INFINITY;
+  int mi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f32x4 l = *(const f32x4*)(logits + row * T + c * 8 + 4 * q);
+        const f32x4 uu = *(const f32x4*)(u + row * T + c * 8 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = -logf(-logf(uu[e]));
+          const float z = (l[e] + g) * inv_temp;
+          v[i][4 * q + e] = z;
+          const int col = c * 8 + 4 * q + e;
+          if (z > mx || (z == mx && col < mi)) { mx = z; mi = col; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64);
+    const int oi = __shfl_xor(mi, o, 64);
+    if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = __expf(v[i][e] - mx);
+        s += v[i][e];
+      }
+    }
+  }
+  const float inv = 1.f / wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      float p[8], o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        p[e] = v[i][e] * inv;
+        o[e] = hard ? ((c * 8 + e == mi) ? 1.f : 0.f) : p[e];
+      }
+      *(u32x4*)(y_soft + row * T + c * 8) = pack8(p);
+      *(u32x4*)(y + row * T + c * 8) = pack8(o);
+    }
+  }
+  if (lane == 0 && index) index[row] = mi;
+}
+extern "C" int dmi_gumbel_softmax_fwd(const float* logits, const float* u, uint16_t* y, uint16_t* y_soft, int32_t* index,
+                                      int64_t M, int T, float temperature, int hard, void* stream) {
+  DMI_REQUIRE(logits && u && y && y_soft && M > 0 && T % 8 == 0 && T <= 4096 && temperature > 0.f, "gumbel_fwd: bad args (T=%d)", T);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv64(M, 4)), blk(256);
+  const float it = 1.f / temperature;
+  if (T <= 512) gumbel_fwd_kernel<1><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
+  else if (T <= 1024) gumbel_fwd_kernel<2><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
+  else if (T <= 2048) gumbel_fwd_kernel<4><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
+  else gumbel_fwd_kernel<8><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
+  DMI_CHECK_LAUNCH("gumbel_fwd");
+  return DMI_OK;
+}
+
+// dlogits = (1/T) * y_soft * (dy - sum_j dy_j y_soft_j)   (hard: straight-through => same formula on y_soft)
+__global__ __launch_bounds__(256) void gumbel_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y_soft,
+                                                         bf16_t* __restrict__ dlogits, int64_t M, int T, float inv_temp) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= M) return;
+  const int nch = T / 8;
+  float dot = 0.f;
+  for (int c = lane; c < nch; c += 64) {
+    float a[8], p[8];
+    unpack8(*(const u32x4*)(dy + row * T + c * 8), a);
+    unpack8(*(const u32x4*)(y_soft + row * T + c * 8), p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dot += a[e] * p[e];
+  }
+  dot = wave_sum(dot);
+  for (int c = lane; c < nch; c += 64) {
+    float a[8], p[8], o[8];
+    unpack8(*(const u32x4*)(dy + row * T + c * 8), a);
+    unpack8(*(const u32x4*)(y_soft + row * T + c * 8), p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = inv_temp * p[e] * (a[e] - dot);
+    *(u32x4*)(dlogits + row * T + c * 8) = pack8(o);
+  }
+}
+extern "C" int dmi_gumbel_softmax_bwd(const uint16_t* dy, const uint16_t* y_soft, uint16_t* dlogits, int64_t M, int T,
+                                      float temperature, void* stream) {
+  DMI_REQUIRE(dy && y_soft && dlogits && M > 0 && T % 8 == 0 && temperature > 0.f, "gumbel_bwd: bad args");
+  gumbel_bwd_kernel<<<dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream>>>(dy, y_soft, dlogits, M, T, 1.f / temperature);
+  DMI_CHECK_LAUNCH("gumbel_bwd");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// MSE (src/vae_tf/layers.py:24-25): loss = mean((img - out)^2) over N*Cin values; out bf16 [N, Cp] (Cp >= Cin padded);
+// d_out = 2 (out - img) * grad_scale / (N*Cin), pad channels 0.  partial sums -> dmi_sum_f32.
+// =====================================================================================
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ img, const bf16_t* __restrict__ outp,
+                                                  bf16_t* __restrict__ dout, float* __restrict__ part, int64_t N, int Cin, int Cp,
+                                                  float gscale) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * Cp; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % Cp);
+    const int64_t n = i / Cp;
+    float d = 0.f;
+    if (c < Cin) {
+      d = bf2f(outp[i]) - img[n * Cin + c];
+      acc += d * d;
+    }
+    if (dout) dout[i] = f2bf(d * gscale);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+#define MSE_BLOCKS 1024
+extern "C" int64_t dmi_mse_workspace_bytes(void) { return MSE_BLOCKS * 4; }
+extern "C" int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream);
+extern "C" int dmi_mse_loss(const float* img, const uint16_t* outp, uint16_t* dout, float* loss, int64_t N, int Cin, int Cp,
+                            float grad_scale, void* workspace, void* stream) {
+  DMI_REQUIRE(img && outp && loss && workspace && N > 0 && Cin <= Cp, "mse: bad args");
+  const float gs = 2.f * grad_scale / ((float)N * (float)Cin);
+  mse_kernel<<<dim3(MSE_BLOCKS), dim3(256), 0, (hipStream_t)stream>>>(img, outp, dout, (float*)workspace, N, Cin, Cp, gs);
+  DMI_CHECK_LAUNCH("mse");
+  return dmi_sum_f32((const float*)workspace, MSE_BLOCKS, 1.f / ((float)N * (float)Cin), loss, stream);
+}
+
+// dst += src  (fp32; the tied codebook receives gradients from the encoder and the decoder matmul)
+__global__ __launch_bounds__(256) void add_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] += src[i];
+}
+extern "C" int dmi_add_f32(float* dst, const float* src, int64_t n, void* stream) {
+  DMI_REQUIRE(dst && src && n > 0, "add_f32: bad args");
+  int64_t blocks = cdiv64(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  add_f32_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(dst, src, n);
+  DMI_CHECK_LAUNCH("add_f32");
+  return DMI_OK;
+}
+
+// bf16 [N, Cp] -> fp32 [N, Cin] (reconstruction image for summaries)
+__global__ __launch_bounds__(256) void unpad_channels_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t N, int Cin, int Cp) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * Cin; i += (int64_t)gridDim.x * 256)
+    out[i] = bf2f(in[(i / Cin) * Cp + (i % Cin)]);
+}
+extern "C" int dmi_unpad_channels(const uint16_t* in, float* out, int64_t N, int Cin, int Cp, void* stream) {
+  DMI_REQUIRE(in && out && N > 0 && Cin <= Cp, "unpad_channels: bad args");
+  int64_t blocks = cdiv64(N * Cin, 256);
+  if (blocks > 16384) blocks = 16384;
+  unpad_channels_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(in, out, N, Cin, Cp);
+  DMI_CHECK_LAUNCH("unpad_channels");
+  return DMI_OK;
+}

@@ -74,6 +74,17 @@ def _declare(L):
         "dmi_sumsq": (I, [P, L64, P, P, P]),
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P]),
         "dmi_cast_f32_bf16": (I, [P, P, L64, P]),
+        "dmi_transpose_bf16_padded": (I, [P, P, I, I, I, P]),
+        "dmi_im2col": (I, [P, P, I, I, I, I, I, I, I, I, P, P, I, P]),
+        "dmi_weight_gather": (I, [P, P, I, I, I, P, I, P]),
+        "dmi_pixel_interleave": (I, [P, P, I, I, I, I, P]),
+        "dmi_pad_channels": (I, [P, P, L64, I, I, P]),
+        "dmi_unpad_channels": (I, [P, P, L64, I, I, P]),
+        "dmi_gumbel_softmax_fwd": (I, [P, P, P, P, P, L64, I, F, I, P]),
+        "dmi_gumbel_softmax_bwd": (I, [P, P, P, L64, I, F, P]),
+        "dmi_mse_workspace_bytes": (L64, []),
+        "dmi_mse_loss": (I, [P, P, P, P, L64, I, I, F, P, P]),
+        "dmi_add_f32": (I, [P, P, L64, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -226,3 +237,68 @@ def adam_step(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, wd, 
 def cast_f32_bf16(inp, out, n):
     _dev(inp, out)
     _check(lib().dmi_cast_f32_bf16(_p(inp), _p(out), n, _stream()), "cast_f32_bf16")
+
+
+# ------------------------------------------------------------------ VAE wrappers
+
+def transpose_padded(inp, out, R_valid, R_pitch, C):
+    _dev(inp, out)
+    _check(lib().dmi_transpose_bf16_padded(_p(inp), _p(out), R_valid, R_pitch, C, _stream()), "transpose_padded")
+
+
+def _iarr(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def im2col(x, out, B, H, W, C, Ho, Wo, stride, taps, ldo):
+    """taps: list of (dy, dx) host tuples."""
+    _dev(x, out)
+    dy, dx = _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps])
+    _check(lib().dmi_im2col(_p(x), _p(out), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p),
+                            ctypes.cast(dx, c_void_p), ldo, _stream()), "im2col")
+
+
+def weight_gather(inp, out, A, Bn, idx, ldo):
+    _dev(inp, out)
+    ia = _iarr(idx)
+    _check(lib().dmi_weight_gather(_p(inp), _p(out), A, Bn, len(idx), ctypes.cast(ia, c_void_p), ldo, _stream()), "weight_gather")
+
+
+def pixel_interleave(in4, out, B, Ht, Wt, C):
+    _dev(in4, out)
+    _check(lib().dmi_pixel_interleave(_p(in4), _p(out), B, Ht, Wt, C, _stream()), "pixel_interleave")
+
+
+def pad_channels(inp, out, N, Cin, Cp):
+    _dev(inp, out)
+    _check(lib().dmi_pad_channels(_p(inp), _p(out), N, Cin, Cp, _stream()), "pad_channels")
+
+
+def unpad_channels(inp, out, N, Cin, Cp):
+    _dev(inp, out)
+    _check(lib().dmi_unpad_channels(_p(inp), _p(out), N, Cin, Cp, _stream()), "unpad_channels")
+
+
+def gumbel_softmax_fwd(logits, u, y, y_soft, index, M, T, temperature, hard):
+    _dev(logits, u, y, y_soft, index)
+    _check(lib().dmi_gumbel_softmax_fwd(_p(logits), _p(u), _p(y), _p(y_soft), _p(index), M, T, float(temperature), int(bool(hard)),
+                                        _stream()), "gumbel_softmax_fwd")
+
+
+def gumbel_softmax_bwd(dy, y_soft, dlogits, M, T, temperature):
+    _dev(dy, y_soft, dlogits)
+    _check(lib().dmi_gumbel_softmax_bwd(_p(dy), _p(y_soft), _p(dlogits), M, T, float(temperature), _stream()), "gumbel_softmax_bwd")
+
+
+def mse_workspace_bytes():
+    return lib().dmi_mse_workspace_bytes()
+
+
+def mse_loss(img, outp, dout, loss, N, Cin, Cp, grad_scale, ws):
+    _dev(img, outp, dout, loss, ws)
+    _check(lib().dmi_mse_loss(_p(img), _p(outp), _p(dout), _p(loss), N, Cin, Cp, float(grad_scale), _p(ws), _stream()), "mse_loss")
+
+
+def add_f32(dst, src, n):
+    _dev(dst, src)
+    _check(lib().dmi_add_f32(_p(dst), _p(src), n, _stream()), "add_f32")

@@ -1,0 +1,93 @@
+"""vae_model_fn -- same (features, labels, mode, params) contract as the reference (src/model_fns_tf.py:9-114):
+builds the DiscreteVAE, anneals the Gumbel temperature (:40-45), forward with reconstruction loss (:48-56),
+tf.train.AdamOptimizer(lr) semantics + mean over replicas (CrossShardOptimizer, :58-66), loss/image summaries
+(:68-107).  predict raises NotImplementedError as upstream (:30-31)."""
+import torch
+
+from .estimator import CheckpointSaverHook, EstimatorSpec, latest_checkpoint
+from .utils import ModeKeys, SummaryWriter, mode_to_str
+from .vae_tf import DiscreteVAE
+
+
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank(), dist.group.WORLD
+    return 1, 0, None
+
+
+def temperature_schedule(step, params):
+    """reference model_fns_tf.py:40-45."""
+    if params.get("temp_anneal_steps", None):
+        warmup_frac = min(float(step) / params["temp_anneal_steps"], 1.0)
+        return params["temp_start"] - warmup_frac * (params["temp_start"] - params["temp"])
+    t = params.get("temp")
+    return 1.0 if t is None else t
+
+
+def _build(params, mode_str):
+    world, rank, pg = _dist_info()
+    H = params["dataset"]["image_size"]
+    gbs = params[f"{mode_str}_batch_size"]
+    assert gbs % world == 0
+    n_channels = params.get("input_channels") or 3
+    model = DiscreteVAE(
+        num_tokens=params["num_tokens"],
+        dim=params["n_embd"],              # None in the VAE configs; unused by the tf VAE
+        hidden_dim=params["hidden_dim"],
+        input_channels=n_channels,
+        convblocks=params.get("convblocks") or [(3, 64), (3, 128), (3, 256)],
+        recompute_grad=params.get("recompute_grad") or False,
+        use_bf16=params.get("use_bf16") or False,
+        stack_factor=params.get("stack_factor") or 1,
+        dimensions=H, batch_size=gbs // world, mode=mode_str, process_group=pg, world_size=world)
+    ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
+    if ck is not None:
+        model.load_state_dict(torch.load(ck, map_location="cpu"))
+    else:
+        model.init_params(seed=params.get("seed") or 4321)
+    if world > 1:
+        import torch.distributed as dist
+        dist.broadcast(model.p, src=0, group=pg)
+        model.refresh_compute_copies(cast=True)
+    saver = CheckpointSaverHook(params.get("model_path"), params.get("steps_per_checkpoint"), model.state_dict,
+                                max_to_keep=params.get("max_checkpoints") or 5, is_chief=(rank == 0))
+    writer = SummaryWriter(params["model_path"]) if (params.get("model_path") and rank == 0) else None
+    return dict(model=model, saver=saver, writer=writer, rank=rank)
+
+
+def vae_model_fn(features, labels, mode, params):
+    mode_str = mode_to_str(mode)
+    if mode == ModeKeys.PREDICT:
+        raise NotImplementedError
+    assert mode in (ModeKeys.TRAIN, ModeKeys.EVAL)
+    key = f"_vae_state_{mode_str}"
+    if params.get(key) is None:
+        if mode == ModeKeys.EVAL and params.get("_vae_state_train") is not None and \
+                params["eval_batch_size"] == params["train_batch_size"]:
+            params[key] = params["_vae_state_train"]
+        else:
+            params[key] = _build(params, mode_str)
+    st = params[key]
+    model = st["model"]
+    model.mode = mode_str
+    train_gumbel = params.get("train_gumbel_hard")
+    eval_gumbel = params.get("eval_gumbel_hard")
+    train_gumbel = True if train_gumbel is None else train_gumbel
+    eval_gumbel = True if eval_gumbel is None else eval_gumbel
+    gumbel = train_gumbel if mode == ModeKeys.TRAIN else eval_gumbel
+    temp = temperature_schedule(model.global_step, params)
+    loss, reconstruction = model.forward(features, return_recon_loss=True, temperature=temp, hard_gumbel=gumbel,
+                                         need_grad=(mode == ModeKeys.TRAIN))
+    if mode == ModeKeys.EVAL:
+        return EstimatorSpec(mode=mode, loss=loss, eval_metrics={"_loss": loss})
+
+    def train_op():
+        model.backward()
+        model.optimizer_step(params["lr"])
+        return model.global_step
+
+    host_call = None
+    if st["writer"] is not None:
+        host_call = (lambda step, **kw: st["writer"].scalars(step, **kw), {"loss": loss, "temperature": temp})
+    return EstimatorSpec(mode=mode, loss=loss, train_op=train_op, host_call=host_call, training_hooks=[st["saver"]])

@@ -1,0 +1,484 @@
+"""DiscreteVAE -- same constructor / forward surface as the reference (src/vae_tf/models.py:46-184), re-hosted on
+libdalle_hip: every convolution is a tap-list im2col (dmi_im2col) feeding the MFMA GEMMs (dmi_gemm_nt / dmi_gemm_tn),
+Gumbel-softmax and MSE are dedicated kernels (csrc/vae.hip).  bf16 activations/weights, fp32 accumulation, fp32
+master weights and Adam state; the codebook logits are produced in fp32 (reference: fp32 matmul, models.py:113-118).
+
+Layer structure (reference lines): encoder 81-120: per block a 4x4 s2 SAME conv (no activation) then (stack-1) x
+`x + conv3x3(relu(conv3x3(x)))`; fp32 `x @ codebook`.  decoder 123-163: `y @ codebook^T` (tied), per reversed block a
+4x4 s2 conv-transpose (no activation) then the residual stacks, final 1x1 conv.  forward 165-184.
+
+Internal tensor conventions: activations NHWC as [B*H*W, C] bf16; the 3-channel image is padded to 8 channels and the
+3-channel reconstruction to 64 so that every GEMM keeps K % 64 == 0 / N % 8 == 0; the corresponding kernel rows /
+columns are zero and stay zero (their gradients are exactly 0).  `export_reference` / `load_reference_params`
+translate to the TF variable names and shapes of SURVEY.md Appendix B.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+import dalle_hip as dh
+
+IMG_CP = 8     # padded image channels
+OUT_CP = 64    # padded reconstruction channels
+ALIGN = 128
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+TAPS4 = [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]       # 4x4 s2 SAME: pad 1 before (Appendix A.8)
+TAPS3 = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]       # 3x3 s1 SAME
+TAPS3_REV = [(1 - ky, 1 - kx) for ky in range(3) for kx in range(3)]   # input gradient of the 3x3 conv
+
+
+def _parity(p):
+    """output-parity class of the stride-2 adjoint: [(k index, dy, dx)] for the 2x2 contributing taps."""
+    def ax(par):
+        return [(1, 0), (3, -1)] if par == 0 else [(0, 1), (2, 0)]   # (k, source offset)
+    py, px = p >> 1, p & 1
+    return [(ky * 4 + kx, dy, dx) for (ky, dy) in ax(py) for (kx, dx) in ax(px)]
+
+
+class _Conv:
+    def __init__(self, name, kind, cin, cout, H, W, cin_ref=None, cout_ref=None):
+        self.name, self.kind, self.cin, self.cout, self.H, self.W = name, kind, cin, cout, H, W
+        self.cin_ref = cin if cin_ref is None else cin_ref     # channels of the reference variable
+        self.cout_ref = cout if cout_ref is None else cout_ref
+        self.kk = {"down": 16, "up": 16, "res": 9, "final": 1}[kind]
+        if kind == "down":
+            self.Ho, self.Wo = H // 2, W // 2
+        elif kind == "up":
+            self.Ho, self.Wo = 2 * H, 2 * W
+        else:
+            self.Ho, self.Wo = H, W
+        # kernel stored [kk][A][Bn]: conv: A=cin, Bn=cout ; conv-transpose (TF [kh,kw,Cout,Cin]): A=cout(z), Bn=cin(y)
+        self.A, self.Bn = (cout, cin) if kind == "up" else (cin, cout)
+
+
+class DiscreteVAE:
+    def __init__(self, num_tokens, dimensions, convblocks, dim=512, hidden_dim=64, input_channels=3, recompute_grad=False,
+                 use_bf16=False, stack_factor=1, batch_size=32, mode="train", device="cuda", process_group=None, world_size=1):
+        if not torch.cuda.is_available():
+            raise dh.DalleHipError("DiscreteVAE needs a HIP device (MI355X); there is no CPU fallback")
+        dh.lib()
+        self.num_tokens = num_tokens
+        self.dim, self.hdim = dim, hidden_dim
+        self.num_ch = input_channels
+        self.H = self.W = dimensions
+        self.convblocks = [tuple(b) for b in convblocks]
+        self.recompute_grad = recompute_grad     # memory-only option upstream; activations are simply kept here
+        self.bf16 = use_bf16                     # kernels always compute in bf16 with fp32 accumulation
+        assert math.log2(stack_factor).is_integer()
+        if stack_factor != 1:
+            raise NotImplementedError("stack_factor > 1 (space_to_depth) is not used by any shipped config")
+        self.stack_factor = stack_factor
+        assert input_channels <= IMG_CP
+        for _, ch in self.convblocks:
+            assert ch % 16 == 0, "channel counts must be multiples of 16"
+        assert num_tokens % 64 == 0, "num_tokens must be a multiple of 64"
+        assert self.convblocks[-1][1] % 64 == 0, "the last block's channel count (codebook width) must be a multiple of 64"
+        self.B, self.mode = batch_size, mode
+        self.dev = torch.device(device)
+        self.pg, self.world = process_group, world_size
+        self.n_hid = self.convblocks[-1][1]
+        self.grid = self.H // (2 ** len(self.convblocks))
+        self.global_step = 0
+        self._build_graph()
+        self._alloc()
+
+    # ------------------------------------------------------------------ structure
+    def _build_graph(self):
+        convs: List[_Conv] = []
+        H, cin, cin_ref = self.H, IMG_CP, self.num_ch
+        for b, (stack, ch) in enumerate(self.convblocks):
+            for i in range(stack):
+                p = f"encoder/block_{b}/layer_{i}/"
+                if i == 0:
+                    convs.append(_Conv(p + "conv_downsample", "down", cin, ch, H, H, cin_ref=cin_ref))
+                    H //= 2
+                else:
+                    convs.append(_Conv(p + "conv_in", "res", ch, ch, H, H))
+                    convs.append(_Conv(p + "conv_out", "res", ch, ch, H, H))
+            cin = cin_ref = ch
+        self.n_enc = len(convs)
+        for b, (stack, ch) in enumerate(reversed(self.convblocks)):
+            for i in range(stack):
+                p = f"decoder/block_{b}/layer_{i}/"
+                if i == 0:
+                    convs.append(_Conv(p + "conv_upsample", "up", cin, ch, H, H))
+                    H *= 2
+                else:
+                    convs.append(_Conv(p + "conv_in", "res", ch, ch, H, H))
+                    convs.append(_Conv(p + "conv_out", "res", ch, ch, H, H))
+            cin = ch
+        convs.append(_Conv("decoder/conv2d", "final", cin, OUT_CP, H, H, cout_ref=self.num_ch))
+        self.convs = convs
+        # flat parameter layout
+        self.offset: Dict[str, int] = {}
+        self.shape: Dict[str, tuple] = {}
+        off = 0
+
+        def add(name, shp):
+            nonlocal off
+            self.offset[name], self.shape[name] = off, shp
+            off += _ru(int(np.prod(shp)), ALIGN)
+        for c in convs[:self.n_enc]:
+            add(c.name + "/kernel", (c.kk, c.A, c.Bn))
+            add(c.name + "/bias", (c.cout,))
+        add("codebook/codebook", (self.n_hid, self.num_tokens))
+        for c in convs[self.n_enc:]:
+            add(c.name + "/kernel", (c.kk, c.A, c.Bn))
+            add(c.name + "/bias", (c.cout,))
+        self.total = off
+
+    def _alloc(self):
+        B, dev = self.B, self.dev
+        b16 = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        n = self.total
+        self.p, self.g = torch.zeros(n, **f32), torch.zeros(n, **f32)
+        self.m, self.v = torch.zeros(n, **f32), torch.zeros(n, **f32)
+        self.pb = torch.zeros(n, **b16)
+        self.gc2 = torch.zeros(self.n_hid * self.num_tokens, **f32)  # second contribution to the tied codebook gradient
+        # derived weight copies
+        self.wf, self.wd, self.wp = {}, {}, {}
+        max_col = 0
+        for c in self.convs:
+            K = c.kk * c.cin
+            Kp = _ru(K, 64)
+            M_out = B * c.Ho * c.Wo
+            if c.kind in ("down", "res", "final"):
+                self.wf[c.name] = torch.zeros(c.cout, Kp, **b16)                         # [co][(k,ci)] fwd
+                max_col = max(max_col, M_out * Kp)
+            if c.kind == "res":
+                self.wd[c.name] = torch.zeros(c.cin, _ru(9 * c.cout, 64), **b16)         # [ci][(k,co)] dgrad
+                max_col = max(max_col, M_out * _ru(9 * c.cout, 64))
+            if c.kind == "down":
+                self.wp[c.name] = [torch.zeros(c.cin, _ru(4 * c.cout, 64), **b16) for _ in range(4)]  # dgrad parity
+                max_col = max(max_col, M_out * _ru(4 * c.cout, 64))
+            if c.kind == "up":
+                self.wp[c.name] = [torch.zeros(c.cout, _ru(4 * c.cin, 64), **b16) for _ in range(4)]  # fwd parity [cz][(a,b,cy)]
+                self.wd[c.name] = torch.zeros(c.cin, _ru(16 * c.cout, 64), **b16)        # [cy][(k,cz)] for dy
+                max_col = max(max_col, B * c.H * c.W * _ru(4 * c.cin, 64), B * c.H * c.W * _ru(16 * c.cout, 64))
+        self.codebook_t = torch.zeros(self.num_tokens, self.n_hid, **b16)
+        self.col = torch.empty(max_col, **b16)
+        # activations
+        self.x_img = torch.empty(B * self.H * self.W, IMG_CP, **b16)
+        self.act_in = [None] * len(self.convs)     # input of each conv (kept for the weight gradients)
+        self.act_out = []
+        for c in self.convs:
+            self.act_out.append(torch.empty(B * c.Ho * c.Wo, c.cout, **b16))
+        Mg = B * self.grid * self.grid
+        self.Mg = Mg
+        self.logits = torch.empty(Mg, self.num_tokens, **f32)
+        self.u = torch.empty(Mg, self.num_tokens, **f32)
+        self.y = torch.empty(Mg, self.num_tokens, **b16)
+        self.y_soft = torch.empty(Mg, self.num_tokens, **b16)
+        self.index = torch.empty(Mg, dtype=torch.int32, device=dev)
+        self.xdec = torch.empty(Mg, self.n_hid, **b16)
+        self.loss = torch.zeros(1, **f32)
+        # scratch for parity outputs and gradients
+        max_act = max(int(a.numel()) for a in self.act_out + [self.x_img])
+        self.par = torch.empty(max_act, **b16)
+        self.ga = torch.empty(max_act, **b16)
+        self.gb = torch.empty(max_act, **b16)
+        self.gc = torch.empty(max_act, **b16)
+        self.dy = torch.empty(Mg, self.num_tokens, **b16)
+        self.dlogits = torch.empty(Mg, self.num_tokens, **b16)
+        wsz = 1 << 20
+        for c in self.convs:
+            M_out = B * c.Ho * c.Wo
+            M_in = B * c.H * c.W
+            wsz = max(wsz, dh.gemm_tn_workspace_bytes(max(M_out, M_in), c.kk * max(c.cin, c.cout), max(c.cin, c.cout)),
+                      dh.colsum_workspace_bytes(max(M_out, M_in), max(c.cout, c.cin)))
+        wsz = max(wsz, dh.gemm_tn_workspace_bytes(Mg, self.n_hid, self.num_tokens), dh.mse_workspace_bytes())
+        self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, buf, name):
+        o = self.offset[name]
+        shp = self.shape[name]
+        return buf[o:o + int(np.prod(shp))].view(shp)
+
+    def init_params(self, seed=4321):
+        """glorot-uniform kernels / codebook, zero biases (tf.layers defaults)."""
+        g = torch.Generator().manual_seed(seed)
+        P = OrderedDict()
+        for name, shp in self.reference_variables().items():
+            if len(shp) == 1:
+                P[name] = np.zeros(shp, np.float32)
+            else:
+                if len(shp) == 4:
+                    rf = shp[0] * shp[1]
+                    fi, fo = shp[2] * rf, shp[3] * rf
+                else:
+                    fi, fo = shp
+                lim = math.sqrt(6.0 / (fi + fo))
+                P[name] = ((torch.rand(*shp, generator=g) * 2 - 1) * lim).numpy()
+        self.load_reference_params(P)
+
+    def reference_variables(self) -> "OrderedDict[str, tuple]":
+        out: "OrderedDict[str, tuple]" = OrderedDict()
+        for i, c in enumerate(self.convs):
+            if i == self.n_enc:
+                out["codebook/codebook"] = (self.n_hid, self.num_tokens)
+            k = {16: 4, 9: 3, 1: 1}[c.kk]
+            if c.kind == "up":
+                out[c.name + "/kernel"] = (k, k, c.cout_ref, c.cin_ref)
+            else:
+                out[c.name + "/kernel"] = (k, k, c.cin_ref, c.cout_ref)
+            out[c.name + "/bias"] = (c.cout_ref,)
+        return out
+
+    def load_reference_params(self, P: Dict[str, np.ndarray]):
+        with torch.no_grad():
+            self.p.zero_()
+            for c in self.convs:
+                w = torch.from_numpy(np.ascontiguousarray(P[c.name + "/kernel"])).float()
+                k = w.shape[0]
+                w = w.reshape(k * k, w.shape[2], w.shape[3])
+                dst = self.view(self.p, c.name + "/kernel")
+                dst[:, :w.shape[1], :w.shape[2]] = w
+                bsrc = torch.from_numpy(np.ascontiguousarray(P[c.name + "/bias"])).float()
+                self.view(self.p, c.name + "/bias")[:bsrc.shape[0]] = bsrc
+            self.view(self.p, "codebook/codebook").copy_(torch.from_numpy(np.ascontiguousarray(P["codebook/codebook"])))
+        self.refresh_compute_copies(cast=True)
+
+    def export_reference(self, buf=None) -> "OrderedDict[str, np.ndarray]":
+        buf = self.p if buf is None else buf
+        out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+        ref = self.reference_variables()
+        for c in self.convs:
+            shp = ref[c.name + "/kernel"]
+            a = self.view(buf, c.name + "/kernel").detach().float().cpu().numpy()
+            out[c.name + "/kernel"] = np.ascontiguousarray(a[:, :shp[2], :shp[3]]).reshape(shp)
+            out[c.name + "/bias"] = np.ascontiguousarray(self.view(buf, c.name + "/bias").detach().float().cpu().numpy()[:shp[3] if c.kind != "up" else shp[2]])
+        out["codebook/codebook"] = self.view(buf, "codebook/codebook").detach().float().cpu().numpy()
+        return out
+
+    def refresh_compute_copies(self, cast=False):
+        if cast:
+            dh.cast_f32_bf16(self.p, self.pb, self.total)
+        for c in self.convs:
+            wn = self.view(self.pb, c.name + "/kernel")            # [kk][A][Bn] bf16
+            K = c.kk * c.cin
+            if c.kind in ("down", "res", "final"):
+                dh.transpose_padded(wn, self.wf[c.name], K, _ru(K, 64), c.cout)          # [(k,ci)][co] -> [co][(k,ci)]
+            if c.kind == "res":
+                dh.weight_gather(wn, self.wd[c.name], c.cin, c.cout, list(range(9)), _ru(9 * c.cout, 64))
+            if c.kind == "down":
+                for p in range(4):
+                    dh.weight_gather(wn, self.wp[c.name][p], c.cin, c.cout, [t[0] for t in _parity(p)], _ru(4 * c.cout, 64))
+            if c.kind == "up":
+                for p in range(4):
+                    dh.weight_gather(wn, self.wp[c.name][p], c.cout, c.cin, [t[0] for t in _parity(p)], _ru(4 * c.cin, 64))
+                Kz = 16 * c.cout
+                dh.transpose_padded(wn, self.wd[c.name], Kz, _ru(Kz, 64), c.cin)         # [(k,cz)][cy] -> [cy][(k,cz)]
+        cb = self.view(self.pb, "codebook/codebook")
+        dh.transpose(cb, self.codebook_t, 1, self.n_hid, self.num_tokens)
+
+    # ------------------------------------------------------------------ conv building blocks
+    def _w(self, name):
+        return self.view(self.pb, name)
+
+    def _conv_fwd(self, c: _Conv, x, out, flags=0, residual=None):
+        B = self.B
+        bias = self._w(c.name + "/bias")
+        if c.kind == "final" and c.cin % 64 == 0:
+            dh.gemm_nt(x, c.cin, self.wf[c.name], c.cin, out, c.cout, B * c.H * c.W, c.cout, c.cin, flags | dh.GEMM_BIAS, bias=bias)
+        elif c.kind in ("down", "res", "final"):
+            K = c.kk * c.cin
+            Kp = _ru(K, 64)
+            taps, s = {"down": (TAPS4, 2), "res": (TAPS3, 1), "final": ([(0, 0)], 1)}[c.kind]
+            dh.im2col(x, self.col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
+            dh.gemm_nt(self.col, Kp, self.wf[c.name], Kp, out, c.cout, B * c.Ho * c.Wo, c.cout, Kp, flags | dh.GEMM_BIAS,
+                       bias=bias, residual=residual)
+        else:  # up: 4 output-parity GEMMs + interleave
+            Kp = _ru(4 * c.cin, 64)
+            Mi = B * c.H * c.W
+            for p in range(4):
+                taps = [(t[1], t[2]) for t in _parity(p)]
+                dh.im2col(x, self.col, B, c.H, c.W, c.cin, c.H, c.W, 1, taps, Kp)
+                dh.gemm_nt(self.col, Kp, self.wp[c.name][p], Kp, self.par[p * Mi * c.cout:], c.cout, Mi, c.cout, Kp, dh.GEMM_BIAS, bias=bias)
+            dh.pixel_interleave(self.par, out, B, c.H, c.W, c.cout)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, features, return_recon_loss=False, return_logits=False, hard_gumbel=True, temperature=1.0, noise=None,
+                need_grad=None):
+        """features: images NHWC fp32 in [-1,1] (or {"inputs": ...}).  Mirrors vae_tf/models.py:165-184.
+        `noise`: optional uniforms [B,g,g,num_tokens] in [1e-9,1) (injected for parity; drawn with torch.rand otherwise)."""
+        img = features["inputs"] if isinstance(features, dict) else features
+        img = img.to(device=self.dev, dtype=torch.float32).contiguous()
+        B = self.B
+        assert img.shape == (B, self.H, self.W, self.num_ch), f"expected {(B, self.H, self.W, self.num_ch)}, got {tuple(img.shape)}"
+        self.img = img
+        dh.pad_channels(img, self.x_img, B * self.H * self.W, self.num_ch, IMG_CP)
+        x = self.x_img
+        convs = self.convs
+        i = 0
+        while i < self.n_enc:
+            c = convs[i]
+            self.act_in[i] = x
+            if c.kind == "down":
+                self._conv_fwd(c, x, self.act_out[i])
+                x = self.act_out[i]
+                i += 1
+            else:  # residual pair: conv_in (bias+relu), conv_out (bias + residual x)
+                self._conv_fwd(c, x, self.act_out[i], flags=dh.GEMM_RELU)
+                self.act_in[i + 1] = self.act_out[i]
+                self._conv_fwd(convs[i + 1], self.act_out[i], self.act_out[i + 1], flags=dh.GEMM_RESIDUAL, residual=x)
+                x = self.act_out[i + 1]
+                i += 2
+        self.x_enc = x
+        dh.gemm_nt(x, self.n_hid, self.codebook_t, self.n_hid, self.logits, self.num_tokens, self.Mg, self.num_tokens, self.n_hid,
+                   dh.GEMM_OUT_F32)
+        if return_logits:
+            return self.logits.view(B, self.grid, self.grid, self.num_tokens)
+        if noise is None:
+            self.u.uniform_(1e-9, 1.0)
+        else:
+            self.u.copy_(noise.to(self.dev).reshape(self.Mg, self.num_tokens))
+        self.temperature = float(temperature)
+        dh.gumbel_softmax_fwd(self.logits, self.u, self.y, self.y_soft, self.index, self.Mg, self.num_tokens, self.temperature, hard_gumbel)
+        dh.gemm_nt(self.y, self.num_tokens, self._w("codebook/codebook"), self.num_tokens, self.xdec, self.n_hid, self.Mg, self.n_hid,
+                   self.num_tokens)
+        x = self.xdec
+        while i < len(convs):
+            c = convs[i]
+            self.act_in[i] = x
+            if c.kind in ("up", "final"):
+                self._conv_fwd(c, x, self.act_out[i])
+                x = self.act_out[i]
+                i += 1
+            else:
+                self._conv_fwd(c, x, self.act_out[i], flags=dh.GEMM_RELU)
+                self.act_in[i + 1] = self.act_out[i]
+                self._conv_fwd(convs[i + 1], self.act_out[i], self.act_out[i + 1], flags=dh.GEMM_RESIDUAL, residual=x)
+                x = self.act_out[i + 1]
+                i += 2
+        self.out_pad = x
+        if not return_recon_loss:
+            return self.reconstruction()
+        need_grad = (self.mode == "train") if need_grad is None else need_grad
+        # d(out) of mean((img-out)^2); 1/world folds the CrossShardOptimizer mean (src/model_fns_tf.py:61) into the gradient
+        dh.mse_loss(img, x, self.ga if need_grad else None, self.loss, B * self.H * self.W, self.num_ch, OUT_CP, 1.0, self.ws)
+        return self.loss[0], self.reconstruction()
+
+    def reconstruction(self):
+        out = torch.empty(self.B, self.H, self.W, self.num_ch, dtype=torch.float32, device=self.dev)
+        dh.unpad_channels(self.out_pad, out, self.B * self.H * self.W, self.num_ch, OUT_CP)
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def _gv(self, name):
+        return self.view(self.g, name)
+
+    def _wgrad(self, c: _Conv, x_in, dy):
+        """dW[(k,ci)][co] = col(x)^T . dy (+ bias gradient fused) -- lands directly in the TF kernel layout."""
+        B = self.B
+        if c.kind == "final":
+            dh.gemm_tn(x_in, c.cin, dy, c.cout, self._gv(c.name + "/kernel"), B * c.H * c.W, c.cin, c.cout, self.ws,
+                       dbias=self._gv(c.name + "/bias"))
+            return
+        K = c.kk * c.cin
+        Kp = _ru(K, 64)
+        taps, s = (TAPS4, 2) if c.kind == "down" else (TAPS3, 1)
+        dh.im2col(x_in, self.col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
+        dh.gemm_tn(self.col, Kp, dy, c.cout, self._gv(c.name + "/kernel"), B * c.Ho * c.Wo, K, c.cout, self.ws,
+                   dbias=self._gv(c.name + "/bias"))
+
+    def _dgrad3(self, c: _Conv, dy, out, flags=0, residual=None, relu_src=None):
+        Kp = _ru(9 * c.cout, 64)
+        dh.im2col(dy, self.col, self.B, c.H, c.W, c.cout, c.H, c.W, 1, TAPS3_REV, Kp)
+        dh.gemm_nt(self.col, Kp, self.wd[c.name], Kp, out, c.cin, self.B * c.H * c.W, c.cin, Kp, flags, residual=residual, relu_src=relu_src)
+
+    def backward(self):
+        """Gradients of the last forward(return_recon_loss=True) into the flat fp32 buffer `g`."""
+        B, convs = self.B, self.convs
+        d = self.ga                       # gradient wrt the padded reconstruction [M0, 64]
+        spare = [self.gb, self.gc]
+        i = len(convs) - 1
+        while i >= 0:
+            c = convs[i]
+            if c.kind == "final":
+                M = B * c.H * c.W
+                self._wgrad(c, self.act_in[i], d)
+                nd = spare[0]
+                dh.gemm_nt(d, c.cout, self._w(c.name + "/kernel"), c.cout, nd, c.cin, M, c.cin, c.cout)   # K = 64 padded channels
+                spare[0], d = d, nd
+                i -= 1
+            elif c.kind == "res":           # c = conv_out of a residual pair (i-1 = conv_in)
+                cin_conv = convs[i - 1]
+                x_in, r = self.act_in[i - 1], self.act_in[i]
+                self._wgrad(c, r, d)
+                da = spare[0]
+                self._dgrad3(c, d, da, flags=dh.GEMM_RELU_MASK, relu_src=r)
+                self._wgrad(cin_conv, x_in, da)
+                nd = spare[1]
+                self._dgrad3(cin_conv, da, nd, flags=dh.GEMM_RESIDUAL, residual=d)
+                spare[1], d = d, nd
+                i -= 2
+            elif c.kind == "up":
+                Mi = B * c.H * c.W
+                Kz = 16 * c.cout
+                Kzp = _ru(Kz, 64)
+                dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, Kzp)     # stride-2 conv view of dz
+                dh.gemm_tn(self.col, Kzp, self.act_in[i], c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, self.ws)
+                dh.colsum(d, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+                nd = spare[0]
+                dh.gemm_nt(self.col, Kzp, self.wd[c.name], Kzp, nd, c.cin, Mi, c.cin, Kzp)
+                spare[0], d = d, nd
+                i -= 1
+            else:  # down
+                self._wgrad(c, self.act_in[i], d)
+                if i > 0:
+                    Mo = B * c.Ho * c.Wo
+                    Kp = _ru(4 * c.cout, 64)
+                    for p in range(4):
+                        taps = [(t[1], t[2]) for t in _parity(p)]
+                        dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, Kp)
+                        dh.gemm_nt(self.col, Kp, self.wp[c.name][p], Kp, self.par[p * Mo * c.cin:], c.cin, Mo, c.cin, Kp)
+                    nd = spare[0]
+                    dh.pixel_interleave(self.par, nd, B, c.Ho, c.Wo, c.cin)
+                    spare[0], d = d, nd
+                i -= 1
+            if i == self.n_enc - 1:
+                # ---- tied codebook + gumbel (between decoder and encoder); d = gradient wrt xdec [Mg, n_hid]
+                T, nh, Mg = self.num_tokens, self.n_hid, self.Mg
+                dh.gemm_tn(d, nh, self.y, T, self.gc2, Mg, nh, T, self.ws)                               # dC from x_dec = y C^T
+                dh.gemm_nt(d, nh, self.codebook_t, nh, self.dy, T, Mg, T, nh)                            # dy = dxdec . C
+                dh.gumbel_softmax_bwd(self.dy, self.y_soft, self.dlogits, Mg, T, self.temperature)
+                dh.gemm_tn(self.x_enc, nh, self.dlogits, T, self._gv("codebook/codebook"), Mg, nh, T, self.ws)  # dC from logits = x C
+                dh.add_f32(self._gv("codebook/codebook"), self.gc2, nh * T)
+                nd = spare[0]
+                dh.gemm_nt(self.dlogits, T, self._w("codebook/codebook"), T, nd, nh, Mg, nh, T)          # dx_enc = dlogits . C^T
+                spare[0], d = d, nd
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=self.pg)
+
+    # ------------------------------------------------------------------ optimizer
+    def optimizer_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        """tf.train.AdamOptimizer (src/model_fns_tf.py:58-60; Appendix A.8): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+        p -= lr_t*m/(sqrt(v)+eps).  grad_scale 1/world = CrossShardOptimizer's mean over replicas (:61)."""
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+        dh.adam_step(self.p, self.g, self.m, self.v, self.pb, self.total, None, 0.0, lr_t, beta1, beta2, eps, 0.0, 1.0 / self.world)
+        self.refresh_compute_copies(cast=False)
+        self.global_step += 1
+
+    def state_dict(self):
+        return {"vae_variables": self.export_reference(), "m": self.m.detach().cpu(), "v": self.v.detach().cpu(),
+                "global_step": self.global_step}
+
+    def load_state_dict(self, sd):
+        self.load_reference_params(sd["vae_variables"])
+        if "m" in sd:
+            self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
+        self.global_step = int(sd.get("global_step", 0))

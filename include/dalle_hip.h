@@ -126,6 +126,36 @@ int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16
 /* fp32 -> bf16 cast (initial weight export) */
 int dmi_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 
+/* in [R_valid, C] -> out [C, R_pitch] with columns [R_valid, R_pitch) zero (K-padding of transposed conv kernels) */
+int dmi_transpose_bf16_padded(const uint16_t* in, uint16_t* out, int R_valid, int R_pitch, int C, void* stream);
+
+/* ================= discrete VAE (src/vae_tf/models.py:81-163, src/vae_tf/layers.py:4-25) =================
+ * K11 convolutions = tap-list im2col + dmi_gemm_nt / dmi_gemm_tn (round-1 lowering, see csrc/vae.hip).
+ * activations NHWC bf16 [B*H*W, C], C % 8 == 0. */
+/* out[(b,oy,ox)][t*C + c] = x[b, oy*stride + dy[t], ox*stride + dx[t], c] (0 outside); row pitch ldo, tail zero-filled.
+ * dy/dx are HOST arrays (ntaps <= 16). */
+int dmi_im2col(const uint16_t* x, uint16_t* out, int B, int H, int W, int C, int Ho, int Wo, int stride,
+               int ntaps, const int* dy, const int* dx, int ldo, void* stream);
+/* out[a][t*Bn + b] = in[idx[t]][a][b], row pitch ldo (tail zero)  (conv kernel [k][ci][co] -> [ci][(k',co)] for the
+ * dgrad / output-parity GEMMs); idx on HOST */
+int dmi_weight_gather(const uint16_t* in, uint16_t* out, int A, int Bn, int nsel, const int* idx, int ldo, void* stream);
+/* out[b, 2t+py, 2u+px, :] = in4[py*2+px][b, t, u, :]  (assembles a stride-2 transposed convolution) */
+int dmi_pixel_interleave(const uint16_t* in4, uint16_t* out, int B, int Ht, int Wt, int C, void* stream);
+/* fp32 [N, Cin] <-> bf16 [N, Cp] (zero-padded channels): image in, reconstruction out */
+int dmi_pad_channels(const float* in, uint16_t* out, int64_t N, int Cin, int Cp, void* stream);
+int dmi_unpad_channels(const uint16_t* in, float* out, int64_t N, int Cin, int Cp, void* stream);
+/* K13 gumbel_softmax (layers.py:4-21) with INJECTED uniforms u in [1e-9, 1): y = softmax((logits - log(-log u))/T);
+ * hard: y = one_hot(argmax) (first max), gradient straight-through.  y, y_soft bf16 [M,T]; index int32 [M] (nullable). */
+int dmi_gumbel_softmax_fwd(const float* logits, const float* u, uint16_t* y, uint16_t* y_soft, int32_t* index,
+                           int64_t M, int T, float temperature, int hard, void* stream);
+int dmi_gumbel_softmax_bwd(const uint16_t* dy, const uint16_t* y_soft, uint16_t* dlogits, int64_t M, int T,
+                           float temperature, void* stream);
+/* K14 mse_loss (layers.py:24-25): loss[0] = mean((img - out)^2) over N*Cin; dout (nullable) = 2(out-img)*grad_scale/(N*Cin) */
+int64_t dmi_mse_workspace_bytes(void);
+int dmi_mse_loss(const float* img, const uint16_t* outp, uint16_t* dout, float* loss, int64_t N, int Cin, int Cp,
+                 float grad_scale, void* workspace, void* stream);
+int dmi_add_f32(float* dst, const float* src, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DALLE_SMALL = dict(n_embd=128, text_vocab_size=120, image_vocab_size=24, text_seq_len=24, image_seq_len=40,
                    n_layers=2, n_heads=1)
 HP = dict(lr=1e-3, train_steps=1000, warmup_steps=2, gradient_clipping=1.0)
+VAE_SMALL = dict(num_tokens=64, dimensions=16, convblocks=[[2, 16], [2, 64]])
 
 
 def dalle_case():
@@ -50,7 +51,7 @@ def dalle_case():
 
 
 def vae_case():
-    cfg = vo.VaeConfig(num_tokens=32, dimensions=16, convblocks=[[2, 16], [2, 32]])
+    cfg = vo.VaeConfig(**VAE_SMALL)
     P = vo.init_params(cfg, seed=11, bias_perturb=0.02)
     img = vo.synthetic_images(2, 16, seed=3)
     u = vo.synthetic_uniforms((2, cfg.grid, cfg.grid, cfg.num_tokens), seed=4)
@@ -61,8 +62,7 @@ def vae_case():
     loss_s, grads_s, out_s = vo.loss_and_grads(P, img, u, cfg, hard=False, temp=0.7)
     res = dict(img=img, u=u, logits=logits, tokens=np.argmax(logits, -1).reshape(2, -1).astype(np.int32),
                loss_hard=np.float32(loss_h), recon_hard=out_h, loss_soft=np.float32(loss_s), recon_soft=out_s)
-    for k in ("encoder/block_0/layer_0/conv_downsample/kernel", "encoder/block_1/layer_1/conv_out/bias", "codebook/codebook",
-              "decoder/block_0/layer_0/conv_upsample/kernel", "decoder/conv2d/kernel"):
+    for k in grads_h:
         res["grad_hard:" + k] = grads_h[k]
         res["grad_soft:" + k] = grads_s[k]
     np.savez_compressed(os.path.join(HERE, "vae_small.npz"), **res)

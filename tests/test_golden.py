@@ -44,7 +44,7 @@ def test_oracle_reproduces_dalle_golden():
 
 
 def test_oracle_reproduces_vae_golden():
-    cfg = vo.VaeConfig(num_tokens=32, dimensions=16, convblocks=[[2, 16], [2, 32]])
+    cfg = vo.VaeConfig(**mg.VAE_SMALL)
     P = vo.init_params(cfg, seed=11, bias_perturb=0.02)
     Pt = OrderedDict((k, torch.tensor(v)) for k, v in P.items())
     logits = vo.forward(Pt, torch.tensor(GV["img"]), cfg, return_logits=True).numpy()
@@ -83,3 +83,45 @@ def test_hip_matches_dalle_golden():
     assert abs(eng.grad_norm() - float(G["gnorm"])) <= 3e-2 * float(G["gnorm"])
     after = eng.export_reference(eng.p)
     assert np.abs(after["layer_0/attn/q"] - G["after:layer_0/attn/q"]).max() <= 6.5 * float(G["lr"])
+
+
+@pytest.mark.gpu
+def test_hip_matches_vae_golden():
+    """VAE rows v1-v4: encoder logits / argmax tokens, Gumbel (injected noise), decoder, MSE, all gradients.
+    bf16 compute vs the fp32 oracle: logits rtol 3e-2 of their scale; hard-Gumbel indices must agree wherever the
+    oracle's top-2 gap exceeds the bf16 error bound (counted); loss within 3e-2; gradients within 1e-1 rel-L2."""
+    from src.vae_tf import DiscreteVAE
+    c = mg.VAE_SMALL
+    cfg = vo.VaeConfig(**c)
+    P = vo.init_params(cfg, seed=11, bias_perturb=0.02)
+    vae = DiscreteVAE(num_tokens=c["num_tokens"], dimensions=c["dimensions"], convblocks=c["convblocks"], batch_size=2)
+    vae.load_reference_params(P)
+    back = vae.export_reference()
+    for k in P:
+        assert np.allclose(back[k], P[k]), k
+    img = torch.from_numpy(GV["img"]).cuda()
+    logits = vae.forward(img, return_logits=True).cpu().numpy()
+    ref = GV["logits"]
+    scale = np.abs(ref).max()
+    err = np.abs(logits - ref).max()
+    assert err <= 3e-2 * scale, (err, scale)
+    tok = np.argmax(logits, -1).reshape(2, -1)
+    srt = np.sort(ref, -1)
+    gap = (srt[..., -1] - srt[..., -2]).reshape(2, -1)
+    safe = gap > 2 * err
+    assert np.array_equal(tok[safe], GV["tokens"][safe]), "argmax differs where the oracle's top-2 gap exceeds the error bound"
+    for hard, temp, lk, gk in ((True, 1.0, "loss_hard", "grad_hard:"), (False, 0.7, "loss_soft", "grad_soft:")):
+        loss, recon = vae.forward(img, return_recon_loss=True, hard_gumbel=hard, temperature=temp,
+                                  noise=torch.from_numpy(GV["u"]), need_grad=True)
+        loss = float(loss)
+        assert abs(loss - float(GV[lk])) <= 3e-2 * float(GV[lk]), (hard, loss, float(GV[lk]))
+        vae.backward()
+        gh = vae.export_reference(vae.g)
+        worst = 0.0
+        for k in GV.files:
+            if k.startswith(gk):
+                a, b = gh[k[len(gk):]].astype(np.float64), GV[k].astype(np.float64)
+                rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+                worst = max(worst, rel)
+                assert rel <= (0.35 if hard else 0.1), (hard, k, rel)   # hard: one flipped argmax changes whole rows
+        print("vae", "hard" if hard else "soft", "loss", loss, "worst grad rel-L2", worst)
