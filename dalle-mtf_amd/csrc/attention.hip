@@ -197,9 +197,10 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16
 // =====================================================================================
 // backward
 // =====================================================================================
-// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d]
+// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d];  also stats[b,h,s] = (lse, delta) pairs for the dK/dV kernel's DMA
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
-                                                         float* __restrict__ delta, int B, int H, int S) {
+                                                         const float* __restrict__ lse, float* __restrict__ delta,
+                                                         float* __restrict__ stats, int B, int H, int S) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wid;
   if (row >= (int64_t)B * S) return;
@@ -217,7 +218,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((lane & 15) == 0 && c < d / 8) delta[((int64_t)b * H + c / 16) * S + s] = acc;
+    if ((lane & 15) == 0 && c < d / 8) {
+      const int64_t idx = ((int64_t)b * H + c / 16) * S + s;
+      delta[idx] = acc;
+      stats[2 * idx] = lse[idx];
+      stats[2 * idx + 1] = acc;
+    }
   }
 }
 
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = 64 * j + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float p = (key > qrow) ? 0.f : __expf(s[e] - lse_q);
+        const float p = __expf((key > qrow) ? -INFINITY : (s[e] - lse_q));  // unconditional exp: no per-element branches
         ds[e] = p * (dp[e] - delta_q);
       }
       bf16x8 dsb[2];
@@ -318,38 +324,124 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ qt,
-                                                              const bf16_t* __restrict__ d_o, const bf16_t* __restrict__ dot,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+// ---- dK/dV kernel v2 -------------------------------------------------------------------------------------------
+// Block = 128 keys (4 waves x 32), loop over 32-query tiles from the diagonal down.
+//   S = Q K^T, dP = dO V^T           : A operands (rows = queries) read with ds_read_b128 from the NATURAL Q / dO tiles
+//   dV^T += dO^T P, dK^T += Q^T dS   : A operands (rows = d) are the TRANSPOSE of the same tiles -> ds_read_b64_tr_b16
+// so only two 8-KiB tiles (+ 256 B of (lse, delta) pairs) stream per step, by LDS-DMA into a 2-stage ring: loads of
+// step t+1 are in flight during the MFMAs of step t, one barrier per step.  LDS rows are 256 B linear (DMA), 16-B chunk
+// index XOR ((row&3)<<2 | (row>>2)&3) on the source side: 16 consecutive rows hit 16 distinct chunks (b128 reads
+// conflict-free) and the 4 rows x 64 B of a transpose-read group cover all banks once.
+// Transposed reads go through inline asm (see gemm.hip: hipcc serialises the intrinsic behind in-flight LDS-DMA).
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+struct Tr4 {
+  u32x2 a0, a1, b0, b1, c0, c1, d0, d1;  // 4 fragments (dt = 0..3) x {keys/queries +0..3, +8..11}
+};
+__device__ __forceinline__ void tr4_issue(Tr4& f, unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, unsigned lo2,
+                                          unsigned hi2, unsigned lo3, unsigned hi3) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\t"
+      "ds_read_b64_tr_b16 %1, %9\n\t"
+      "ds_read_b64_tr_b16 %2, %10\n\t"
+      "ds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\t"
+      "ds_read_b64_tr_b16 %5, %13\n\t"
+      "ds_read_b64_tr_b16 %6, %14\n\t"
+      "ds_read_b64_tr_b16 %7, %15"
+      : "=&v"(f.a0), "=&v"(f.a1), "=&v"(f.b0), "=&v"(f.b1), "=&v"(f.c0), "=&v"(f.c1), "=&v"(f.d0), "=&v"(f.d1)
+      : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(lo2), "v"(hi2), "v"(lo3), "v"(hi3)
+      : "memory");
+}
+__device__ __forceinline__ void tr4_wait(Tr4& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.c0), "+v"(f.c1), "+v"(f.d0), "+v"(f.d1)
+               :
+               : "memory");
+}
+__device__ __forceinline__ bf16x8 cat2(u32x2 a, u32x2 b) {
+  u32x4 v = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, 0, 0, 0);
+}
+
+#define DKV_STAGE 16640  // Q 8192 | dO 8192 | (lse,delta) pairs 256
+#define DKV_NSTAGE 4
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                              const float* __restrict__ stats /* [B,H,S,2] (lse, delta) */,
                                                               bf16_t* __restrict__ dqkv, int B, int H, int S) {
-  __shared__ __attribute__((aligned(16))) bf16_t sv[128 * KP];   // resident V rows of this block's keys
-  __shared__ __attribute__((aligned(16))) bf16_t sq[32 * KP];
-  __shared__ __attribute__((aligned(16))) bf16_t sdo[32 * KP];
-  __shared__ __attribute__((aligned(16))) bf16_t sqt[128 * TP32];
-  __shared__ __attribute__((aligned(16))) bf16_t sdot[128 * TP32];
-  __shared__ float slse[32], sdelta[32];
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int ktile = blockIdx.x;
   const int bh = blockIdx.y, b = bh / H, hh = bh % H;
   const int key0 = ktile * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
   const int krow = key0 + wid * 32 + r;
   const int krow_c = krow < S ? krow : S - 1;
   const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
   const bf16_t* kb = qb + d;
   const bf16_t* vb = qb + 2 * d;
-  const bf16_t* qtb = qt + (int64_t)bh * HD * S;
-  const bf16_t* dotb = dot + (int64_t)bh * HD * S;
   const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+
+  // buffer descriptors: num_records ends with the last valid row so tail rows read as zeros
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(((int64_t)(S - 1) * d + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)(stats + (int64_t)bh * S * 2), 0, S * 8, 0x00020000);
 
   bf16x8 kf[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kb + (int64_t)krow_c * ld3 + 16 * kk + 8 * h);
-  {
-    u32x4 t[8];
-    load_nat_regs<128>(t, vb, ld3, key0, S, tid);
-    store_nat_lds<128>(t, sv, tid);
+
+  // resident V tile: 128 rows x 16 chunks = 2048 chunks, 8 per thread; rows past S clamp (their keys are never stored)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    int gr = key0 + row;
+    gr = gr < S ? gr : S - 1;
+    dma16(rv, sm + (wid * 64 + 256 * i) * 16, (gr * ld3 + 8 * (pc ^ swz(row))) * 2);
   }
+  // per-step DMA offsets (2 chunks of Q, 2 of dO per thread; tile row = c>>4, rows advance by 32 per step)
+  int voq[2], vod[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    voq[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
+    vod[i] = (row * d + 8 * (pc ^ swz(row))) * 2;
+  }
+  auto stage = [&](int st, int q0) {
+    char* base = sm + 32768 + st * DKV_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      dma16(rq, base + (wid * 64 + 256 * i) * 16, voq[i] + q0 * ld3 * 2);
+      dma16(rdo, base + 8192 + (wid * 64 + 256 * i) * 16, vod[i] + q0 * d * 2);
+    }
+    dma4(rst, base + 16384, (q0 * 2 + lane) * 4);  // 32 (lse, delta) pairs; every wave (identical bytes): uniform DMA count
+  };
+  // hoisted fragment offsets
+  int ofa[8];  // natural A operand: row r, chunk (2kk+h) ^ swz(r)
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ofa[kk] = r * 256 + (((2 * kk + h) ^ swz(r)) << 4);
+  // transposed A operand: rows 16*s2 + 4h + (l16>>2) [+8], byte in row (dt*64 + 32*(g4&1) + 8*(l16&3)) swizzled
+  const int rr = l16 >> 2;
+  unsigned oft[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      const int row = 4 * h + rr + 8 * w2;  // + 16*s2 does not change swz
+      const int chunk = dt * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);
+      oft[dt][w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
+    }
+
   f32x16 dv[4], dk[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -358,45 +450,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 
   const int wave_kmin = key0 + wid * 32;
   const int nqi = (S + 31) / 32;
-  for (int qi = key0 / 32; qi < nqi; ++qi) {
-    __syncthreads();
-    {
-      u32x4 t[2];
-      load_nat_regs<32>(t, qb, ld3, 32 * qi, S, tid);
-      store_nat_lds<32>(t, sq, tid);
-      load_nat_regs<32>(t, dob, d, 32 * qi, S, tid);
-      store_nat_lds<32>(t, sdo, tid);
-      load_tr_regs<32>(t, qtb, S, 32 * qi, tid);
-      store_tr_lds<32, TP32>(t, sqt, tid);
-      load_tr_regs<32>(t, dotb, S, 32 * qi, tid);
-      store_tr_lds<32, TP32>(t, sdot, tid);
-      if (tid < 32) {
-        const int qq = 32 * qi + tid;
-        slse[tid] = (qq < S) ? lse[(int64_t)bh * S + qq] : 1e30f;  // rows past the end get probability 0
-        sdelta[tid] = (qq < S) ? delta[(int64_t)bh * S + qq] : 0.f;
-      }
-    }
-    __syncthreads();
-    if (32 * qi + 31 < wave_kmin) continue;  // every query of the tile precedes every key of this wave
+  const int qi0 = key0 / 32;
+
+  auto compute = [&](int st, int qi) {
+    if (32 * qi + 31 < wave_kmin) return;  // wave-uniform: every query of the tile precedes every key of this wave
+    const char* base = sm + 32768 + st * DKV_STAGE;
+    const unsigned lb = lds0 + 32768 + st * DKV_STAGE;
+    const float* sst = (const float*)(base + 16384);
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 qa = *(const bf16x8*)(sq + r * KP + 16 * kk + 8 * h);
-      const bf16x8 da = *(const bf16x8*)(sdo + r * KP + 16 * kk + 8 * h);
-      const bf16x8 vf = *(const bf16x8*)(sv + (wid * 32 + r) * KP + 16 * kk + 8 * h);
+      const bf16x8 qa = *(const bf16x8*)(base + ofa[kk]);
+      const bf16x8 da = *(const bf16x8*)(base + 8192 + ofa[kk]);
+      const bf16x8 vf = *(const bf16x8*)(sm + wid * 8192 + ofa[kk]);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);   // S[q][key]
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf, dp, 0, 0, 0);     // dP[q][key]
     }
+    Tr4 tdo, tq;  // first 16 queries (s2 = 0): dO^T then Q^T fragments, issued before the softmax VALU work
+    tr4_issue(tdo, lb + 8192 + oft[0][0], lb + 8192 + oft[0][1], lb + 8192 + oft[1][0], lb + 8192 + oft[1][1],
+              lb + 8192 + oft[2][0], lb + 8192 + oft[2][1], lb + 8192 + oft[3][0], lb + 8192 + oft[3][1]);
+    // (lse, delta) pairs of this lane's 16 query rows: rows (e&3) + 8*(e>>2) + 4h -> 4 consecutive pairs per e>>2.
+    // Loaded unconditionally with vector reads; the exponential is unconditional too (exp(-inf) = 0 for masked
+    // entries) -- a ternary around exp() is compiled into per-element branches with an LDS wait inside each.
     float pv[16], ds[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int ql = (e & 3) + 8 * (e >> 2) + 4 * h;
-      const int qg = 32 * qi + ql;
-      const float p = (krow > qg) ? 0.f : __expf(s[e] - slse[ql]);
-      pv[e] = p;
-      ds[e] = p * (dp[e] - sdelta[ql]);
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 st0 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h));
+      const f32x4 st1 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h) + 4);
+      const float lq[4] = {st0[0], st0[2], st1[0], st1[2]};
+      const float dl[4] = {st0[1], st0[3], st1[1], st1[3]};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * g + j;
+        const int qg = 32 * qi + 8 * g + 4 * h + j;
+        const bool masked = (krow > qg) || (qg >= S);
+        const float x = masked ? -INFINITY : (s[e] - lq[j]);
+        const float pe = __expf(x);
+        pv[e] = pe;
+        ds[e] = pe * (dp[e] - dl[j]);
+      }
     }
     bf16x8 pb[2], dsb[2];
     pb[0] = pack_bf8(pv);
@@ -405,18 +499,58 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
     dsb[1] = pack_bf8(ds + 8);
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      const int base = 16 * s2 + 4 * h;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t* p1 = sdot + (dt * 32 + r) * TP32 + base;
-        const bf16_t* p2 = sqt + (dt * 32 + r) * TP32 + base;
-        const bf16x8 a1 = cat4(*(const bf16x4*)p1, *(const bf16x4*)(p1 + 8));
-        const bf16x8 a2 = cat4(*(const bf16x4*)p2, *(const bf16x4*)(p2 + 8));
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, pb[s2], dv[dt], 0, 0, 0);   // dV^T[d][key]
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, dsb[s2], dk[dt], 0, 0, 0);  // dK^T[d][key]
+      const unsigned o = lb + s2 * 4096;
+      tr4_wait(tdo);
+      tr4_issue(tq, o + oft[0][0], o + oft[0][1], o + oft[1][0], o + oft[1][1], o + oft[2][0], o + oft[2][1], o + oft[3][0], o + oft[3][1]);
+      dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.a0, tdo.a1), pb[s2], dv[0], 0, 0, 0);   // dV^T[d][key]
+      dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.b0, tdo.b1), pb[s2], dv[1], 0, 0, 0);
+      dv[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.c0, tdo.c1), pb[s2], dv[2], 0, 0, 0);
+      dv[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.d0, tdo.d1), pb[s2], dv[3], 0, 0, 0);
+      tr4_wait(tq);
+      if (s2 == 0) {
+        const unsigned o2 = lb + 8192 + 4096;
+        tr4_issue(tdo, o2 + oft[0][0], o2 + oft[0][1], o2 + oft[1][0], o2 + oft[1][1], o2 + oft[2][0], o2 + oft[2][1], o2 + oft[3][0], o2 + oft[3][1]);
       }
+      dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.a0, tq.a1), dsb[s2], dk[0], 0, 0, 0);    // dK^T[d][key]
+      dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.b0, tq.b1), dsb[s2], dk[1], 0, 0, 0);
+      dk[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.c0, tq.c1), dsb[s2], dk[2], 0, 0, 0);
+      dk[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.d0, tq.d1), dsb[s2], dk[3], 0, 0, 0);
     }
+  };
+
+  // 4-stage DMA ring, loads issued 3 steps ahead; counted vmcnt (5 DMA per wave per stage) + raw barriers so the
+  // loads stay in flight across barriers; ONE barrier per step:
+  //   [barrier: everyone finished compute(t-1) and everyone's stage-t data landed] issue t+3 -> compute t -> wait t+1
+  const int nsteps = nqi - qi0;
+#define DKV_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#define DKV_BARRIER()                                  \
+  do {                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_s_barrier();                      \
+  } while (0)
+  if (nsteps > 0) stage(0, 32 * qi0);
+  if (nsteps > 1) stage(1, 32 * (qi0 + 1));
+  if (nsteps > 2) stage(2, 32 * (qi0 + 2));
+  if (nsteps > 2) DKV_WAIT(10); else if (nsteps > 1) DKV_WAIT(5); else DKV_WAIT(0);
+  DKV_BARRIER();
+  int t = 0;
+#define DKV_STEP(ST)                                                        \
+  {                                                                         \
+    if (t + 3 < nsteps) stage((ST + 3) & 3, 32 * (qi0 + t + 3));            \
+    compute(ST, qi0 + t);                                                   \
+    const int rem = nsteps - 1 - t; /* steps after this one */              \
+    if (rem >= 3) DKV_WAIT(10); else if (rem == 2) DKV_WAIT(5); else DKV_WAIT(0); \
+    DKV_BARRIER();                                                          \
+    ++t;                                                                    \
   }
+  while (t + 4 <= nsteps) {
+    DKV_STEP(0) DKV_STEP(1) DKV_STEP(2) DKV_STEP(3)
+  }
+  if (t < nsteps) DKV_STEP(0)
+  if (t < nsteps) DKV_STEP(1)
+  if (t < nsteps) DKV_STEP(2)
+#undef DKV_STEP
+
   if (krow < S) {
     bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
     bf16_t* ovp = okp + d;
@@ -434,14 +568,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16_t* __re
 extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
                                  const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
                                  uint16_t* dqkv, int B, int H, int S, void* stream) {
-  DMI_REQUIRE(qkv && qt && kt && o && d_o && dot && lse && delta && dqkv, "attention_bwd: null pointer");
+  (void)qt; (void)dot;  // v2 dK/dV kernel reads Q^T / dO^T fragments with hardware transpose reads
+  DMI_REQUIRE(qkv && kt && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_bwd: S must be a multiple of 8 (S=%d)", S);
+  DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_bwd: sequence too long for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
-  attn_delta_kernel<<<dim3((unsigned)cdiv64((int64_t)B * S, 4)), dim3(256), 0, st>>>(o, d_o, delta, B, H, S);
+  float* stats = delta + (int64_t)B * H * S;  // delta scratch is [3][B,H,S]: delta | (lse, delta) pairs
+  attn_delta_kernel<<<dim3((unsigned)cdiv64((int64_t)B * S, 4)), dim3(256), 0, st>>>(o, d_o, lse, delta, stats, B, H, S);
   DMI_CHECK_LAUNCH("attention_delta");
   attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, st>>>(qkv, kt, d_o, lse, delta, dqkv, B, H, S);
   DMI_CHECK_LAUNCH("attention_bwd_dq");
-  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, st>>>(qkv, qt, d_o, dot, lse, delta, dqkv, B, H, S);
+  static bool attr_done = false;
+  const int shm = 32768 + DKV_NSTAGE * DKV_STAGE;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
+  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S);
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
 }

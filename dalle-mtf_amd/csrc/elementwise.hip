@@ -576,6 +576,7 @@ extern "C" int dmi_assemble_tokens(const int32_t* text, const float* vae_logits,
 // K7 cross entropy over bf16 logits (models.py:348-359; mtf softmax_cross_entropy_with_logits A.5)
 // one 256-thread block per row; pass 1 online max/sum; pass 2 (L2-resident re-read) writes dz in place.
 // =====================================================================================
+// General path: 256 threads per row, two passes (second pass re-reads the row through the caches).
 __global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__ z, int ldz,
                                                             const int* __restrict__ labels,
                                                             float* __restrict__ loss_rows, float* __restrict__ lse_out,
@@ -602,7 +603,6 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += __expf(f[j] - m);
   }
-  // wave then block combine of (m, s)
   float wm = wave_max(m);
   s *= (m == -INFINITY) ? 0.f : __expf(m - wm);
   s = wave_sum(s);
@@ -637,11 +637,95 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(bf16_t* __restrict__
     *(u32x4*)(zr + c * 8) = pack8(f);
   }
 }
+
+// Large-vocabulary path: 1024 threads per row, the row (<= NC*1024 chunks of 16 B) stays in registers between the
+// statistics pass and the dlogits pass: one HBM read + one HBM write per element.
+template <int NC>
+__global__ __launch_bounds__(1024) void cross_entropy_reg_kernel(bf16_t* __restrict__ z, int ldz,
+                                                                 const int* __restrict__ labels,
+                                                                 float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                                 int V, float dz_scale) {
+  __shared__ float sm_m[16], sm_s[16];
+  const int64_t row = blockIdx.x;
+  bf16_t* zr = z + row * ldz;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int nch = ldz / 8;
+  u32x4 v[NC];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = tid + 1024 * i;
+    if (c < nch) {
+      v[i] = *(const u32x4*)(zr + c * 8);
+      float f[8];
+      unpack8(v[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, (c * 8 + j < V) ? f[j] : -INFINITY);
+    }
+  }
+  m = wave_max(m);
+  if (lane == 0) sm_m[wid] = m;
+  __syncthreads();
+  float bm = sm_m[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) bm = fmaxf(bm, sm_m[w]);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = tid + 1024 * i;
+    if (c < nch) {
+      float f[8];
+      unpack8(v[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (c * 8 + j < V) ? __expf(f[j] - bm) : 0.f;
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) sm_s[wid] = s;
+  __syncthreads();
+  float bs = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) bs += sm_s[w];
+  const float lse = bm + __logf(bs);
+  const int label = labels[row];
+  if (tid == 0) {
+    const float zl = (label >= 0 && label < V) ? bf2f(zr[label]) : 0.f;  // row not overwritten yet (barrier below)
+    loss_rows[row] = lse - zl;
+    if (lse_out) lse_out[row] = lse;
+  }
+  if (dz_scale == 0.f) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NC; ++i) {
+    const int c = tid + 1024 * i;
+    if (c < nch) {
+      float f[8];
+      unpack8(v[i], f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int col = c * 8 + j;
+        float p = (col < V) ? __expf(f[j] - lse) : 0.f;
+        if (col == label) p -= 1.f;
+        f[j] = p * dz_scale;
+      }
+      *(u32x4*)(zr + c * 8) = pack8(f);
+    }
+  }
+}
+
 extern "C" int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, float* loss_rows, float* lse,
                                  int64_t M, int V, float dz_scale, void* stream) {
   DMI_REQUIRE(z && labels && loss_rows, "cross_entropy: null pointer");
   DMI_REQUIRE(ldz % 8 == 0 && ldz >= ((V + 7) / 8) * 8 && M > 0 && V > 0, "cross_entropy: ldz must be a multiple of 8 and >= round_up(V,8)");
-  cross_entropy_kernel<<<dim3((unsigned)M), dim3(256), 0, (hipStream_t)stream>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = ldz / 8;
+  if (nch > 2048 && nch <= 8 * 1024) {
+    if (nch <= 4 * 1024) cross_entropy_reg_kernel<4><<<dim3((unsigned)M), dim3(1024), 0, st>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
+    else if (nch <= 7 * 1024) cross_entropy_reg_kernel<7><<<dim3((unsigned)M), dim3(1024), 0, st>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
+    else cross_entropy_reg_kernel<8><<<dim3((unsigned)M), dim3(1024), 0, st>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
+  } else {
+    cross_entropy_kernel<<<dim3((unsigned)M), dim3(256), 0, st>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
+  }
   DMI_CHECK_LAUNCH("cross_entropy");
   return DMI_OK;
 }

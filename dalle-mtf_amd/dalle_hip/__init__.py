@@ -194,7 +194,7 @@ def attention_fwd(qkv, vt, o, lse, B, H, S):
 
 
 def attention_bwd(qkv, qt, kt, o, d_o, dot, lse, delta, dqkv, B, H, S):
-    _dev(qkv, qt, kt, o, d_o, dot, lse, delta, dqkv)
+    _dev(qkv, kt, o, d_o, lse, delta, dqkv)
     _check(lib().dmi_attention_bwd(_p(qkv), _p(qt), _p(kt), _p(o), _p(d_o), _p(dot), _p(lse), _p(delta), _p(dqkv),
                                    B, H, S, _stream()), "attention_bwd")
 

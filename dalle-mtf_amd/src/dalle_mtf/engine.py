@@ -234,7 +234,7 @@ class DalleEngine:
         self.dh = torch.empty(M, 4 * d, **b16)
         self.dqkv = torch.empty(M, 3 * d, **b16)
         self.d_o = torch.empty(M, d, **b16)
-        self.delta = torch.empty(B, H, S, **f32)
+        self.delta = torch.empty(3, B, H, S, **f32)   # delta | (lse, delta) pairs for the dK/dV kernel's DMA
         wsz = max(dh.gemm_tn_workspace_bytes(M, d, Vp), dh.gemm_tn_workspace_bytes(M, 4 * d, d),
                   dh.gemm_tn_workspace_bytes(M, d, 4 * d), dh.gemm_tn_workspace_bytes(M, d, 3 * d),
                   dh.gemm_tn_workspace_bytes(M, d, d), dh.colsum_workspace_bytes(M, Vp),
@@ -336,10 +336,9 @@ class DalleEngine:
                        dbias=self._gv(p + "attn/compute_output_bias/o_b"))
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             qkv = self.qkv[l]
-            dh.transpose_strided(qkv.data_ptr(), self.tr[0], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)          # q^T
+            # only the dQ kernel still consumes a transposed copy (K^T); dK/dV reads Q^T / dO^T with ds_read_b64_tr_b16
             dh.transpose_strided(qkv.data_ptr() + d * 2, self.tr[1], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)  # k^T
-            dh.transpose_strided(self.d_o.data_ptr(), self.tr[2], B, H, S, HEAD_DIM, S * d, HEAD_DIM, d)             # dO^T
-            dh.attention_bwd(qkv, self.tr[0], self.tr[1], self.o[l], self.d_o, self.tr[2], self.lse[l], self.delta,
+            dh.attention_bwd(qkv, None, self.tr[1], self.o[l], self.d_o, None, self.lse[l], self.delta,
                              self.dqkv, B, H, S)
             dh.gemm_tn(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, ws)
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)

@@ -242,7 +242,7 @@ def test_attention_fwd_bwd(B, H, S):
     d_o_d = d_o.to(DEV)
     dot = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
     dh.transpose_strided(d_o_d.data_ptr(), dot, B, H, S, 128, S * d, 128, d)
-    delta = torch.zeros(B, H, S, dtype=torch.float32, device=DEV)
+    delta = torch.zeros(3, B, H, S, dtype=torch.float32, device=DEV)
     dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device=DEV)
     dh.attention_bwd(qkv_d, qt, kt, o, d_o_d, dot, lse, delta, dqkv, B, H, S)
     gref = qr.grad.view(B * S, 3, d)

@@ -77,7 +77,7 @@ def bench_attention(B, H, S):
     print(f"attn_fwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TF/s dense-equivalent ({fl/2/t/1e12:.1f} causal)", flush=True)
     d_o = rb(B * S, d)
     dh.transpose_strided(d_o.data_ptr(), T[3], B, H, S, 128, S * d, 128, d)
-    delta = torch.empty(B, H, S, dtype=torch.float32, device=DEV)
+    delta = torch.empty(3, B, H, S, dtype=torch.float32, device=DEV)
     dqkv = torch.empty(B * S, 3 * d, dtype=torch.bfloat16, device=DEV)
     t = timeit(lambda: dh.attention_bwd(qkv, T[0], T[1], o, d_o, T[3], lse, delta, dqkv, B, H, S))
     print(f"attn_bwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {2*fl/t/1e12:8.1f} TF/s dense-equivalent", flush=True)
