@@ -23,16 +23,19 @@
 static int g_opt_glds = 1;
 static int g_opt_tn_trread = 1;
 static int g_opt_nt2 = 1;
+static int g_opt_prio = 0;
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
   if (!strcmp(name, "tn_trread")) return g_opt_tn_trread;
   if (!strcmp(name, "nt2")) return g_opt_nt2;
+  if (!strcmp(name, "prio")) return g_opt_prio;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "glds")) { g_opt_glds = value; return 0; }
   if (!strcmp(name, "tn_trread")) { g_opt_tn_trread = value; return 0; }
   if (!strcmp(name, "nt2")) { g_opt_nt2 = value; return 0; }
+  if (!strcmp(name, "prio")) { g_opt_prio = value; return 0; }
   return -1;
 }
 
@@ -52,6 +55,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int k_per_split;     // multiple of BK
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
+  int prio;             // raise wave priority around the MFMA clusters (co-resident blocks run at different phases)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
   };
   auto compute = [&](int st) {
     const char* cur = smem + st * 32768;
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[2], fb[2];
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
   };
 
   stage(0, 0);
@@ -444,7 +450,7 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
   a.A = A; a.B = Bt; a.C = C; a.bias = bias; a.residual = residual; a.relu_src = relu_src;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-  a.k_per_split = K; a.slab_stride = 0;
+  a.k_per_split = K; a.slab_stride = 0; a.prio = g_opt_prio;
   hipStream_t st = (hipStream_t)stream;
   switch (flags) {
     case 0: return launch_nt<0>(a, 1, st);
@@ -466,9 +472,14 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
 #define TN_BKM 64      // rows of m per step
 
 static int tn_splits(int M, int I, int J) {
+  // 2 blocks of 256 threads are resident per CU (64 KiB LDS each): 512 slots.  Pick the split count that fills
+  // whole multiples of the residency (a 1.5x grid leaves a quarter of the chip idle in the tail) and keeps at
+  // least 4 k-steps per block; fewer splits also means fewer fp32 slabs to write and reduce.
   const int tiles = ((I + 127) / 128) * ((J + 127) / 128);
-  int s = (768 + tiles - 1) / tiles;           // aim for >= 3 blocks per CU
-  const int max_s = (M + 4 * TN_BKM - 1) / (4 * TN_BKM);  // at least 4 k-steps per split
+  const int max_s = (M + 4 * TN_BKM - 1) / (4 * TN_BKM);
+  if (tiles >= 384) return 1;
+  int s = 512 / tiles;
+  if (s < 1) s = 1;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;
   return s;
@@ -493,6 +504,7 @@ struct TnArgs {
   int tiles_i, tiles_j;
   int m_per_split;  // multiple of TN_BKM
   int64_t slab_stride;
+  int prio;
 };
 
 // Transposed fragment fetch through inline asm: hipcc orders the ds_read_tr16_b64 INTRINSIC behind every in-flight
@@ -602,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
   auto compute = [&](int st) {
     const unsigned base = lds0 + st * 32768;
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
     TrFrag f[2];
     tr_issue(f[0], base + ofx[0], base + ofx[1], base + ofy[0], base + ofy[1]);
 #pragma unroll
@@ -623,6 +636,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
         else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fy1, bacc, 0, 0, 0);
       }
     }
+    if (a.prio) __builtin_amdgcn_s_setprio(0);
   };
 
   if (nt > 0) {
@@ -689,6 +703,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
     a.C = (nsplit > 1) ? slabs : dW;
     a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
+    a.prio = g_opt_prio;
     // bias partials live behind the transposed-copy region of the workspace (unused in this mode)
     float* bpart = (float*)((char*)workspace + slab_bytes);
     a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
@@ -718,6 +733,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     g.k_per_split = (int)round_up64((Mp + nsplit - 1) / nsplit, BK);
     g.C = (nsplit > 1) ? (void*)slabs : (void*)dW;
     g.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
+    g.prio = g_opt_prio;
     const int ns = (Mp + g.k_per_split - 1) / g.k_per_split;
     rc = launch_nt<DMI_GEMM_OUT_F32>(g, ns, st);
     if (rc) return rc;

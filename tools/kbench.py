@@ -38,7 +38,7 @@ def bench_gemm_nt(M, N, K, flags=0, tag=""):
     A, Bt = rb(M, K), rb(N, K, scale=0.05)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     bias, res = rb(N), rb(M, N)
-    for name, opts in (("nt2", dict(nt2=1, glds=1)), ("glds", dict(nt2=0, glds=1)), ("regstage", dict(nt2=0, glds=0))):
+    for name, opts in (("nt2+prio", dict(nt2=1, glds=1, prio=1)), ("nt2", dict(nt2=1, glds=1, prio=0))):
         for k, v in opts.items():
             dh.set_option(k, v)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res))
@@ -52,14 +52,11 @@ def bench_gemm_tn(M, I, J):
     dW = torch.empty(I, J, dtype=torch.float32, device=DEV)
     db = torch.empty(J, dtype=torch.float32, device=DEV)
     w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
-    for tr in (1, 0):
-        dh.set_option("tn_trread", tr)
-        try:
-            t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db))
-            print(f"gemm_tn M={M} I={I} J={J} trread={tr}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
-        except Exception as ex:  # noqa
-            print("gemm_tn failed", tr, ex)
-    dh.set_option("tn_trread", 1)
+    for pr in (1, 0):
+        dh.set_option("prio", pr)
+        t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db))
+        print(f"gemm_tn M={M} I={I} J={J} prio={pr}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
+    dh.set_option("prio", 1)
 
 
 def bench_attention(B, H, S):
