@@ -95,12 +95,18 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), __file__] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
+    # DALLE_BENCH_SHARE_GPU=1 (tests only): all ranks share cuda:0 and use gloo, to exercise the N>1 code path on a
+    # 1-GPU box; the driver's multi-GPU runs use one GPU per rank over RCCL (backend "nccl").
+    share = os.environ.get("DALLE_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         pg = dist.group.WORLD
 
     from src.dalle_mtf.engine import DalleEngine

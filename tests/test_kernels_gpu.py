@@ -156,6 +156,24 @@ def test_gemm_nt_epilogues(glds):
         _set_variant("nt2")
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(4000, 2568, 128, 0), (8192, 1280, 256, 5), (3000, 3000 // 8 * 8, 384, 3)])
+def test_gemm_nt_persistent(M, N, K, flags):
+    """> 512 tiles and an even number of K-steps: the persistent kernel (nt3) path, incl. M/N tails; must agree with nt2."""
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None)
+    ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None)
+    outs = []
+    for nt3 in (1, 0):
+        dh.set_option("nt3", nt3)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
+        close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt3={nt3}")
+        outs.append(C.cpu())
+    dh.set_option("nt3", 1)
+    assert torch.equal(outs[0], outs[1]), "persistent and per-tile kernels must be bit-identical"
+
+
 @pytest.mark.parametrize("trread", [1, 0])
 @pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200)])
 def test_gemm_tn(trread, M, I, J):

@@ -38,12 +38,13 @@ def bench_gemm_nt(M, N, K, flags=0, tag=""):
     A, Bt = rb(M, K), rb(N, K, scale=0.05)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     bias, res = rb(N), rb(M, N)
-    for name, opts in (("nt2+prio", dict(nt2=1, glds=1, prio=1)), ("nt2", dict(nt2=1, glds=1, prio=0))):
+    for name, opts in (("nt3", dict(nt2=1, glds=1, nt3=1)), ("nt2", dict(nt2=1, glds=1, nt3=0))):
         for k, v in opts.items():
             dh.set_option(k, v)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res))
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     dh.set_option("nt2", 1)
+    dh.set_option("nt3", 1)
     dh.set_option("glds", 1)
 
 
