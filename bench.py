@@ -155,6 +155,10 @@ def main():
         k_ms = [a.elapsed_time(b) for a, b in evs]
         k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
         achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
+        traffic = None  # HBM bytes per launch of the same kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_vocab_gemm.json")
+        if os.path.exists(tpath) and B == PER_GPU_BATCH:
+            traffic = json.load(open(tpath)).get("traffic_bytes")
         out = {
             "metric": "train tokens/sec (text+image) per node, dalle_example", "value": tokens_per_s, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -165,7 +169,8 @@ def main():
                        "final_loss": loss},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (vocabulary projection M=B*S, N=50816, K=512)",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": None,
+                         "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": traffic,
+                         "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_vocab_gemm.json; algorithmic 4.26e9)",
                          "launch_ms": k_avg, "launches_timed": len(k_ms),
                          "step_mfma_frac": train_flops_step_gpu / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "step_tflops_per_gpu": train_flops_step_gpu / (ms * 1e-3) / 1e12},
