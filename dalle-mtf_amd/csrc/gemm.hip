@@ -24,12 +24,14 @@ static int g_opt_glds = 1;
 static int g_opt_tn_trread = 1;
 static int g_opt_nt2 = 1;
 static int g_opt_prio = 0;
+static int g_opt_nt4 = 1;
 static int g_opt_nt3 = 0;  // persistent variant: bit-identical, measured 5-12 % slower than per-tile launches (kept as a tested option)
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
   if (!strcmp(name, "tn_trread")) return g_opt_tn_trread;
   if (!strcmp(name, "nt2")) return g_opt_nt2;
   if (!strcmp(name, "prio")) return g_opt_prio;
+  if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt3")) return g_opt_nt3;
   return -1;
 }
@@ -38,6 +40,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "tn_trread")) { g_opt_tn_trread = value; return 0; }
   if (!strcmp(name, "nt2")) { g_opt_nt2 = value; return 0; }
   if (!strcmp(name, "prio")) { g_opt_prio = value; return 0; }
+  if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt3")) { g_opt_nt3 = value; return 0; }
   return -1;
 }
@@ -582,6 +585,149 @@ __global__ __launch_bounds__(256, 2) void gemm_nt3_kernel(GemmArgs a, int ntiles
 #undef NT3_RAW_BARRIER
 }
 
+// =====================================================================================
+// NT kernel v4: 256x128x32 block tile, 4 waves (2x2), each wave 128x64 = 4x2 MFMA 32x32x16 tiles (128 accumulator
+// VGPRs).  Two stages x (A 16 KiB + B 8 KiB) = 48 KiB LDS -> still 2 blocks / CU and the same 16 MFMAs per wave per
+// barrier as v2, but per output element 25 % fewer LDS-read / LDS-DMA / L2 bytes and half the per-tile prologue +
+// epilogue overhead (the K = 512 shapes of this model ran the MFMA pipe at ~30 % with 128x128 tiles vs 61 % at large K).
+// LDS rows are 64 B (4 chunks); chunk ^= (row>>2)&3 on the DMA source side keeps ds_read_b128 conflict-free.
+// Used when the grid still covers >= 3 full residencies (N >= 1024 at M = 40960).
+// =====================================================================================
+#define BM4 256
+#define BK4 32
+__device__ __forceinline__ int lds4_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 8K]
+  constexpr int STG = 24576;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
+  const int m0 = tm * BM4, n0 = tn * BN;
+  const int nt = a.K / BK4;  // even (K % 64 == 0)
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)n0 * a.ldb), 0, 0x7fffffff, 0x00020000);
+  int voa[4], vob[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
+    const int rr = m0 + row < a.M ? row : a.M - 1 - m0;
+    voa[i] = (rr * a.lda + 8 * (pc ^ ((row >> 2) & 3))) * 2;
+    if (i < 2) {
+      const int rn = n0 + row < a.N ? row : a.N - 1 - n0;
+      vob[i] = (rn * a.ldb + 8 * (pc ^ ((row >> 2) & 3))) * 2;
+    }
+  }
+  int offa[2], offb[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    offa[kk] = lds4_off(wm * 128 + r, kk * 2 + h);
+    offb[kk] = 16384 + lds4_off(wn * 64 + r, kk * 2 + h);
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stage = [&](int st, int soff) {
+    char* base = smem + st * STG + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) glds16(ra, base + i * 4096, voa[i], soff);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(rb, base + 16384 + i * 4096, vob[i], soff);
+  };
+  auto compute = [&](int st) {
+    const char* cur = smem + st * STG;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 2048);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *(const bf16x8*)(cur + offb[kk] + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < nt; t += 2) {
+    stage(1, (t + 1) * BK4 * 2);
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < nt) stage(0, (t + 2) * BK4 * 2);
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: wave-private fp32 staging, 32 rows x 64 cols at a time (pitch 272 B), full-row 16-B stores
+  float* stg = (float*)(smem + wid * 8704);
+  const int orow = lane >> 3, ocol = (lane & 7) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
+            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + orow;
+      const int m = m0 + wm * 128 + i * 32 + row;
+      const int n = n0 + wn * 64 + ocol;
+      const f32x4 lo = *(const f32x4*)(stg + row * 68 + ocol);
+      const f32x4 hi = *(const f32x4*)(stg + row * 68 + ocol + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (m < a.M && n < a.N) {
+        const int64_t off = (int64_t)m * a.ldc + n;
+        if constexpr (FLAGS & DMI_GEMM_BIAS) {
+          float b[8];
+          unpack8(*(const u32x4*)(a.bias + n), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+        if constexpr (FLAGS & DMI_GEMM_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
+          float b[8];
+          unpack8(*(const u32x4*)(a.residual + off), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+        if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+          float b[8];
+          unpack8(*(const u32x4*)(a.relu_src + off), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
+        }
+        *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int nsplit, int64_t n4, int64_t stride4) {
@@ -600,6 +746,16 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
   const size_t shm = 65536;
   if constexpr (!(FLAGS & DMI_GEMM_OUT_F32)) {
+    const int tiles4 = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
+    if (g_opt_nt4 && g_opt_nt2 && g_opt_glds && nsplit == 1 && a.k_per_split == a.K && ((tiles4 >= 1536 && a.K <= 1024) || g_opt_nt4 == 2)) {  // 2 = force (tests); long-K shapes prefer the BK=64 kernel
+      static bool attr4 = false;
+      if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152); attr4 = true; }
+      GemmArgs b = a;
+      b.tiles_m = (a.M + BM4 - 1) / BM4;
+      gemm_nt4_kernel<FLAGS><<<dim3(tiles4), blk, 49152, st>>>(b);
+      DMI_CHECK_LAUNCH("gemm_nt4");
+      return DMI_OK;
+    }
     const int ntiles = a.tiles_m * a.tiles_n;
     if (g_opt_nt3 && g_opt_nt2 && g_opt_glds && nsplit == 1 && a.k_per_split == a.K && (a.K / BK) % 2 == 0 && ntiles > 512) {
       static bool attr3 = false;

@@ -156,6 +156,27 @@ def test_gemm_nt_epilogues(glds):
         _set_variant("nt2")
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3), (515, 136, 64, 8)])
+def test_gemm_nt4_tile_256(M, N, K, flags):
+    """256x128x32-tile kernel (forced), incl. M/N tails: same results as the 128x128x64 kernel (identical k order)."""
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    hsrc = torch.relu(rnd(M, N, seed=5))
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None,
+              relu_src=hsrc.to(DEV) if flags & 8 else None)
+    ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None,
+                    relu_src=hsrc if flags & 8 else None)
+    outs = []
+    for nt4 in (2, 0):
+        dh.set_option("nt4", nt4)
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
+        close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt4={nt4}")
+        outs.append(C.cpu())
+    dh.set_option("nt4", 1)
+    assert torch.equal(outs[0], outs[1]), "256-row-tile and 128-row-tile kernels must be bit-identical"
+
+
 @pytest.mark.parametrize("M,N,K,flags", [(4000, 2568, 128, 0), (8192, 1280, 256, 5), (3000, 3000 // 8 * 8, 384, 3)])
 def test_gemm_nt_persistent(M, N, K, flags):
     """> 512 tiles and an even number of K-steps: the persistent kernel (nt3) path, incl. M/N tails; must agree with nt2."""
@@ -164,13 +185,15 @@ def test_gemm_nt_persistent(M, N, K, flags):
     kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None)
     ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None)
     outs = []
+    dh.set_option("nt4", 0)
     for nt3 in (1, 0):
         dh.set_option("nt3", nt3)
         C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
         dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
         close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt3={nt3}")
         outs.append(C.cpu())
-    dh.set_option("nt3", 1)
+    dh.set_option("nt3", 0)
+    dh.set_option("nt4", 1)
     assert torch.equal(outs[0], outs[1]), "persistent and per-tile kernels must be bit-identical"
 
 

@@ -38,13 +38,14 @@ def bench_gemm_nt(M, N, K, flags=0, tag=""):
     A, Bt = rb(M, K), rb(N, K, scale=0.05)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     bias, res = rb(N), rb(M, N)
-    for name, opts in (("nt3", dict(nt2=1, glds=1, nt3=1)), ("nt2", dict(nt2=1, glds=1, nt3=0))):
+    for name, opts in (("nt2", dict(nt2=1, glds=1, nt3=0, nt4=0)), ("nt4", dict(nt2=1, glds=1, nt3=0, nt4=2)), ("nt2 again", dict(nt2=1, glds=1, nt3=0, nt4=0))):
         for k, v in opts.items():
             dh.set_option(k, v)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res))
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     dh.set_option("nt2", 1)
-    dh.set_option("nt3", 1)
+    dh.set_option("nt3", 0)
+    dh.set_option("nt4", 1)
     dh.set_option("glds", 1)
 
 
@@ -129,11 +130,15 @@ if __name__ == "__main__":
     M = 32 * 1280
     which = sys.argv[1:] or ["gemm", "tn", "attn", "misc"]
     if "pmc" in which:   # short list for counter collection
-        bench_gemm_nt(8192, 8192, 8192, 0, tag="[square]")
-        bench_gemm_nt(M, 50816, 512, 1, tag="[logits]")
-        bench_gemm_nt(M, 2048, 512, 3, tag="[ffn1]")
+        dh.set_option("nt3", 0)
+        for (mm, nn, kk_, fl) in ((8192, 8192, 8192, 0), (M, 50816, 512, 1), (M, 1536, 512, 0), (M, 512, 2048, 5)):
+            A, Bt = rb(mm, kk_), rb(nn, kk_, scale=0.05)
+            C = torch.empty(mm, nn, dtype=torch.bfloat16, device=DEV)
+            bias, res = rb(nn), rb(mm, nn)
+            for _ in range(3):
+                dh.gemm_nt(A, kk_, Bt, kk_, C, nn, mm, nn, kk_, fl, bias=bias, residual=res)
+            torch.cuda.synchronize()
         bench_gemm_tn(M, 2048, 512)
-        bench_attention(32, 4, 1280)
     if "gemm" in which:
         bench_gemm_nt(M, 1536, 512, tag="[qkv]")
         bench_gemm_nt(M, 512, 512, 5, tag="[outproj]")
