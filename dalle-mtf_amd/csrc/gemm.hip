@@ -818,6 +818,48 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
   }
 }
 
+// out_bf16[i] = sum_s slabs[s*stride + i]   (split-K epilogue for bf16 outputs; deterministic order)
+__global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __restrict__ slabs, bf16_t* __restrict__ out,
+                                                                int nsplit, int64_t n8, int64_t stride) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    const f32x4 a0 = ((const f32x4*)slabs)[2 * i], a1 = ((const f32x4*)slabs)[2 * i + 1];
+    v[0] = a0[0]; v[1] = a0[1]; v[2] = a0[2]; v[3] = a0[3]; v[4] = a1[0]; v[5] = a1[1]; v[6] = a1[2]; v[7] = a1[3];
+    for (int s = 1; s < nsplit; ++s) {
+      const f32x4 b0 = ((const f32x4*)(slabs + s * stride))[2 * i], b1 = ((const f32x4*)(slabs + s * stride))[2 * i + 1];
+      v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
+    }
+    ((u32x4*)out)[i] = pack8(v);
+  }
+}
+
+extern "C" int64_t dmi_gemm_nt_splitk_workspace_bytes(int M, int N, int nsplit) { return (int64_t)nsplit * M * N * 4 + 256; }
+
+// C[M,N] (bf16, ldc == N) = A . Bt^T with the K range split over `nsplit` block groups (fp32 slabs in `workspace`,
+// reduced deterministically).  For long-K GEMMs whose tile count does not fill whole residencies of the chip.
+extern "C" int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int M, int N, int K,
+                                  int nsplit, void* workspace, void* stream) {
+  int rc = check_nt(A, lda, Bt, ldb, C, N, M, N, K);
+  if (rc) return rc;
+  DMI_REQUIRE(workspace && nsplit >= 1 && nsplit <= 16 && ((int64_t)M * N) % 8 == 0, "gemm_nt_splitk: bad arguments");
+  GemmArgs a;
+  a.A = A; a.B = Bt; a.C = workspace; a.bias = nullptr; a.residual = nullptr; a.relu_src = nullptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N;
+  a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+  a.k_per_split = (int)((((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK);
+  a.slab_stride = (int64_t)M * N; a.prio = g_opt_prio;
+  const int ns = (K + a.k_per_split - 1) / a.k_per_split;
+  hipStream_t st = (hipStream_t)stream;
+  rc = launch_nt<DMI_GEMM_OUT_F32>(a, ns, st);
+  if (rc) return rc;
+  const int64_t n8 = (int64_t)M * N / 8;
+  int64_t blocks = (n8 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  reduce_slabs_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const float*)workspace, (bf16_t*)C, ns, n8, (int64_t)M * N);
+  DMI_CHECK_LAUNCH("gemm_nt_splitk_reduce");
+  return DMI_OK;
+}
+
 // =====================================================================================
 // TN weight-gradient GEMM
 // =====================================================================================

@@ -58,6 +58,8 @@ def _declare(L):
         "dmi_layernorm_bwd_workspace_bytes": (L64, [L64, I]),
         "dmi_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L64, I, P]),
         "dmi_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, I, P, P, P, P]),
+        "dmi_gemm_nt_splitk_workspace_bytes": (L64, [I, I, I]),
+        "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P]),
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
         "dmi_gemm_tn": (I, [P, I, P, I, P, P, I, I, I, P, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
@@ -157,6 +159,15 @@ def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None,
     _dev(A, Bt, C)
     _check(lib().dmi_gemm_nt(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _p(residual),
                              _p(relu_src), _stream()), "gemm_nt")
+
+
+def gemm_nt_splitk_workspace_bytes(M, N, nsplit):
+    return lib().dmi_gemm_nt_splitk_workspace_bytes(M, N, nsplit)
+
+
+def gemm_nt_splitk(A, lda, Bt, ldb, C, M, N, K, nsplit, ws):
+    _dev(A, Bt, C, ws)
+    _check(lib().dmi_gemm_nt_splitk(_p(A), lda, _p(Bt), ldb, _p(C), M, N, K, nsplit, _p(ws), _stream()), "gemm_nt_splitk")
 
 
 def gemm_tn_workspace_bytes(M, I, J):

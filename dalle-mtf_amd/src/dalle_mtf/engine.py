@@ -239,7 +239,8 @@ class DalleEngine:
         wsz = max(dh.gemm_tn_workspace_bytes(M, d, Vp), dh.gemm_tn_workspace_bytes(M, 4 * d, d),
                   dh.gemm_tn_workspace_bytes(M, d, 4 * d), dh.gemm_tn_workspace_bytes(M, d, 3 * d),
                   dh.gemm_tn_workspace_bytes(M, d, d), dh.colsum_workspace_bytes(M, Vp),
-                  dh.layernorm_bwd_workspace_bytes(M, d), dh.sumsq_workspace_bytes(self.lay.total))
+                  dh.layernorm_bwd_workspace_bytes(M, d), dh.sumsq_workspace_bytes(self.lay.total),
+                  dh.gemm_nt_splitk_workspace_bytes(M, d, 2))
         self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
         # optional (hparams["wgrad_side_stream"]): weight gradients on a second HIP stream -- they only feed the optimizer.
         # Measured on MI355X: no gain (22.8 vs 22.5 ms/step; both kernel families already fill the LDS-limited residency)
@@ -361,7 +362,16 @@ class DalleEngine:
         # head
         self._wgrad(self.xnf, d, dz, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
                     dbias=self._gv("to_logits/linear_out/bias"))
-        dh.gemm_nt(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, d, M, d, Vp)
+        # K = vocabulary: 128x128 tiles of this [M, d] output do not fill whole residencies of the chip -> split K
+        tiles = ((M + 127) // 128) * ((d + 127) // 128)
+        frac = (tiles / 512.0) % 1.0          # 512 = blocks resident at once (2 per CU)
+        # measured on MI355X: no gain at dalle_example (22.0 vs 21.7 ms/step; dynamic block dispatch already smooths the
+        # partial last round), so split-K is opt-in (hparams["dlogits_splitk"])
+        nsplit = 2 if (self.hp.get("dlogits_splitk") and tiles >= 256 and 0.4 <= frac <= 0.75) else 1
+        if nsplit > 1:
+            dh.gemm_nt_splitk(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, M, d, Vp, nsplit, self.ws)
+        else:
+            dh.gemm_nt(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, d, M, d, Vp)
         dxa, dxb = self.dx
         dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                          self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)

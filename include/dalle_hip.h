@@ -68,6 +68,11 @@ int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, 
 int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc,
                 int M, int N, int K, int flags, const uint16_t* bias, const uint16_t* residual,
                 const uint16_t* relu_src, void* stream);
+/* same product with the K range split over nsplit block groups (fp32 slabs in workspace, deterministic reduction to
+ * bf16 C with ldc == N): for long-K GEMMs whose tile count does not fill whole residencies (dlogits: K = vocab). */
+int64_t dmi_gemm_nt_splitk_workspace_bytes(int M, int N, int nsplit);
+int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int M, int N, int K,
+                       int nsplit, void* workspace, void* stream);
 /* weight gradient: dW[I,J] (fp32, ld = J) = sum_m X[m,I] * dY[m,J]; deterministic split over m.
  * dbias (nullable): fp32 [J] = sum_m dY[m, :] fused into the same pass (bias gradient of the dense layer).
  * workspace: dmi_gemm_tn_workspace_bytes(M, I, J). */

@@ -197,6 +197,15 @@ def test_gemm_nt_persistent(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "persistent and per-tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,N,K,ns", [(300, 256, 1024, 2), (1024, 512, 4096, 2), (130, 128, 448, 3)])
+def test_gemm_nt_splitk(M, N, K, ns):
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    w = ws(dh.gemm_nt_splitk_workspace_bytes(M, N, ns))
+    dh.gemm_nt_splitk(A.to(DEV), K, Bt.to(DEV), K, C, M, N, K, ns, w)
+    close(C, _gemm_ref(A, Bt), 1.6e-2, 2e-2 * math.sqrt(K / 64) * 0.1, "gemm_nt_splitk")
+
+
 @pytest.mark.parametrize("trread", [1, 0])
 @pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200)])
 def test_gemm_tn(trread, M, I, J):
