@@ -12,8 +12,8 @@
 //   fwd      : S^T = K Q^T ;  O^T += V^T P^T        (block = 128 queries, 64-key tiles)
 //   bwd dQ   : S^T = K Q^T ; dP^T = V dO^T ; dQ^T += K^T dS^T
 //   bwd dKdV : S = Q K^T ; dP = dO V^T ; dV^T += dO^T P ; dK^T += Q^T dS   (block = 128 keys, 32-query tiles)
-// Transposed operand copies (V^T, K^T, Q^T, dO^T as [B,H,128,S]) are produced by dmi_transpose_bf16_strided.
-// LDS tiles are padded (+8 / +4 elements per row) so all fragment reads are bank-conflict-free.
+// No transposed operand copies: K / V / Q / dO tiles land in LDS in their natural layout by LDS-DMA (swizzled on the
+// source side) and every transposed fragment (V^T, K^T, Q^T, dO^T) is a hardware transpose read (ds_read_b64_tr_b16).
 #include "common.h"
 
 #define HD 128
@@ -69,28 +69,116 @@ __device__ __forceinline__ void store_tr_lds(const u32x4* r, bf16_t* lds, int ti
   }
 }
 
+__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+struct Tr4 {
+  u32x2 a0, a1, b0, b1, c0, c1, d0, d1;  // 4 fragments (dt = 0..3) x {keys/queries +0..3, +8..11}
+};
+__device__ __forceinline__ void tr4_issue(Tr4& f, unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, unsigned lo2,
+                                          unsigned hi2, unsigned lo3, unsigned hi3) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\t"
+      "ds_read_b64_tr_b16 %1, %9\n\t"
+      "ds_read_b64_tr_b16 %2, %10\n\t"
+      "ds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\t"
+      "ds_read_b64_tr_b16 %5, %13\n\t"
+      "ds_read_b64_tr_b16 %6, %14\n\t"
+      "ds_read_b64_tr_b16 %7, %15"
+      : "=&v"(f.a0), "=&v"(f.a1), "=&v"(f.b0), "=&v"(f.b1), "=&v"(f.c0), "=&v"(f.c1), "=&v"(f.d0), "=&v"(f.d1)
+      : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(lo2), "v"(hi2), "v"(lo3), "v"(hi3)
+      : "memory");
+}
+__device__ __forceinline__ void tr4_wait(Tr4& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.c0), "+v"(f.c1), "+v"(f.d0), "+v"(f.d1)
+               :
+               : "memory");
+}
+struct Tr2 {
+  u32x2 a0, a1, b0, b1;  // 2 fragments x {+0..3, +8..11}
+};
+__device__ __forceinline__ void tr2_issue(Tr2& f, unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4\n\t"
+      "ds_read_b64_tr_b16 %1, %5\n\t"
+      "ds_read_b64_tr_b16 %2, %6\n\t"
+      "ds_read_b64_tr_b16 %3, %7"
+      : "=&v"(f.a0), "=&v"(f.a1), "=&v"(f.b0), "=&v"(f.b1)
+      : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1)
+      : "memory");
+}
+__device__ __forceinline__ void tr2_wait(Tr2& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1) : : "memory");
+}
+__device__ __forceinline__ bf16x8 cat2(u32x2 a, u32x2 b) {
+  u32x4 v = {a[0], a[1], b[0], b[1]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, 0, 0, 0);
+}
+
+
 // =====================================================================================
 // forward
 // =====================================================================================
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt,
-                                                          bf16_t* __restrict__ o, float* __restrict__ lse, int B,
-                                                          int H, int S) {
-  __shared__ __attribute__((aligned(16))) bf16_t sk[64 * KP];
-  __shared__ __attribute__((aligned(16))) bf16_t sv[128 * TP];
+// Forward v2: K and V NATURAL tiles (64 keys x 256 B each) stream by LDS-DMA into a 2-stage ring (one barrier per
+// 64-key step, loads of step j+1 in flight during the MFMAs of step j).  S^T = K Q^T reads K rows with ds_read_b128;
+// O^T += V^T P^T needs V^T fragments = hardware transpose reads of the same natural V tile (no transposed copy of V).
+#define QK_STAGE 32768  // K 16384 | V 16384
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                          float* __restrict__ lse, int B, int H, int S) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
   const int bh = blockIdx.y, b = bh / H, hh = bh % H;
   const int q0 = qt * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
   const int qrow = q0 + wid * 32 + r;
   const int qrow_c = qrow < S ? qrow : S - 1;
   const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
-  const bf16_t* kb = qb + d;
-  const bf16_t* vtb = vt + (int64_t)bh * HD * S;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+  const int nbytes = (int)(((int64_t)(S - 1) * ld3 + HD) * 2);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + d), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 2 * d), 0, nbytes, 0x00020000);
 
   bf16x8 qf[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qb + (int64_t)qrow_c * ld3 + 16 * kk + 8 * h);
+
+  int vo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    vo[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
+  }
+  auto stage = [&](int st, int key0) {
+    char* base = sm + st * QK_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(rk, base + (wid * 64 + 256 * i) * 16, vo[i] + key0 * ld3 * 2);
+      dma16(rv, base + 16384 + (wid * 64 + 256 * i) * 16, vo[i] + key0 * ld3 * 2);
+    }
+  };
+  int ofa[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ofa[kk] = r * 256 + (((2 * kk + h) ^ swz(r)) << 4);
+  const int rr = l16 >> 2;
+  unsigned oft[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      const int row = 4 * h + rr + 8 * w2;
+      const int chunk = dt * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);
+      oft[dt][w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
+    }
 
   f32x16 oacc[4];
 #pragma unroll
@@ -100,38 +188,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   float m = -1e30f, l = 0.f;
 
   const int qlast = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;
-  const int jmax = qlast / 64;
+  const int nsteps = qlast / 64 + 1;
   const int wave_qmin = q0 + wid * 32, wave_qmax = wave_qmin + 31;
 
-  u32x4 pk[4], pv[4];
-  load_nat_regs<64>(pk, kb, ld3, 0, S, tid);
-  load_tr_regs<64>(pv, vtb, S, 0, tid);
-  for (int j = 0; j <= jmax; ++j) {
-    __syncthreads();
-    store_nat_lds<64>(pk, sk, tid);
-    store_tr_lds<64, TP>(pv, sv, tid);
-    __syncthreads();
-    if (j < jmax) {
-      load_nat_regs<64>(pk, kb, ld3, 64 * (j + 1), S, tid);
-      load_tr_regs<64>(pv, vtb, S, 64 * (j + 1), tid);
-    }
-    if (64 * j > wave_qmax) continue;  // wave-uniform: tile entirely above the diagonal for this wave
+  auto compute = [&](int st, int j) {
+    if (64 * j > wave_qmax) return;  // wave-uniform: tile entirely above the diagonal for this wave
+    const char* base = sm + st * QK_STAGE;
+    const unsigned vb = lds0 + st * QK_STAGE + 16384;
     f32x16 s0, s1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 a0 = *(const bf16x8*)(sk + r * KP + 16 * kk + 8 * h);
-      const bf16x8 a1 = *(const bf16x8*)(sk + (32 + r) * KP + 16 * kk + 8 * h);
+      const bf16x8 a0 = *(const bf16x8*)(base + ofa[kk]);
+      const bf16x8 a1 = *(const bf16x8*)(base + 8192 + ofa[kk]);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[kk], s0, 0, 0, 0);  // S^T[key][q]
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[kk], s1, 0, 0, 0);
     }
+    Tr4 tv[2];
+    tr4_issue(tv[0], vb + oft[0][0], vb + oft[0][1], vb + oft[1][0], vb + oft[1][1], vb + oft[2][0], vb + oft[2][1], vb + oft[3][0], vb + oft[3][1]);
     if (64 * j + 63 > wave_qmin) {  // diagonal tile: additive -1e10 mask == probability exactly 0
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = 64 * j + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (key > qrow) s0[e] = -1e30f;
-        if (key + 32 > qrow) s1[e] = -1e30f;
+        s0[e] = (key > qrow) ? -1e30f : s0[e];
+        s1[e] = (key + 32 > qrow) ? -1e30f : s1[e];
       }
     }
     float mx = -1e30f;
@@ -141,34 +222,61 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const float mn = fmaxf(m, mx);
     const float alpha = __expf(m - mn);
     m = mn;
-    float p0[16], p1[16], rs = 0.f;
+    float rs = 0.f;
+    bf16x8 pb[4];
+    {
+      float pe[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      p0[e] = __expf(s0[e] - mn);
-      p1[e] = __expf(s1[e] - mn);
-      rs += p0[e] + p1[e];
+      for (int e = 0; e < 16; ++e) {
+        pe[e] = __expf(s0[e] - mn);
+        rs += pe[e];
+      }
+      pb[0] = pack_bf8(pe);
+      pb[1] = pack_bf8(pe + 8);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        pe[e] = __expf(s1[e] - mn);
+        rs += pe[e];
+      }
+      pb[2] = pack_bf8(pe);
+      pb[3] = pack_bf8(pe + 8);
     }
     l = l * alpha + rs;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
-    bf16x8 pb[4];
-    pb[0] = pack_bf8(p0);
-    pb[1] = pack_bf8(p0 + 8);
-    pb[2] = pack_bf8(p1);
-    pb[3] = pack_bf8(p1 + 8);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // 16-key step: keys 16*ks + {4h..4h+3, 8+4h..8+4h+3}
-      const int base = 16 * ks + 4 * h;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const bf16_t* vp = sv + (dt * 32 + r) * TP + base;
-        const bf16x8 a = cat4(*(const bf16x4*)vp, *(const bf16x4*)(vp + 8));
-        oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[ks], oacc[dt], 0, 0, 0);  // O^T[d][q]
+      Tr4& c = tv[ks & 1];
+      tr4_wait(c);
+      if (ks < 3) {
+        const unsigned o2 = vb + (ks + 1) * 4096;
+        tr4_issue(tv[(ks + 1) & 1], o2 + oft[0][0], o2 + oft[0][1], o2 + oft[1][0], o2 + oft[1][1], o2 + oft[2][0], o2 + oft[2][1], o2 + oft[3][0], o2 + oft[3][1]);
       }
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.a0, c.a1), pb[ks], oacc[0], 0, 0, 0);  // O^T[d][q]
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.b0, c.b1), pb[ks], oacc[1], 0, 0, 0);
+      oacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.c0, c.c1), pb[ks], oacc[2], 0, 0, 0);
+      oacc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.d0, c.d1), pb[ks], oacc[3], 0, 0, 0);
     }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int j = 0;
+  for (; j + 2 <= nsteps; j += 2) {
+    stage(1, 64 * (j + 1));
+    compute(0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (j + 2 < nsteps) stage(0, 64 * (j + 2));
+    compute(1, j + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
+  if (j < nsteps) compute(0, j);
+
   l += __shfl_xor(l, 32, 64);
   if (qrow < S) {
     const float inv = 1.f / l;
@@ -187,9 +295,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 
 extern "C" int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16_t* o, float* lse, int B, int H,
                                  int S, void* stream) {
-  DMI_REQUIRE(qkv && vt && o && lse, "attention_fwd: null pointer");
+  (void)vt;  // v2 reads V^T fragments with hardware transpose reads of the natural V tile
+  DMI_REQUIRE(qkv && o && lse, "attention_fwd: null pointer");
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_fwd: S must be a multiple of 8 (S=%d)", S);
-  attn_fwd_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, (hipStream_t)stream>>>(qkv, vt, o, lse, B, H, S);
+  DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_fwd: sequence too long for 32-bit buffer offsets");
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE); attr_done = true; }
+  attn_fwd_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S);
   DMI_CHECK_LAUNCH("attention_fwd");
   return DMI_OK;
 }
@@ -227,25 +339,27 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ kt,
-                                                             const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
-                                                             const float* __restrict__ delta, bf16_t* __restrict__ dqkv,
-                                                             int B, int H, int S) {
-  __shared__ __attribute__((aligned(16))) bf16_t sk[64 * KP];
-  __shared__ __attribute__((aligned(16))) bf16_t sv[64 * KP];
-  __shared__ __attribute__((aligned(16))) bf16_t skt[128 * TP];
+// dQ kernel v2: same K / V natural-tile DMA ring as the forward.  S^T = K Q^T and dP^T = V dO^T read tile rows with
+// ds_read_b128; dQ^T += K^T dS^T takes K^T fragments from the SAME K tile with hardware transpose reads.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dqkv, int B, int H, int S) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int qt = gridDim.x - 1 - blockIdx.x;
   const int bh = blockIdx.y, b = bh / H, hh = bh % H;
   const int q0 = qt * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
   const int qrow = q0 + wid * 32 + r;
   const int qrow_c = qrow < S ? qrow : S - 1;
   const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
-  const bf16_t* kb = qb + d;
-  const bf16_t* vb = qb + 2 * d;
-  const bf16_t* ktb = kt + (int64_t)bh * HD * S;
   const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+  const int nbytes = (int)(((int64_t)(S - 1) * ld3 + HD) * 2);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + d), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 2 * d), 0, nbytes, 0x00020000);
 
   bf16x8 qf[8], dof[8];
 #pragma unroll
@@ -256,6 +370,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const float lse_q = lse[(int64_t)bh * S + qrow_c];
   const float delta_q = delta[(int64_t)bh * S + qrow_c];
 
+  int vo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    vo[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
+  }
+  auto stage = [&](int st, int key0) {
+    char* base = sm + st * QK_STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dma16(rk, base + (wid * 64 + 256 * i) * 16, vo[i] + key0 * ld3 * 2);
+      dma16(rv, base + 16384 + (wid * 64 + 256 * i) * 16, vo[i] + key0 * ld3 * 2);
+    }
+  };
+  int ofa[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ofa[kk] = r * 256 + (((2 * kk + h) ^ swz(r)) << 4);
+  const int rr = l16 >> 2;
+  unsigned oft[4][2];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2) {
+      const int row = 4 * h + rr + 8 * w2;
+      const int chunk = dt * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);
+      oft[dt][w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
+    }
+
   f32x16 dq[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -263,21 +405,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
 
   const int qlast = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;
-  const int jmax = qlast / 64;
+  const int nsteps = qlast / 64 + 1;
   const int wave_qmax = q0 + wid * 32 + 31;
-  for (int j = 0; j <= jmax; ++j) {
-    __syncthreads();
-    {
-      u32x4 t[4];
-      load_nat_regs<64>(t, kb, ld3, 64 * j, S, tid);
-      store_nat_lds<64>(t, sk, tid);
-      load_nat_regs<64>(t, vb, ld3, 64 * j, S, tid);
-      store_nat_lds<64>(t, sv, tid);
-      load_tr_regs<64>(t, ktb, S, 64 * j, tid);
-      store_tr_lds<64, TP>(t, skt, tid);
-    }
-    __syncthreads();
-    if (64 * j > wave_qmax) continue;
+
+  auto compute = [&](int st, int j) {
+    if (64 * j > wave_qmax) return;
+    const char* base = sm + st * QK_STAGE;
+    const unsigned kb = lds0 + st * QK_STAGE;
 #pragma unroll
     for (int kt2 = 0; kt2 < 2; ++kt2) {
       f32x16 s, dp;
@@ -285,33 +419,57 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        const bf16x8 ka = *(const bf16x8*)(sk + (kt2 * 32 + r) * KP + 16 * kk + 8 * h);
-        const bf16x8 va = *(const bf16x8*)(sv + (kt2 * 32 + r) * KP + 16 * kk + 8 * h);
+        const bf16x8 ka = *(const bf16x8*)(base + kt2 * 8192 + ofa[kk]);
+        const bf16x8 va = *(const bf16x8*)(base + 16384 + kt2 * 8192 + ofa[kk]);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], s, 0, 0, 0);     // S^T[key][q]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[kk], dp, 0, 0, 0);  // dP^T[key][q]
       }
+      // K^T fragments in pairs of d-tiles (8 VGPRs per set, two sets in flight): step q = (s2, d-tile pair)
+      Tr2 tk[2];
+      const unsigned o0 = kb + kt2 * 8192;
+      tr2_issue(tk[0], o0 + oft[0][0], o0 + oft[0][1], o0 + oft[1][0], o0 + oft[1][1]);
       float ds[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = 64 * j + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float p = __expf((key > qrow) ? -INFINITY : (s[e] - lse_q));  // unconditional exp: no per-element branches
-        ds[e] = p * (dp[e] - delta_q);
+        const float pe = __expf((key > qrow) ? -INFINITY : (s[e] - lse_q));  // unconditional exp: no per-element branches
+        ds[e] = pe * (dp[e] - delta_q);
       }
       bf16x8 dsb[2];
       dsb[0] = pack_bf8(ds);
       dsb[1] = pack_bf8(ds + 8);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int base = kt2 * 32 + 16 * s2 + 4 * h;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          const bf16_t* kp = skt + (dt * 32 + r) * TP + base;
-          const bf16x8 a = cat4(*(const bf16x4*)kp, *(const bf16x4*)(kp + 8));
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, dsb[s2], dq[dt], 0, 0, 0);  // dQ^T[d][q]
+      for (int q = 0; q < 4; ++q) {
+        const int s2 = q >> 1, dp2 = (q & 1) * 2;  // d-tiles dp2, dp2+1
+        Tr2& c = tk[q & 1];
+        tr2_wait(c);
+        if (q < 3) {
+          const int s2n = (q + 1) >> 1, dn = ((q + 1) & 1) * 2;
+          const unsigned o1 = o0 + s2n * 4096;
+          tr2_issue(tk[(q + 1) & 1], o1 + oft[dn][0], o1 + oft[dn][1], o1 + oft[dn + 1][0], o1 + oft[dn + 1][1]);
         }
+        dq[dp2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.a0, c.a1), dsb[s2], dq[dp2], 0, 0, 0);          // dQ^T[d][q]
+        dq[dp2 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.b0, c.b1), dsb[s2], dq[dp2 + 1], 0, 0, 0);
       }
     }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int j = 0;
+  for (; j + 2 <= nsteps; j += 2) {
+    stage(1, 64 * (j + 1));
+    compute(0, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (j + 2 < nsteps) stage(0, 64 * (j + 2));
+    compute(1, j + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
+  if (j < nsteps) compute(0, j);
+
   if (qrow < S) {
     bf16_t* op = dqkv + ((int64_t)b * S + qrow) * ld3 + hh * HD;
 #pragma unroll
@@ -333,43 +491,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // index XOR ((row&3)<<2 | (row>>2)&3) on the source side: 16 consecutive rows hit 16 distinct chunks (b128 reads
 // conflict-free) and the 4 rows x 64 B of a transpose-read group cover all banks once.
 // Transposed reads go through inline asm (see gemm.hip: hipcc serialises the intrinsic behind in-flight LDS-DMA).
-__device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-
-struct Tr4 {
-  u32x2 a0, a1, b0, b1, c0, c1, d0, d1;  // 4 fragments (dt = 0..3) x {keys/queries +0..3, +8..11}
-};
-__device__ __forceinline__ void tr4_issue(Tr4& f, unsigned lo0, unsigned hi0, unsigned lo1, unsigned hi1, unsigned lo2,
-                                          unsigned hi2, unsigned lo3, unsigned hi3) {
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %8\n\t"
-      "ds_read_b64_tr_b16 %1, %9\n\t"
-      "ds_read_b64_tr_b16 %2, %10\n\t"
-      "ds_read_b64_tr_b16 %3, %11\n\t"
-      "ds_read_b64_tr_b16 %4, %12\n\t"
-      "ds_read_b64_tr_b16 %5, %13\n\t"
-      "ds_read_b64_tr_b16 %6, %14\n\t"
-      "ds_read_b64_tr_b16 %7, %15"
-      : "=&v"(f.a0), "=&v"(f.a1), "=&v"(f.b0), "=&v"(f.b1), "=&v"(f.c0), "=&v"(f.c1), "=&v"(f.d0), "=&v"(f.d1)
-      : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(lo2), "v"(hi2), "v"(lo3), "v"(hi3)
-      : "memory");
-}
-__device__ __forceinline__ void tr4_wait(Tr4& f) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.c0), "+v"(f.c1), "+v"(f.d0), "+v"(f.d1)
-               :
-               : "memory");
-}
-__device__ __forceinline__ bf16x8 cat2(u32x2 a, u32x2 b) {
-  u32x4 v = {a[0], a[1], b[0], b[1]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
-}
-__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, 0, 0, 0);
-}
-
 #define DKV_STAGE 16640  // Q 8192 | dO 8192 | (lse,delta) pairs 256
 #define DKV_NSTAGE 4
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
@@ -568,19 +689,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
 extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
                                  const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
                                  uint16_t* dqkv, int B, int H, int S, void* stream) {
-  (void)qt; (void)dot;  // v2 dK/dV kernel reads Q^T / dO^T fragments with hardware transpose reads
-  DMI_REQUIRE(qkv && kt && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
+  (void)qt; (void)kt; (void)dot;  // v2 kernels fetch every transposed fragment with hardware transpose reads
+  DMI_REQUIRE(qkv && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_bwd: S must be a multiple of 8 (S=%d)", S);
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_bwd: sequence too long for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
   float* stats = delta + (int64_t)B * H * S;  // delta scratch is [3][B,H,S]: delta | (lse, delta) pairs
   attn_delta_kernel<<<dim3((unsigned)cdiv64((int64_t)B * S, 4)), dim3(256), 0, st>>>(o, d_o, lse, delta, stats, B, H, S);
   DMI_CHECK_LAUNCH("attention_delta");
-  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 0, st>>>(qkv, kt, d_o, lse, delta, dqkv, B, H, S);
-  DMI_CHECK_LAUNCH("attention_bwd_dq");
   static bool attr_done = false;
   const int shm = 32768 + DKV_NSTAGE * DKV_STAGE;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    attr_done = true;
+  }
+  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, d_o, lse, delta, dqkv, B, H, S);
+  DMI_CHECK_LAUNCH("attention_bwd_dq");
   attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S);
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;

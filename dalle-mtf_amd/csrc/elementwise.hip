@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   if (grp == 0 && c < ncols) out[c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
 }
 
-#define LN_BWD_RPB 64  // rows per block (16 per wave)
+#define LN_BWD_RPB 32  // rows per block (8 per wave): 1280 blocks at M = 40960 -> ~20 waves/CU hide the per-row latency chain
 extern "C" int64_t dmi_layernorm_bwd_workspace_bytes(int64_t rows, int d) {
   return cdiv64(rows, LN_BWD_RPB) * 2 * (int64_t)d * 4;
 }
@@ -352,30 +352,29 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
-// out layout of the reduce: [dg(d) | db(d)] -> two destination pointers
+// out layout of the reduce: [dg(d) | db(d)] -> two destination pointers.  16 columns x 16 row-groups per block
+// (2d/16 blocks), 2 independent chains per thread.
 __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restrict__ part, float* __restrict__ dg,
                                                             float* __restrict__ db, int P, int d) {
-  __shared__ float sm[4][64];
-  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  float acc = 0.f;
-  if (c < 2 * d) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  __shared__ float sm[16][17];
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int64_t nc = 2 * (int64_t)d;
+  float a0 = 0.f, a1 = 0.f;
+  if (c < nc) {
     int p = grp;
-    const int64_t nc = 2 * (int64_t)d;
-    for (; p + 12 < P; p += 16) {
+    for (; p + 16 < P; p += 32) {
       a0 += part[(int64_t)p * nc + c];
-      a1 += part[(int64_t)(p + 4) * nc + c];
-      a2 += part[(int64_t)(p + 8) * nc + c];
-      a3 += part[(int64_t)(p + 12) * nc + c];
+      a1 += part[(int64_t)(p + 16) * nc + c];
     }
-    for (; p < P; p += 4) a0 += part[(int64_t)p * nc + c];
-    acc = (a0 + a1) + (a2 + a3);
+    if (p < P) a0 += part[(int64_t)p * nc + c];
   }
-  sm[grp][cl] = acc;
+  sm[grp][cl] = a0 + a1;
   __syncthreads();
-  if (grp == 0 && c < 2 * d) {
-    const float s = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+  if (grp == 0 && c < nc) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += sm[q][cl];
     if (c < d) dg[c] = s;
     else db[c - d] = s;
   }
@@ -395,7 +394,7 @@ extern "C" int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const ui
   else if (d <= 1024) ln_bwd_kernel<2><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
   else ln_bwd_kernel<4><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
   DMI_CHECK_LAUNCH("layernorm_bwd");
-  ln_bwd_finish_kernel<<<dim3((2 * d + 63) / 64), blk, 0, st>>>(part, dg, db, P, d);
+  ln_bwd_finish_kernel<<<dim3((2 * d + 15) / 16), blk, 0, st>>>(part, dg, db, P, d);
   DMI_CHECK_LAUNCH("layernorm_bwd_finish");
   return DMI_OK;
 }

@@ -200,12 +200,12 @@ def transpose_strided(inp_ptr, out, nb, nh, R, C, sb, sh, sr):
 
 
 def attention_fwd(qkv, vt, o, lse, B, H, S):
-    _dev(qkv, vt, o, lse)
+    _dev(qkv, o, lse)
     _check(lib().dmi_attention_fwd(_p(qkv), _p(vt), _p(o), _p(lse), B, H, S, _stream()), "attention_fwd")
 
 
 def attention_bwd(qkv, qt, kt, o, d_o, dot, lse, delta, dqkv, B, H, S):
-    _dev(qkv, kt, o, d_o, lse, delta, dqkv)
+    _dev(qkv, o, d_o, lse, delta, dqkv)
     _check(lib().dmi_attention_bwd(_p(qkv), _p(qt), _p(kt), _p(o), _p(d_o), _p(dot), _p(lse), _p(delta), _p(dqkv),
                                    B, H, S, _stream()), "attention_bwd")
 

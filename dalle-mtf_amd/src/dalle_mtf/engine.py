@@ -229,7 +229,6 @@ class DalleEngine:
         self.loss = torch.zeros(1, **f32)
         self.gnorm_sq = torch.zeros(1, **f32)
         # scratch
-        self.tr = [torch.empty(B, H, HEAD_DIM, S, **b16) for _ in range(3)]  # vt (fwd) / qt, kt, dot (bwd)
         self.dx = [torch.empty(M, d, **b16) for _ in range(2)]
         self.dxn = torch.empty(M, d, **b16)
         self.dh = torch.empty(M, 4 * d, **b16)
@@ -267,8 +266,7 @@ class DalleEngine:
             st = self.stats[l]
             dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
             dh.gemm_nt(self.xn1[l], d, self.tview(p + "attn/qkv"), d, self.qkv[l], 3 * d, M, 3 * d, d)
-            dh.transpose_strided(self.qkv[l].data_ptr() + 2 * d * 2, self.tr[0], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)
-            dh.attention_fwd(self.qkv[l], self.tr[0], self.o[l], self.lse[l], B, H, S)
+            dh.attention_fwd(self.qkv[l], None, self.o[l], self.lse[l], B, H, S)   # no transposed copies: hardware transpose reads
             dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
                        bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
             dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
@@ -396,11 +394,8 @@ class DalleEngine:
                         dbias=self._gv(p + "attn/compute_output_bias/o_b"), tag="dxb")
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             qkv = self.qkv[l]
-            # only the dQ kernel still consumes a transposed copy (K^T); dK/dV reads Q^T / dO^T with ds_read_b64_tr_b16
-            dh.transpose_strided(qkv.data_ptr() + d * 2, self.tr[1], B, H, S, HEAD_DIM, S * 3 * d, HEAD_DIM, 3 * d)  # k^T
             self._wait_tag("dqkv")    # previous layer's Wqkv gradient still reads self.dqkv
-            dh.attention_bwd(qkv, None, self.tr[1], self.o[l], self.d_o, None, self.lse[l], self.delta,
-                             self.dqkv, B, H, S)
+            dh.attention_bwd(qkv, None, None, self.o[l], self.d_o, None, self.lse[l], self.delta, self.dqkv, B, H, S)
             self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, tag="dqkv")
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
             self._wait_tag("dxa")     # this layer's W2 gradient (issued at the top) read dxa

@@ -91,13 +91,13 @@ int dmi_transpose_bf16_strided(const uint16_t* in, uint16_t* out, int nb, int nh
 
 /* ---- K4  causal attention, UNSCALED logits, fp32 softmax   models.py:221-227,292-299 (Appendix A.2/A.3)
  * qkv [B*S, 3*H*128] bf16 = the QKV projection output, row = [q | k | v] x [H, 128] (heads-major, A.1);
- * vt = v transposed per head [B,H,128,S] (dmi_transpose_bf16_strided);  o [B*S, H*128] bf16;  lse [B,H,S] fp32.
- * head dim is fixed at 128 (README.md:164 "n_embd / n_heads should equal 128"); S % 8 == 0. */
+ * o [B*S, H*128] bf16;  lse [B,H,S] fp32.  head dim is fixed at 128 (README.md:164); S % 8 == 0.
+ * The vt / qt / kt / dot parameters are legacy (transposed operand copies of the first kernel generation) and are
+ * ignored: every transposed fragment is fetched with hardware transpose reads.  Pass NULL. */
 int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16_t* o, float* lse,
                       int B, int H, int S, void* stream);
-/* backward.  d_o [B*S, H*128] bf16; kt = per-head transposed copy [B,H,128,S] of k (qt / dot are ignored since the
- * dK/dV kernel fetches Q^T / dO^T fragments with hardware transpose reads; pass NULL).
- * delta: fp32 scratch of 3*B*H*S floats (delta | interleaved (lse, delta) pairs).  dqkv [B*S, 3*H*128] bf16 in the qkv layout (what the QKV dgrad/wgrad GEMMs consume). */
+/* backward.  d_o [B*S, H*128] bf16; delta: fp32 scratch of 3*B*H*S floats (delta | interleaved (lse, delta) pairs);
+ * dqkv [B*S, 3*H*128] bf16 in the qkv layout (what the QKV dgrad/wgrad GEMMs consume). */
 int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
                       const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
                       uint16_t* dqkv, int B, int H, int S, void* stream);
