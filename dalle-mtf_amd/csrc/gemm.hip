@@ -922,6 +922,13 @@ __device__ __forceinline__ void tr_issue(TrFrag& f, unsigned ax0, unsigned ax1, 
       : "v"(ax0), "v"(ax1), "v"(ay0), "v"(ay1)
       : "memory");
 }
+// wait until at most 8 LDS operations (= one younger fragment set) are outstanding: LDS data returns in order
+__device__ __forceinline__ void tr_wait8(TrFrag& f) {
+  asm volatile("s_waitcnt lgkmcnt(8)"
+               : "+v"(f.x0a), "+v"(f.x0b), "+v"(f.x1a), "+v"(f.x1b), "+v"(f.y0a), "+v"(f.y0b), "+v"(f.y1a), "+v"(f.y1b)
+               :
+               : "memory");
+}
 __device__ __forceinline__ void tr_wait(TrFrag& f) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(f.x0a), "+v"(f.x0b), "+v"(f.x1a), "+v"(f.x1b), "+v"(f.y0a), "+v"(f.y0b), "+v"(f.y1a), "+v"(f.y1b)
@@ -1009,15 +1016,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   auto compute = [&](int st) {
     const unsigned base = lds0 + st * 32768;
     if (a.prio) __builtin_amdgcn_s_setprio(1);
-    TrFrag f[2];
+    TrFrag f[3];  // ring of 3 fragment sets: two k-steps of transposed reads in flight ahead of the MFMAs
     tr_issue(f[0], base + ofx[0], base + ofx[1], base + ofy[0], base + ofy[1]);
+    tr_issue(f[1], base + 4096 + ofx[0], base + 4096 + ofx[1], base + 4096 + ofy[0], base + 4096 + ofy[1]);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      TrFrag& c = f[kk & 1];
-      tr_wait(c);
-      if (kk < 3) {
-        const unsigned b2 = base + (kk + 1) * 4096;
-        tr_issue(f[(kk + 1) & 1], b2 + ofx[0], b2 + ofx[1], b2 + ofy[0], b2 + ofy[1]);  // overlaps the MFMAs below
+      TrFrag& c = f[kk % 3];
+      if (kk < 3) tr_wait8(c); else tr_wait(c);
+      if (kk + 2 < 4) {
+        const unsigned b2 = base + (kk + 2) * 4096;
+        tr_issue(f[(kk + 2) % 3], b2 + ofx[0], b2 + ofx[1], b2 + ofy[0], b2 + ofy[1]);
       }
       const bf16x8 fx0 = tr_cat(c.x0a, c.x0b), fx1 = tr_cat(c.x1a, c.x1b);
       const bf16x8 fy0 = tr_cat(c.y0a, c.y0b), fy1 = tr_cat(c.y1a, c.y1b);

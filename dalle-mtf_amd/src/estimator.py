@@ -91,6 +91,8 @@ class Estimator:
         for hk in spec.training_hooks or []:
             if isinstance(hk, CheckpointSaverHook):
                 hk.save(step)
+        if hasattr(it, "close"):
+            it.close()
         return step
 
     def evaluate(self, input_fn, steps):
@@ -100,5 +102,7 @@ class Estimator:
             features, labels = next(it)
             spec = self.model_fn(features, labels, ModeKeys.EVAL, self.params)
             tot += float(spec.loss)
+        if hasattr(it, "close"):
+            it.close()
         self._log(f"eval: mean loss {tot / max(steps, 1):.4f} over {steps} steps")
         return {"loss": tot / max(steps, 1)}

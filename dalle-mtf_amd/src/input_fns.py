@@ -1,9 +1,74 @@
-"""Input pipelines.  The reference's tf.data TFRecord/JPEG readers (src/input_fns.py:15-120) are the
-"next" row (f)1 of SURVEY.md §8; the hot-path metric uses synthetic batches:
-CIFAR-shaped uint8 images normalised (x-127.5)/127.5 (input_fns.py:20) and random captions right-padded
-with padding_id to text_seq_len (input_fns.py:32-38)."""
+"""Input pipelines (reference src/input_fns.py:1-120).
+
+Two sources behind the reference's two entry points `dalle_input_fn` / `vae_input_fn`:
+  * real data: TFRecord shards of tf.train.Example{"image": JPEG bytes, "caption": int64[]} (written by
+    src/data/create_tfrecords.py:47-56) or, for the VAE, a glob of JPEG files.  Framing/proto parsing is in
+    data/tfrecord.py; JPEG decode is PIL (libjpeg, same codec family as tf.image.decode_jpeg); the reference's
+    tf.data graph (file shuffle -> 4-way interleave -> map -> shuffle(5*batch) -> batch(drop_remainder) -> prefetch
+    -> repeat, input_fns.py:23-29,104-120) is restated as a Python generator with a decode thread pool and a
+    bounded prefetch queue feeding the GPU step;
+  * `synthetic*` / `gs://` paths: seeded synthetic batches of the same shapes (the bench metric's data, §8(d)).
+"""
+import glob as _glob
+import queue
+import threading
+from concurrent.futures import ThreadPoolExecutor
+import io
+
 import numpy as np
 import torch
+
+from .data.tfrecord import read_records, decode_example
+
+
+def crop_center_and_resize(img, size):
+    """reference input_fns.py:4-12 over tf.image.crop_and_resize (bilinear, extrapolation 0).
+
+    Kept bug-for-bug: the reference names s[0] (rows) `w` and s[1] (cols) `h`, and passes the box as
+    [(1-wn)/2, (1-hn)/2, wn, hn] where TF expects [y1, x1, y2, x2]; for square inputs that is the identity box
+    [0,0,1,1] (a plain bilinear resize), for non-square inputs it is whatever that expression selects.
+    img: [H,W,C] uint8/float; returns [size,size,C] float32."""
+    img = np.asarray(img)
+    H, W = img.shape[0], img.shape[1]
+    w, h = H, W
+    c = max(w, h)
+    wn, hn = h / c, w / c
+    y1, x1, y2, x2 = np.float32((1 - wn) / 2), np.float32((1 - hn) / 2), np.float32(wn), np.float32(hn)
+    f32 = np.float32
+    src = img.astype(np.float32)
+    idx = np.arange(size, dtype=np.float32)
+    if size > 1:
+        in_y = y1 * f32(H - 1) + idx * ((y2 - y1) * f32(H - 1) / f32(size - 1))
+        in_x = x1 * f32(W - 1) + idx * ((x2 - x1) * f32(W - 1) / f32(size - 1))
+    else:
+        in_y = np.full((1,), f32(0.5) * (y1 + y2) * f32(H - 1), dtype=np.float32)
+        in_x = np.full((1,), f32(0.5) * (x1 + x2) * f32(W - 1), dtype=np.float32)
+    oky = (in_y >= 0) & (in_y <= H - 1)
+    okx = (in_x >= 0) & (in_x <= W - 1)
+    cy, cx = np.clip(in_y, 0, H - 1), np.clip(in_x, 0, W - 1)
+    top, bot = np.floor(cy).astype(np.int64), np.ceil(cy).astype(np.int64)
+    lef, rig = np.floor(cx).astype(np.int64), np.ceil(cx).astype(np.int64)
+    ly = (cy - top.astype(np.float32))[:, None, None]
+    lx = (cx - lef.astype(np.float32))[None, :, None]
+    tl, tr = src[top][:, lef], src[top][:, rig]
+    bl, br = src[bot][:, lef], src[bot][:, rig]
+    t = tl + (tr - tl) * lx
+    b = bl + (br - bl) * lx
+    out = t + (b - t) * ly
+    out = out * (oky[:, None, None] & okx[None, :, None])
+    return out.astype(np.float32)
+
+
+def decode_img(img_bytes, size, channels=3):
+    """reference input_fns.py:15-21: decode_jpeg(channels) -> crop_center_and_resize -> (x - 127.5) / 127.5."""
+    from PIL import Image
+    im = Image.open(io.BytesIO(img_bytes))
+    im = im.convert("L" if channels == 1 else "RGB")
+    arr = np.asarray(im)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    out = crop_center_and_resize(arr, size)
+    return (out - np.float32(127.5)) / np.float32(127.5)
 
 
 def truncate_or_pad_label(label, params):
@@ -28,38 +93,203 @@ def _is_synthetic(path):
     return (not path) or str(path).startswith("synthetic") or str(path).startswith("gs://")
 
 
-def dalle_input_fn(params, eval=False):
-    """yields (image [B,H,W,C] fp32 in [-1,1], caption ids [B,text_seq_len] int32) forever."""
+def _batch_size(params, eval):
+    return params["batch_size"] if params.get("batch_size") else params["eval_batch_size" if eval else "train_batch_size"]
+
+
+def _dp_shard(params):
+    """(rank, world): data-parallel ranks read disjoint element streams (element i goes to rank i % world)."""
+    return int(params.get("dp_rank", 0)), int(params.get("dp_world", 1))
+
+
+def read_labeled_tfrecord(params):
+    """reference input_fns.py:41-55: Example -> (image fp32 [size,size,C], caption int32 [text_seq_len])."""
+    size, ch = params["dataset"]["image_size"], params.get("n_channels") or 3
+
+    def read_fn(example):
+        feats = decode_example(example)
+        image = decode_img(feats["image"][0], size, ch)
+        label = truncate_or_pad_label(feats.get("caption", []), params)
+        return image, label
+    return read_fn
+
+
+def read_tfrecord(params):
+    """reference input_fns.py:58-68: Example -> (image, image)."""
+    size, ch = params["dataset"]["image_size"], params.get("n_channels") or 3
+
+    def read_fn(example):
+        image = decode_img(decode_example(example)["image"][0], size, ch)
+        return image, image
+    return read_fn
+
+
+def _interleave_records(files, cycle_length=4):
+    """tf.data parallel_interleave(TFRecordDataset, cycle_length=4, sloppy=False, block_length=1): round-robin one
+    record at a time over up to cycle_length open files; an exhausted file's slot is refilled with the next file."""
+    pending = list(files)
+    slots = []
+    while pending and len(slots) < cycle_length:
+        slots.append(read_records(pending.pop(0)))
+    i = 0
+    while slots:
+        i %= len(slots)
+        try:
+            yield next(slots[i])
+            i += 1
+        except StopIteration:
+            if pending:
+                slots[i] = read_records(pending.pop(0))
+            else:
+                slots.pop(i)
+
+
+def _shuffle(it, buffer_size, rng):
+    """tf.data shuffle(buffer_size): fill a buffer, emit a uniformly random slot, refill it."""
+    buf = []
+    for x in it:
+        if len(buf) < buffer_size:
+            buf.append(x)
+            continue
+        j = int(rng.integers(0, buffer_size))
+        yield buf[j]
+        buf[j] = x
+    while buf:
+        j = int(rng.integers(0, len(buf)))
+        yield buf.pop(j)
+
+
+class _Prefetch:
+    """Bounded background producer (tf.data prefetch): decodes on a thread pool so JPEG work overlaps the GPU step."""
+
+    def __init__(self, make_epoch, map_fn, batch, shuffle_buf, seed, workers=8, depth=4, shard=(0, 1)):
+        self._q = queue.Queue(maxsize=depth)
+        self._stop = threading.Event()
+        self._args = (make_epoch, map_fn, batch, shuffle_buf, seed, workers, shard)
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        make_epoch, map_fn, batch, shuffle_buf, seed, workers, (rank, world) = self._args
+        rng = np.random.default_rng(seed)
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                def mapped():             # ordered map with a bounded number of decodes in flight
+                    inflight, ahead = [], workers * 4
+                    for n, raw in enumerate(make_epoch()):
+                        if n % world != rank:
+                            continue
+                        inflight.append(pool.submit(map_fn, raw))
+                        if len(inflight) >= ahead:
+                            yield inflight.pop(0).result()
+                    for f in inflight:
+                        yield f.result()
+
+                while not self._stop.is_set():     # .repeat() sits after batch(): every epoch drops its remainder
+                    stream = mapped()
+                    if shuffle_buf:
+                        stream = _shuffle(stream, shuffle_buf, rng)
+                    window, produced = [], 0
+                    for el in stream:
+                        if self._stop.is_set():
+                            return
+                        window.append(el)
+                        if len(window) < batch:
+                            continue
+                        a = torch.from_numpy(np.stack([w[0] for w in window]))
+                        b = torch.from_numpy(np.stack([w[1] for w in window]))
+                        window, produced = [], produced + 1
+                        while not self._stop.is_set():
+                            try:
+                                self._q.put((a, b), timeout=0.2)
+                                break
+                            except queue.Full:
+                                pass
+                    if produced == 0:
+                        raise ValueError(f"input pipeline: an epoch holds fewer than batch_size={batch} elements")
+        except BaseException as e:  # surfaced to the consumer
+            self._q.put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        self._stop.set()
+
+
+def _file_order(files, eval, seed):
+    """Dataset.shuffle(file_count, reshuffle_each_iteration=False): one fixed permutation (train only)."""
+    files = sorted(files)
+    if not eval and len(files) > 1:
+        files = [files[i] for i in np.random.default_rng(seed).permutation(len(files))]
+    return files
+
+
+def _synthetic_dalle(params, eval):
     ds = params["dataset"]
-    path = ds["train_path"] if not eval else ds["eval_path"]
-    if not _is_synthetic(path):
-        raise NotImplementedError("TFRecord input is SURVEY.md §8(f) rank 1 (next row); use a 'synthetic' dataset path")
-    B = params["batch_size"] if params.get("batch_size") else params["eval_batch_size" if eval else "train_batch_size"]
+    B = _batch_size(params, eval)
     size, ch = ds["image_size"], params.get("n_channels") or 3
     pad = params["padding_id"] if params.get("padding_id") is not None else params["text_vocab_size"] - 1
     rng = np.random.default_rng(1 if not eval else 101)
+    while True:
+        img = rng.integers(0, 256, size=(B, size, size, ch), dtype=np.uint8)
+        img = (img.astype(np.float32) - 127.5) / 127.5
+        yield torch.from_numpy(img), torch.from_numpy(_synthetic_captions(rng, B, params["text_seq_len"], pad))
 
-    def gen():
-        while True:
-            img = rng.integers(0, 256, size=(B, size, size, ch), dtype=np.uint8)
-            img = (img.astype(np.float32) - 127.5) / 127.5
-            yield torch.from_numpy(img), torch.from_numpy(_synthetic_captions(rng, B, params["text_seq_len"], pad))
-    return gen()
+
+def _synthetic_vae(params, eval):
+    ds = params["dataset"]
+    B = _batch_size(params, eval)
+    size, ch = ds["image_size"], params.get("n_channels") or 3
+    rng = np.random.default_rng(0 if not eval else 100)
+    while True:
+        img = rng.integers(0, 256, size=(B, size, size, ch), dtype=np.uint8)
+        img = torch.from_numpy((img.astype(np.float32) - 127.5) / 127.5)
+        yield img, img
+
+
+def dalle_input_fn(params, eval=False):
+    """reference input_fns.py:104-120.  Yields (image [B,H,W,C] fp32 in [-1,1], caption ids [B,text_seq_len] int32)
+    forever."""
+    ds = params["dataset"]
+    path = ds["train_path"] if not eval else ds["eval_path"]
+    if _is_synthetic(path):
+        return _synthetic_dalle(params, eval)
+    files = _glob.glob(path)
+    if not files:
+        raise FileNotFoundError(f"dalle_input_fn: no TFRecord files match {path!r}")
+    seed = int(params.get("input_seed", 0))
+    files = _file_order(files, eval, seed)
+    B = _batch_size(params, eval)
+    return _Prefetch(lambda: _interleave_records(files, 4), read_labeled_tfrecord(params), B,
+                     0 if eval else B * 5, seed + 1, shard=_dp_shard(params))
 
 
 def vae_input_fn(params, eval=False):
-    """yields (image, image) forever ("returns image twice", input_fns.py:64,100)."""
+    """reference input_fns.py:68-101.  Yields (image, image) forever ("returns image twice")."""
     ds = params["dataset"]
     path = ds["train_path"] if not eval else ds["eval_path"]
-    if not _is_synthetic(path):
-        raise NotImplementedError("JPEG/TFRecord input is SURVEY.md §8(f) rank 1 (next row); use a 'synthetic' dataset path")
-    B = params["batch_size"] if params.get("batch_size") else params["eval_batch_size" if eval else "train_batch_size"]
-    size, ch = ds["image_size"], params.get("n_channels") or 3
-    rng = np.random.default_rng(0 if not eval else 100)
+    if _is_synthetic(path):
+        return _synthetic_vae(params, eval)
+    files = _glob.glob(path)
+    if not files:
+        raise FileNotFoundError(f"vae_input_fn: nothing matches {path!r}")
+    seed = int(params.get("input_seed", 0))
+    files = _file_order(files, eval, seed)
+    B = _batch_size(params, eval)
+    size = ds["image_size"]
+    if ds.get("tfrecords"):
+        return _Prefetch(lambda: _interleave_records(files, 4), read_tfrecord(params), B,
+                         0 if eval else B * 5, seed + 1, shard=_dp_shard(params))
 
-    def gen():
-        while True:
-            img = rng.integers(0, 256, size=(B, size, size, ch), dtype=np.uint8)
-            img = torch.from_numpy((img.astype(np.float32) - 127.5) / 127.5)
-            yield img, img
-    return gen()
+    def _process_path(file_path):          # input_fns.py:92-96 (decode_img with its default 3 channels)
+        with open(file_path, "rb") as f:
+            img = decode_img(f.read(), size)
+        return img, img
+    return _Prefetch(lambda: iter(files), _process_path, B, 0 if eval else B * 5, seed + 1, shard=_dp_shard(params))

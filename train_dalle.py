@@ -64,6 +64,7 @@ def main():
         f"tokenizer vocab size {len(tokenizer)} must equal model vocab size {params['text_vocab_size']}"
     params["padding_id"] = tokenizer.encode(tokenizer.pad_token)[0]
     params["batch_size"] = params["train_batch_size"] // world
+    params["dp_rank"], params["dp_world"] = int(os.environ.get("RANK", "0")), world
 
     estimator = Estimator(model_fn=dalle_model_fn, model_dir=params["model_path"], params=params,
                           log_every=min(params["iterations"] or 100, 100), logger=logging)

@@ -48,6 +48,7 @@ def main():
     params["use_tpu"] = False
     params["gpu_ids"] = args.gpu_ids
     params["batch_size"] = params["train_batch_size"] // world
+    params["dp_rank"], params["dp_world"] = int(os.environ.get("RANK", "0")), world
     estimator = Estimator(model_fn=vae_model_fn, model_dir=params["model_path"], params=params,
                           log_every=min(params["iterations"] or 100, 100), logger=logging)
     has_predict_or_eval_steps = params["predict_steps"] > 0 or params["eval_steps"] > 0
