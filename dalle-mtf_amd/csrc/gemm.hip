@@ -25,6 +25,8 @@ static int g_opt_tn_trread = 1;
 static int g_opt_nt2 = 1;
 static int g_opt_prio = 0;
 static int g_opt_nt4 = 1;
+static int g_opt_nt5 = 0;  // hand-scheduled 3-stage kernel (0 off, 2 = 256x128 tiles, 3 = 128x128 tiles): bit-identical, measured equal
+                           // to v2/v4 within noise on every shape of the model (tools/ksweep.py) -- kept as a tested option
 static int g_opt_nt3 = 0;  // persistent variant: bit-identical, measured 5-12 % slower than per-tile launches (kept as a tested option)
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
@@ -33,6 +35,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "prio")) return g_opt_prio;
   if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt3")) return g_opt_nt3;
+  if (!strcmp(name, "nt5")) return g_opt_nt5;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
@@ -42,6 +45,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "prio")) { g_opt_prio = value; return 0; }
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt3")) { g_opt_nt3 = value; return 0; }
+  if (!strcmp(name, "nt5")) { g_opt_nt5 = value; return 0; }
   return -1;
 }
 
@@ -728,6 +732,221 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   }
 }
 
+// =====================================================================================
+// NT GEMM v5: hand-scheduled main loop.  hipcc schedules the fragment ds_reads of v2/v4 with a minimal register
+// footprint (4 reads -> wait -> 1 MFMA -> wait -> 3 MFMAs -> 2 reads -> wait ...), exposing an LDS round trip three
+// times per 8 MFMAs, and both kernels prefetch only one k-step ahead (vmcnt(0) + barrier every step).  Here:
+//   * fragment reads are inline-asm ds_read_b128 into two register sets; the set for k-substep s+1 is issued before
+//     the 8 (MI=4) / 4 (MI=2) MFMAs of substep s and waited for (lgkmcnt) after them;
+//   * a ring of 3 LDS stages (BK = 32) with counted vmcnt keeps two stages of LDS-DMA in flight; one raw s_barrier per
+//     step, placed between the two substeps so the DMA issue + next reads are covered by the second MFMA cluster.
+// Tile = (64*MI) x 128: MI = 4 -> 256x128, 72 KiB LDS, 2 blocks / CU; MI = 2 -> 128x128, 48 KiB, 3 blocks / CU.
+// =====================================================================================
+template <int MI>
+struct Frag5 {
+  u32x4 a[MI];
+  u32x4 b[2];
+};
+template <int OFF>
+__device__ __forceinline__ void f5_issue(Frag5<4>& f, unsigned va, unsigned vb) {
+  asm volatile(
+      "ds_read_b128 %4, %7 offset:%8\n\t"
+      "ds_read_b128 %0, %6 offset:%8\n\t"
+      "ds_read_b128 %5, %7 offset:%9\n\t"
+      "ds_read_b128 %1, %6 offset:%9\n\t"
+      "ds_read_b128 %2, %6 offset:%10\n\t"
+      "ds_read_b128 %3, %6 offset:%11"
+      : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.a[2]), "=&v"(f.a[3]), "=&v"(f.b[0]), "=&v"(f.b[1])
+      : "v"(va), "v"(vb), "i"(OFF), "i"(OFF + 2048), "i"(OFF + 4096), "i"(OFF + 6144)
+      : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void f5_issue(Frag5<2>& f, unsigned va, unsigned vb) {
+  asm volatile(
+      "ds_read_b128 %2, %5 offset:%6\n\t"
+      "ds_read_b128 %0, %4 offset:%6\n\t"
+      "ds_read_b128 %3, %5 offset:%7\n\t"
+      "ds_read_b128 %1, %4 offset:%7"
+      : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1])
+      : "v"(va), "v"(vb), "i"(OFF), "i"(OFF + 2048)
+      : "memory");
+}
+// Ordering pins (hipcc freely moves the pure MFMA builtins across asm statements otherwise -- it sank the fragment
+// issue below 6 of the 8 MFMAs it was meant to hide under):
+//   f5_pin(cur):        names the set the next MFMAs consume as "+v" -> those MFMAs are scheduled after this point;
+//   f5_wait(f, acc...): names the accumulators as "+v" -> every MFMA issued so far is scheduled before the wait.
+__device__ __forceinline__ void f5_pin(Frag5<4>& f) {
+  asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
+}
+__device__ __forceinline__ void f5_pin(Frag5<2>& f) {
+  asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
+}
+__device__ __forceinline__ void f5_wait(Frag5<4>& f, f32x16 (&c)[4][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]),
+                 "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[3][0]), "+v"(c[3][1])
+               :
+               : "memory");
+}
+__device__ __forceinline__ void f5_wait(Frag5<2>& f, f32x16 (&c)[2][2]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1])
+               :
+               : "memory");
+}
+
+template <int FLAGS, int MI>
+__global__ __launch_bounds__(256, (MI == 4 ? 2 : 3)) void gemm_nt5_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][A (64*MI rows x 64 B) | B 8 KiB]
+  constexpr int TM = 64 * MI;            // tile rows
+  constexpr int ASZ = TM * 64;           // bytes of the A part of a stage
+  constexpr int STG = ASZ + 8192;
+  constexpr int NL = MI + 2;             // LDS-DMA instructions per wave per stage
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
+  const int m0 = tm * TM, n0 = tn * BN;
+  const int nt = a.K / BK4;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)n0 * a.ldb), 0, 0x7fffffff, 0x00020000);
+  int voa[MI], vob[2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
+    const int rr = m0 + row < a.M ? row : a.M - 1 - m0;
+    voa[i] = (rr * a.lda + 8 * (pc ^ ((row >> 2) & 3))) * 2;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
+    const int rn = n0 + row < a.N ? row : a.N - 1 - n0;
+    vob[i] = (rn * a.ldb + 8 * (pc ^ ((row >> 2) & 3))) * 2;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned va[2], vb[2];  // per-lane fragment addresses of k-substep 0 / 1 inside a stage
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    va[kk] = lds0 + lds4_off(wm * (32 * MI) + r, kk * 2 + h);
+    vb[kk] = lds0 + ASZ + lds4_off(wn * 64 + r, kk * 2 + h);
+  }
+
+  f32x16 acc[MI][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stage = [&](int st, int t) {  // st compile-time after unrolling
+    char* base = smem + st * STG + wid * 1024;
+    const int soff = t * (BK4 * 2);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) glds16(ra, base + i * 4096, voa[i], soff);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(rb, base + ASZ + i * 4096, vob[i], soff);
+  };
+  auto mfmas = [&](Frag5<MI>& f) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[j]), __builtin_bit_cast(bf16x8, f.a[i]),
+                                                            acc[i][j], 0, 0, 0);  // D[n][m]
+  };
+  Frag5<MI> F0, F1;
+
+#define NT5_STEP(S, T)                                                                \
+  {                                                                                   \
+    f5_wait(F0, acc);                                                                 \
+    f5_issue<(S) * STG>(F1, va[1], vb[1]);                                            \
+    f5_pin(F0);                                                                       \
+    mfmas(F0);                                                                        \
+    f5_wait(F1, acc);                                                                 \
+    if ((T) + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory"); \
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              \
+    if ((T) + 3 < nt) stage((S), (T) + 3);                                            \
+    if ((T) + 1 < nt) f5_issue<(((S) + 1) % 3) * STG>(F0, va[0], vb[0]);              \
+    f5_pin(F1);                                                                       \
+    mfmas(F1);                                                                        \
+  }
+
+  stage(0, 0);
+  if (nt > 1) stage(1, 1);
+  if (nt > 2) stage(2, 2);
+  if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");
+  else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  f5_issue<0>(F0, va[0], vb[0]);
+  int t = 0;
+  for (; t + 3 <= nt; t += 3) {  // single-exit loop: stage indices stay compile-time, accumulators stay in place
+    NT5_STEP(0, t);
+    NT5_STEP(1, t + 1);
+    NT5_STEP(2, t + 2);
+  }
+  if (t < nt) {
+    NT5_STEP(0, t);
+    if (t + 1 < nt) NT5_STEP(1, t + 1);
+  }
+#undef NT5_STEP
+
+  // epilogue (all fragment reads were completed before the last barrier): wave-private fp32 staging, 32 rows x 64
+  // cols at a time (pitch 272 B), full-row 16-B stores
+  float* stg = (float*)(smem + wid * 8704);
+  const int orow = lane >> 3, ocol = (lane & 7) * 8;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
+            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + orow;
+      const int m = m0 + wm * (32 * MI) + i * 32 + row;
+      const int n = n0 + wn * 64 + ocol;
+      const f32x4 lo = *(const f32x4*)(stg + row * 68 + ocol);
+      const f32x4 hi = *(const f32x4*)(stg + row * 68 + ocol + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if (m < a.M && n < a.N) {
+        const int64_t off = (int64_t)m * a.ldc + n;
+        if constexpr (FLAGS & DMI_GEMM_BIAS) {
+          float b[8];
+          unpack8(*(const u32x4*)(a.bias + n), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+        if constexpr (FLAGS & DMI_GEMM_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
+          float b[8];
+          unpack8(*(const u32x4*)(a.residual + off), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += b[e];
+        }
+        if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+          float b[8];
+          unpack8(*(const u32x4*)(a.relu_src + off), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
+        }
+        *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int nsplit, int64_t n4, int64_t stride4) {
@@ -746,6 +965,21 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
   const size_t shm = 65536;
   if constexpr (!(FLAGS & DMI_GEMM_OUT_F32)) {
+    if (g_opt_nt5 >= 2 && nsplit == 1 && a.k_per_split == a.K) {
+      GemmArgs b = a;
+      if (g_opt_nt5 == 2) {
+        static bool attr5 = false;
+        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<FLAGS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728); attr5 = true; }
+        b.tiles_m = (a.M + 255) / 256;
+        gemm_nt5_kernel<FLAGS, 4><<<dim3(b.tiles_m * a.tiles_n), blk, 73728, st>>>(b);
+      } else {
+        static bool attr5 = false;
+        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<FLAGS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152); attr5 = true; }
+        gemm_nt5_kernel<FLAGS, 2><<<dim3(a.tiles_m * a.tiles_n), blk, 49152, st>>>(b);
+      }
+      DMI_CHECK_LAUNCH("gemm_nt5");
+      return DMI_OK;
+    }
     const int tiles4 = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
     if (g_opt_nt4 && g_opt_nt2 && g_opt_glds && nsplit == 1 && a.k_per_split == a.K && ((tiles4 >= 1536 && a.K <= 1024) || g_opt_nt4 == 2)) {  // 2 = force (tests); long-K shapes prefer the BK=64 kernel
       static bool attr4 = false;

@@ -101,7 +101,10 @@ def _check(rc, what):
 
 
 def _p(t):
-    return 0 if t is None else t.data_ptr()
+    """device pointer of a tensor, or a raw device address (int) for sub-buffer views (row chunks)."""
+    if t is None:
+        return 0
+    return t if isinstance(t, int) else t.data_ptr()
 
 
 def _stream():
@@ -110,7 +113,7 @@ def _stream():
 
 def _dev(*ts):
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is not None and not isinstance(t, int) and not t.is_cuda:
             raise DalleHipError("dalle_hip ops need CUDA(HIP) tensors; there is no CPU fallback")
 
 

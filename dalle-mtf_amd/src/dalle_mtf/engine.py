@@ -338,7 +338,7 @@ class DalleEngine:
             self._side_done = None
         self._ev.clear()
 
-    def backward(self):
+    def backward(self, allreduce=True):
         """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  Weight gradients are issued on the
         side stream; with world_size > 1 each finished bucket is all-reduced (SUM) asynchronously, one layer behind the
         compute so the join with the side stream never stalls the dependency chain -- the explicit form of mtf's
@@ -352,7 +352,7 @@ class DalleEngine:
         def flush_buckets(keep_last):
             while len(pending_bucket) > (1 if keep_last else 0):
                 idx, ev = pending_bucket.pop(0)
-                if self.world > 1:
+                if self.world > 1 and allreduce:
                     if ev is not None:
                         torch.cuda.current_stream().wait_event(ev)
                     self._allreduce_bucket(idx)
@@ -469,10 +469,34 @@ class DalleEngine:
         return lr
 
     def train_step(self, tokens: torch.Tensor) -> torch.Tensor:
-        loss = self.forward(tokens, need_grad=True)
-        self.backward()
+        """One optimizer step.  With hparams["num_microbatches"] = n > 1, `tokens` holds n micro-batches of B rows
+        ([n*B, S]): gradients are accumulated locally and reduced once, and the loss is the sum of the micro-batch
+        means / n (mtf.serialize_training_step as used at src/model_fns.py:156-166; src/dalle_mtf/models.py:356)."""
+        nmb = self.hp.get("num_microbatches", 1) or 1
+        if nmb == 1:
+            loss = self.forward(tokens, need_grad=True)
+            self.backward()
+            self.optimizer_step()
+            return loss
+        assert tokens.shape == (nmb * self.B, self.S), f"expected {nmb} micro-batches of {self.B} rows"
+        if getattr(self, "gacc", None) is None:
+            self.gacc = torch.empty_like(self.g)
+        if getattr(self, "loss_acc", None) is None:
+            self.loss_acc = torch.zeros_like(self.loss)
+        self.loss_acc.zero_()
+        for i in range(nmb):
+            loss = self.forward(tokens[i * self.B:(i + 1) * self.B], need_grad=True)
+            self.loss_acc += loss
+            self.backward(allreduce=False)
+            if i == 0:
+                self.gacc.copy_(self.g)
+            else:
+                dh.add_f32(self.gacc, self.g, self.lay.total)
+        self.g.copy_(self.gacc)
+        for idx in range(len(self.lay.bucket_ends)):
+            self._allreduce_bucket(idx)
         self.optimizer_step()
-        return loss
+        return self.loss_acc
 
     def grad_norm(self) -> float:
         return float(torch.sqrt(self.gnorm_sq).item())

@@ -58,6 +58,15 @@ def initialize_vae_weights(vae, checkpoint_path):
     vae.load_reference_params(sd["vae_variables"])
 
 
+def serialize_num_microbatches(batch_per_replica, sequence_length, tokens_per_microbatch_per_replica=None):
+    """mtf.transformer.utils.serialize_num_microbatches (mesh_tensorflow 0.1.18) for the batch_dim:data layout:
+    sequences per micro-batch = max(1, tokens_per_mb // seq_len); count = batch_per_replica // that."""
+    if not tokens_per_microbatch_per_replica:
+        return 1
+    microbatch_size = max(1, int(tokens_per_microbatch_per_replica) // int(sequence_length))
+    return max(1, batch_per_replica // microbatch_size)
+
+
 def _build(params, mode_str):
     world, rank, pg = _dist_info()
     mesh = parse_mesh_shape(params.get("mesh_shape"))
@@ -74,14 +83,20 @@ def _build(params, mode_str):
         # reference model_fns.py:68
         image_seq_len = (vae.H // (2 ** len(vae.convblocks))) ** 2 // (vae.stack_factor ** 2)
         state["vae"] = vae
+    nmb = 1
+    if mode_str == "train":
+        nmb = serialize_num_microbatches(local_bs, params["text_seq_len"] + image_seq_len,
+                                         params.get("tokens_per_mb_per_replica"))
+        assert local_bs % nmb == 0, f"per-replica batch {local_bs} does not split into {nmb} micro-batches"
     model = DALLE(n_embd=params["n_embd"], text_vocab_size=params["text_vocab_size"],
                   image_vocab_size=params["image_vocab_size"], text_seq_len=params["text_seq_len"],
                   image_seq_len=image_seq_len, n_layers=params["n_layers"], n_heads=params["n_heads"],
-                  batch_size=local_bs, bf_16=params["bf_16"], mode=mode_str, params=params,
-                  process_group=pg, world_size=world, global_batch_size=gbs)
+                  batch_size=local_bs // nmb, bf_16=params["bf_16"], mode=mode_str, params=params,
+                  process_group=pg, world_size=world, global_batch_size=gbs // nmb)
     eng = model.engine
-    eng.hp["num_microbatches"] = 1  # tokens_per_mb_per_replica unset in every shipped config (model_fns.py:141-154)
-    params["num_microbatches"] = 1
+    eng.hp["num_microbatches"] = nmb   # reference model_fns.py:141-154 (1 when tokens_per_mb_per_replica is unset)
+    params["num_microbatches"] = nmb
+    state["local_bs"] = local_bs
     ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
     if ck is not None:
         eng.load_state_dict(torch.load(ck, map_location="cpu")["dalle"])
@@ -117,7 +132,8 @@ def dalle_model_fn(features, labels, mode, params):
     model, eng = st["model"], st["model"].engine
     model.mode = mode_str
     dev = eng.dev
-    B, T, P = eng.B, eng.T, st["image_seq_len"]
+    nmb = eng.hp.get("num_microbatches", 1) if mode == ModeKeys.TRAIN else 1
+    B, T, P = eng.B * nmb, eng.T, st["image_seq_len"]
     text = labels.to(device=dev, dtype=torch.int32).reshape(B, T)
     tokens = torch.empty(B, T + P, dtype=torch.int32, device=dev)
     if st["vae"] is not None:
@@ -128,6 +144,20 @@ def dalle_model_fn(features, labels, mode, params):
         img = features["image_tokens"] if isinstance(features, dict) else features
         tokens[:, :T] = text
         tokens[:, T:] = img.to(device=dev, dtype=torch.int32).reshape(B, P) + eng.text_vocab_size
+    if nmb > 1:
+        # serialized training step (model_fns.py:156-166): forward/backward per micro-batch inside train_op, gradients
+        # accumulated locally and reduced once; spec.loss is filled in by train_op
+        if getattr(eng, "loss_acc", None) is None:
+            eng.loss_acc = torch.zeros_like(eng.loss)
+
+        def train_op_mb():
+            eng.train_step(tokens)
+            return eng.global_step
+        scalar_summary("loss", eng.loss_acc[0])
+        scalar_summary("lr", st["lr_fn"]())
+        return EstimatorSpec(mode=mode, loss=eng.loss_acc[0], train_op=train_op_mb,
+                             host_call=create_host_call(params["model_path"]) if params.get("model_path") else None,
+                             training_hooks=[st["saver"]])
     loss, _loss_batch = model.forward({"tokens": tokens}, return_loss=True)
     if mode == ModeKeys.EVAL:
         return EstimatorSpec(mode=mode, loss=loss)

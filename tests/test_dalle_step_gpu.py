@@ -52,3 +52,33 @@ def test_eval_logits_match_oracle():
     _, _, ref = do.forward(Pt, tokens, cfg, bf16=False, return_logits=True)
     ref = ref.numpy()
     assert np.abs(got - ref).max() <= 3e-2 * max(1.0, np.abs(ref).max()), np.abs(got - ref).max()
+
+
+def test_microbatched_step_equals_full_batch_step():
+    """Serialized training step (src/model_fns.py:141-166, src/dalle_mtf/models.py:356): 4 micro-batches of 1 row
+    accumulated locally == one step on the 4-row batch -- same loss, same gradients (fp32 accumulation-order
+    tolerance) and therefore the same Adam update; also equals the oracle's full-batch loss."""
+    from collections import OrderedDict
+    from oracle import dalle_oracle as do
+    from src.dalle_mtf.engine import DalleEngine
+    cfg = do.DalleConfig(128, 100, 20, 24, 40, 2, 1)
+    P0 = do.init_params(cfg, seed=11, perturb=0.05)
+    tokens = do.assemble_tokens(do.synthetic_captions(4, 24, 100, seed=1), do.synthetic_image_tokens(4, 40, 20, seed=2), 100)
+    tok = torch.from_numpy(tokens).cuda()
+    hp = dict(lr=1e-3, train_steps=10, warmup_steps=0)
+    full = DalleEngine(128, 2, 1, 100, 20, 24, 40, batch_size=4, hparams=dict(hp))
+    full.load_reference_params(P0)
+    loss_full = float(full.train_step(tok))
+    g_full = full.g.clone()
+    mb = DalleEngine(128, 2, 1, 100, 20, 24, 40, batch_size=1, global_batch_size=1, hparams=dict(hp, num_microbatches=4))
+    mb.load_reference_params(P0)
+    loss_mb = float(mb.train_step(tok))
+    assert mb.global_step == 1
+    assert abs(loss_mb - loss_full) <= 2e-3 * abs(loss_full), (loss_mb, loss_full)
+    num = float((mb.g - g_full).norm())
+    den = float(g_full.norm())
+    assert num <= 2e-2 * den, (num, den)          # bf16 activations: per-row kernels see different tilings
+    assert float((mb.p - full.p).abs().max()) <= 2.5e-3  # |Adam step| <= ~3.2 lr without bias correction
+    Pt = OrderedDict((k, torch.tensor(v)) for k, v in P0.items())
+    ref_loss, _ = do.forward(Pt, tokens, cfg, bf16=False)[:2]
+    assert abs(loss_mb - float(ref_loss)) <= 1e-2 * abs(float(ref_loss))

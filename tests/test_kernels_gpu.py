@@ -177,6 +177,35 @@ def test_gemm_nt4_tile_256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "256-row-tile and 128-row-tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 64, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3),
+                                         (515, 136, 64, 8), (700, 384, 320, 0), (260, 128, 1024, 4), (1024, 512, 2112, 0)])
+@pytest.mark.parametrize("mode", [2, 3])
+def test_gemm_nt5_hand_scheduled(M, N, K, flags, mode):
+    """3-stage-ring kernel with asm-scheduled fragment reads (forced; mode 2 = 256x128 tiles, 3 = 128x128), K-step counts
+    2..66 (all residues mod 3), M/N tails and every epilogue: bit-identical to the 128x128x64 kernel (same k order)."""
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    hsrc = torch.relu(rnd(M, N, seed=5))
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None,
+              relu_src=hsrc.to(DEV) if flags & 8 else None)
+    ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None,
+                    relu_src=hsrc if flags & 8 else None)
+    outs = []
+    saved = dh.get_option("nt5")
+    dh.set_option("nt4", 0)
+    try:
+        for nt5 in (mode, 0):
+            dh.set_option("nt5", nt5)
+            C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
+            close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt5={nt5}")
+            outs.append(C.cpu())
+    finally:
+        dh.set_option("nt5", saved)
+        dh.set_option("nt4", 1)
+    assert torch.equal(outs[0], outs[1]), "hand-scheduled and compiler-scheduled kernels must be bit-identical"
+
+
 @pytest.mark.parametrize("M,N,K,flags", [(4000, 2568, 128, 0), (8192, 1280, 256, 5), (3000, 3000 // 8 * 8, 384, 3)])
 def test_gemm_nt_persistent(M, N, K, flags):
     """> 512 tiles and an even number of K-steps: the persistent kernel (nt3) path, incl. M/N tails; must agree with nt2."""

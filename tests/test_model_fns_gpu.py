@@ -140,3 +140,23 @@ def test_estimator_trains_from_tfrecords(tmp_path):
     st = dp["_dalle_state_train"]
     toks = st["model"].engine.tokens.cpu().numpy()
     assert toks[:, :dp["text_seq_len"]].max() < dp["text_vocab_size"] and toks[:, dp["text_seq_len"]:].min() >= dp["text_vocab_size"]
+
+
+def test_dalle_model_fn_microbatching():
+    """tokens_per_mb_per_replica -> num_microbatches (src/model_fns.py:141-166): the engine is built for one
+    micro-batch, train_op runs the serialized step, spec.loss reports the full-batch mean."""
+    from oracle import dalle_oracle as do
+    from src.model_fns import dalle_model_fn
+    from src.utils import ModeKeys
+    p = _params("dalle_example", train_batch_size=4, eval_batch_size=4, model_path=None, n_layers=1, n_embd=256, n_heads=2,
+                synthetic_image_tokens=112, text_seq_len=16, warmup_steps=1, lr=3e-3, tokens_per_mb_per_replica=256)
+    text = torch.from_numpy(do.synthetic_captions(4, 16, p["text_vocab_size"], seed=3))
+    imgtok = torch.from_numpy(do.synthetic_image_tokens(4, 112, 512, seed=4))
+    losses = []
+    for i in range(12):
+        spec = dalle_model_fn(imgtok, text, ModeKeys.TRAIN, p)
+        assert spec.train_op() == i + 1
+        losses.append(float(spec.loss))
+    eng = p["_dalle_state_train"]["model"].engine
+    assert p["num_microbatches"] == 2 and eng.B == 2 and eng.hp["num_microbatches"] == 2
+    assert abs(losses[0] - np.log(eng.V)) < 1.0 and losses[-1] < losses[0] - 0.5, losses

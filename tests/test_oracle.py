@@ -178,3 +178,12 @@ def test_space_depth_roundtrip_and_temperature():
     assert vo.temperature(0, p) == 1.0 and abs(vo.temperature(50, p) - 0.525) < 1e-6
     assert abs(vo.temperature(1000, p) - 0.05) < 1e-6
     assert vo.temperature(5, {}) == 1.0
+
+
+def test_serialize_num_microbatches_rule():
+    """mtf.transformer.utils.serialize_num_microbatches as used at reference src/model_fns.py:141-154."""
+    from src.model_fns import serialize_num_microbatches as f
+    assert f(32, 1280, None) == 1 and f(32, 1280, 0) == 1
+    assert f(32, 1280, 1280 * 8) == 4          # 8 sequences per micro-batch
+    assert f(32, 1280, 100) == 32              # < one sequence -> micro-batch of 1
+    assert f(32, 1280, 10 ** 9) == 1           # micro-batch larger than the batch
