@@ -21,8 +21,11 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // RNE (v_cvt_pk_bf16_f32 on gfx950)
   return __builtin_bit_cast(unsigned short, b);
 }
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const pk_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, pk_bf16x2));  // one v_cvt_pk_bf16_f32 (RNE)
 }
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {
 #pragma unroll

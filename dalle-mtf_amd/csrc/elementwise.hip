@@ -649,17 +649,30 @@ __global__ __launch_bounds__(1024) void cross_entropy_reg_kernel(bf16_t* __restr
   bf16_t* zr = z + row * ldz;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int nch = ldz / 8;
-  u32x4 v[NC];
+  // the row lives in registers as fp32 (NC x 8 per thread); each element costs one unpack, one max, one fma + v_exp
+  // (kept: the probabilities are exp(x - max) * (scale / sum), no second exp), one mul and half a pack.  Columns >= V
+  // are set to -inf once at load time so no later pass carries a mask.
+  float f[NC][8];
   float m = -INFINITY;
+  {
+    u32x4 raw[NC];  // all loads in flight before the first use
+    const u32x4 ninf = {0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = tid + 1024 * i;
-    if (c < nch) {
-      v[i] = *(const u32x4*)(zr + c * 8);
-      float f[8];
-      unpack8(v[i], f);
+    for (int i = 0; i < NC; ++i) {
+      const int c = tid + 1024 * i;
+      raw[i] = (c < nch) ? *(const u32x4*)(zr + c * 8) : ninf;
+    }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m = fmaxf(m, (c * 8 + j < V) ? f[j] : -INFINITY);
+    for (int i = 0; i < NC; ++i) {
+      const int c = tid + 1024 * i;
+      unpack8(raw[i], f[i]);
+      if (c * 8 + 8 > V) {  // only the chunk straddling V (and pad chunks); the empty asm keeps this a real branch
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[i][j] = (c * 8 + j < V) ? f[i][j] : -INFINITY;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m = fmaxf(m, f[i][j]);
     }
   }
   m = wave_max(m);
@@ -668,17 +681,16 @@ __global__ __launch_bounds__(1024) void cross_entropy_reg_kernel(bf16_t* __restr
   float bm = sm_m[0];
 #pragma unroll
   for (int w = 1; w < 16; ++w) bm = fmaxf(bm, sm_m[w]);
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float bm2 = bm * LOG2E;
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < NC; ++i) {
-    const int c = tid + 1024 * i;
-    if (c < nch) {
-      float f[8];
-      unpack8(v[i], f);
+  for (int i = 0; i < NC; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += (c * 8 + j < V) ? __expf(f[j] - bm) : 0.f;
+    for (int j = 0; j < 8; ++j) {
+      f[i][j] = __builtin_amdgcn_exp2f(__builtin_fmaf(f[i][j], LOG2E, -bm2));
+      s += f[i][j];
     }
-  }
   s = wave_sum(s);
   if (lane == 0) sm_s[wid] = s;
   __syncthreads();
@@ -694,20 +706,20 @@ __global__ __launch_bounds__(1024) void cross_entropy_reg_kernel(bf16_t* __restr
   }
   if (dz_scale == 0.f) return;
   __syncthreads();
+  const float k = dz_scale / bs;
+  const int lch = (label >= 0 && label < V) ? (label >> 3) : -1, lj = label & 7;
 #pragma unroll
   for (int i = 0; i < NC; ++i) {
     const int c = tid + 1024 * i;
     if (c < nch) {
-      float f[8];
-      unpack8(v[i], f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int col = c * 8 + j;
-        float p = (col < V) ? __expf(f[j] - lse) : 0.f;
-        if (col == label) p -= 1.f;
-        f[j] = p * dz_scale;
+      for (int j = 0; j < 8; ++j) f[i][j] *= k;
+      if (c == lch) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[i][j] -= (j == lj) ? dz_scale : 0.f;
       }
-      *(u32x4*)(zr + c * 8) = pack8(f);
+      *(u32x4*)(zr + c * 8) = pack8(f[i]);
     }
   }
 }
