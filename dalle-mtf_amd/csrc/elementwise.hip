@@ -360,16 +360,23 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restr
   const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cl;
   const int64_t nc = 2 * (int64_t)d;
-  float a0 = 0.f, a1 = 0.f;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
   if (c < nc) {
     int p = grp;
-    for (; p + 16 < P; p += 32) {
-      a0 += part[(int64_t)p * nc + c];
-      a1 += part[(int64_t)(p + 16) * nc + c];
+    for (; p + 112 < P; p += 128) {  // eight independent loads in flight per thread
+      const float* q = part + (int64_t)p * nc + c;
+      a0 += q[0];
+      a1 += q[16 * nc];
+      a2 += q[32 * nc];
+      a3 += q[48 * nc];
+      a4 += q[64 * nc];
+      a5 += q[80 * nc];
+      a6 += q[96 * nc];
+      a7 += q[112 * nc];
     }
-    if (p < P) a0 += part[(int64_t)p * nc + c];
+    for (; p < P; p += 16) a0 += part[(int64_t)p * nc + c];
   }
-  sm[grp][cl] = a0 + a1;
+  sm[grp][cl] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
   __syncthreads();
   if (grp == 0 && c < nc) {
     float s = 0.f;
@@ -447,13 +454,8 @@ extern "C" int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int
 // batched bf16 transpose: element (b,h,r,c) at in + b*sb + h*sh + r*sr + c  ->  out[((b*nh+h)*C + c)*R + r]
 // =====================================================================================
 // Rv = valid input rows, R = output row pitch (>= Rv; rows in [Rv, R) are written as zeros)
-__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
-                                                        int nh, int Rv, int R, int C, int64_t sb, int64_t sh, int64_t sr) {
-  __shared__ unsigned t[64][33];
-  const int bh = blockIdx.z, b = bh / nh, h = bh % nh;
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const bf16_t* src = in + b * sb + h * sh;
-  bf16_t* dst = out + (int64_t)bh * C * R;
+__device__ __forceinline__ void transpose_tile(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int Rv, int R,
+                                               int C, int64_t sr, int r0, int c0, unsigned (*t)[33]) {
   const int tid = threadIdx.x;
   {
     const int chunk = tid & 7, rp = tid >> 3;
@@ -487,6 +489,36 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                        int nh, int Rv, int R, int C, int64_t sb, int64_t sh, int64_t sr) {
+  __shared__ unsigned t[64][33];
+  const int bh = blockIdx.z, b = bh / nh, h = bh % nh;
+  transpose_tile(in + b * sb + h * sh, out + (int64_t)bh * C * R, Rv, R, C, sr, blockIdx.y * 64, blockIdx.x * 64, t);
+}
+
+// Many independent [R,C] -> [C,R] transposes inside one pair of buffers in ONE launch (the per-step refresh of the
+// forward GEMMs' [out,in] weight copies was 25 launches of ~5 us each).  table[i] = {in_off, out_off, R, C,
+// first_tile} in elements / 64x64 tiles, first_tile ascending.
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                              const int64_t* __restrict__ table, int n) {
+  __shared__ unsigned t[64][33];
+  const int64_t tile = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && table[(i + 1) * 5 + 4] <= tile) ++i;
+  const int64_t in_off = table[i * 5], out_off = table[i * 5 + 1];
+  const int R = (int)table[i * 5 + 2], C = (int)table[i * 5 + 3];
+  const int local = (int)(tile - table[i * 5 + 4]);
+  const int tc = (C + 63) / 64;
+  transpose_tile(in + in_off, out + out_off, R, R, C, C, (local / tc) * 64, (local % tc) * 64, t);
+}
+extern "C" int dmi_transpose_bf16_batch(const uint16_t* in_base, uint16_t* out_base, const int64_t* table, int n,
+                                        int64_t total_tiles, void* stream) {
+  DMI_REQUIRE(in_base && out_base && table && n > 0 && total_tiles > 0, "transpose_batch: bad args");
+  transpose_batch_kernel<<<dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream>>>(in_base, out_base, table, n);
+  DMI_CHECK_LAUNCH("transpose_batch");
+  return DMI_OK;
 }
 
 int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int Rv, int Rp, int C,
@@ -751,17 +783,44 @@ __device__ __forceinline__ float block_sum_256(float x, float* sm) {
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, int64_t n, float scale,
-                                                      float* __restrict__ out) {
-  __shared__ float sm[4];
-  float acc = 0.f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) acc += x[i];
-  const float t = block_sum_256(acc, sm);
-  if (threadIdx.x == 0) out[0] = t * scale;
+// one block, 1024 threads, four independent float4 chains per thread (fixed order -> deterministic)
+__global__ __launch_bounds__(1024) void sum_f32_kernel(const float* __restrict__ x, int64_t n, float scale,
+                                                       float* __restrict__ out) {
+  __shared__ float sm[16];
+  const int tid = threadIdx.x;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if ((((uintptr_t)x) & 15) == 0) {
+    const int64_t n4 = n / 4;
+    const f32x4* x4 = (const f32x4*)x;
+    int64_t i = tid;
+    for (; i + 3072 < n4; i += 4096) {
+      const f32x4 v0 = x4[i], v1 = x4[i + 1024], v2 = x4[i + 2048], v3 = x4[i + 3072];
+      a0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+      a1 += (v1[0] + v1[1]) + (v1[2] + v1[3]);
+      a2 += (v2[0] + v2[1]) + (v2[2] + v2[3]);
+      a3 += (v3[0] + v3[1]) + (v3[2] + v3[3]);
+    }
+    for (; i < n4; i += 1024) {
+      const f32x4 v0 = x4[i];
+      a0 += (v0[0] + v0[1]) + (v0[2] + v0[3]);
+    }
+    if (tid < (n & 3)) a1 += x[n4 * 4 + tid];
+  } else {
+    for (int64_t i = tid; i < n; i += 1024) a0 += x[i];
+  }
+  float t = wave_sum((a0 + a1) + (a2 + a3));
+  if ((tid & 63) == 0) sm[tid >> 6] = t;
+  __syncthreads();
+  if (tid == 0) {
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) r += sm[w];
+    out[0] = r * scale;
+  }
 }
 extern "C" int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream) {
   DMI_REQUIRE(x && out && n > 0, "sum_f32: bad args");
-  sum_f32_kernel<<<dim3(1), dim3(256), 0, (hipStream_t)stream>>>(x, n, scale, out);
+  sum_f32_kernel<<<dim3(1), dim3(1024), 0, (hipStream_t)stream>>>(x, n, scale, out);
   DMI_CHECK_LAUNCH("sum_f32");
   return DMI_OK;
 }
@@ -790,7 +849,7 @@ extern "C" int dmi_sumsq(const float* g, int64_t n, float* out, void* workspace,
   hipStream_t st = (hipStream_t)stream;
   sumsq_kernel<<<dim3(SUMSQ_BLOCKS), dim3(256), 0, st>>>(g, n, (float*)workspace);
   DMI_CHECK_LAUNCH("sumsq");
-  sum_f32_kernel<<<dim3(1), dim3(256), 0, st>>>((const float*)workspace, SUMSQ_BLOCKS, 1.0f, out);
+  sum_f32_kernel<<<dim3(1), dim3(1024), 0, st>>>((const float*)workspace, SUMSQ_BLOCKS, 1.0f, out);
   DMI_CHECK_LAUNCH("sumsq_finish");
   return DMI_OK;
 }

@@ -77,6 +77,7 @@ def _declare(L):
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P]),
         "dmi_cast_f32_bf16": (I, [P, P, L64, P]),
         "dmi_transpose_bf16_padded": (I, [P, P, I, I, I, P]),
+        "dmi_transpose_bf16_batch": (I, [P, P, P, I, L64, P]),
         "dmi_im2col": (I, [P, P, I, I, I, I, I, I, I, I, P, P, I, P]),
         "dmi_weight_gather": (I, [P, P, I, I, I, P, I, P]),
         "dmi_pixel_interleave": (I, [P, P, I, I, I, I, P]),
@@ -194,6 +195,12 @@ def colsum(Y, ldy, out, M, N, ws):
 def transpose(inp, out, batch, R, C):
     _dev(inp, out)
     _check(lib().dmi_transpose_bf16(_p(inp), _p(out), batch, R, C, _stream()), "transpose")
+
+
+def transpose_batch(in_base, out_base, table, n, total_tiles):
+    """table: int64 device tensor [n,5] = {in_off, out_off, R, C, first_tile}."""
+    _dev(in_base, out_base, table)
+    _check(lib().dmi_transpose_bf16_batch(_p(in_base), _p(out_base), _p(table), n, total_tiles, _stream()), "transpose_batch")
 
 
 def transpose_strided(inp_ptr, out, nb, nh, R, C, sb, sh, sr):

@@ -202,9 +202,15 @@ class DalleEngine:
         """bf16 natural copy (if not already written by the Adam kernel) + [out,in] copies for the fwd GEMMs."""
         if cast:
             dh.cast_f32_bf16(self.p, self.pb, self.lay.total)
-        for name in self.lay.t_offset:
-            r, c = self.lay.shape[name]
-            dh.transpose(self.view(self.pb, name), self.tview(name), 1, r, c)
+        if getattr(self, "_t_table", None) is None:   # one launch for all [in,out] -> [out,in] weight copies
+            rows, tile = [], 0
+            for name in self.lay.t_offset:
+                r, c = self.lay.shape[name]
+                rows.append([self.lay.offset[name], self.lay.t_offset[name], r, c, tile])
+                tile += ((r + 63) // 64) * ((c + 63) // 64)
+            self._t_table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._t_tiles = tile
+        dh.transpose_batch(self.pb, self.pbt, self._t_table, self._t_table.shape[0], self._t_tiles)
 
     # ------------------------------------------------------------------ buffers
     def _alloc_activations(self):

@@ -132,6 +132,13 @@ int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16
 /* fp32 -> bf16 cast (initial weight export) */
 int dmi_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 
+/* n independent [R,C] -> [C,R] bf16 transposes between two buffers in one launch: table[i] = {in_off, out_off, R, C,
+ * first_tile} (int64, elements / 64x64 tiles, first_tile ascending; R, C multiples of 8); total_tiles = sum of
+ * ceil(R/64)*ceil(C/64).  The per-step refresh of the forward GEMMs' [out,in] weight copies (replaces what mtf's
+ * einsum lowering does implicitly for y = x W, reference src/dalle_mtf/models.py:361-371). */
+int dmi_transpose_bf16_batch(const uint16_t* in_base, uint16_t* out_base, const int64_t* table, int n,
+                             int64_t total_tiles, void* stream);
+
 /* in [R_valid, C] -> out [C, R_pitch] with columns [R_valid, R_pitch) zero (K-padding of transposed conv kernels) */
 int dmi_transpose_bf16_padded(const uint16_t* in, uint16_t* out, int R_valid, int R_pitch, int C, void* stream);
 

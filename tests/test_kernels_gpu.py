@@ -289,6 +289,33 @@ def _attn_ref(qkv, B, H, S):
     return o.permute(0, 2, 1, 3).reshape(B * S, d), lse
 
 
+def test_transpose_batch_and_fast_sums():
+    """one-launch transposes of several ragged matrices living in one flat buffer (bit-exact), and the single-block
+    vectorised sum (fixed order) for aligned / unaligned / tail lengths."""
+    shapes = [(512, 1536), (72, 200), (8, 8), (2048, 512), (200, 72)]
+    src = rnd(sum(r * c for r, c in shapes), seed=21).to(DEV)
+    dst = torch.zeros_like(src)
+    rows, off, tile = [], 0, 0
+    for r, c in shapes:
+        rows.append([off, off, r, c, tile])
+        off += r * c
+        tile += ((r + 63) // 64) * ((c + 63) // 64)
+    table = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    dh.transpose_batch(src, dst, table, len(shapes), tile)
+    off = 0
+    for r, c in shapes:
+        want = src[off:off + r * c].view(r, c).t().contiguous().view(-1)
+        assert torch.equal(dst[off:off + r * c], want), (r, c)
+        off += r * c
+    for n in (1, 3, 4, 1000, 40960, 40963, 2048):
+        x = torch.randn(n + 1, generator=torch.Generator().manual_seed(n)).to(DEV)
+        out = torch.zeros(1, device=DEV)
+        for view in (x[:n], x[1:n + 1]):       # second view is only 4-byte aligned
+            dh.sum_f32(view, n, 0.5, out)
+            ref = float(view.double().sum()) * 0.5
+            assert abs(float(out) - ref) <= 1e-5 * max(1.0, abs(ref)) + 2e-4 * (n ** 0.5) * 1e-2, (n, float(out), ref)
+
+
 def _transposes(qkv, B, H, S):
     d = H * 128
     outs = []
