@@ -29,6 +29,11 @@ import torch
 
 CFG = dict(n_embd=512, n_layers=6, n_heads=4, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256,
            image_seq_len=1024)
+MODELS = {  # --model: the default is BASELINE.json's metric config; "1.3B" is SURVEY.md §8(d) C5 (secondary datapoint)
+    "dalle_example": CFG,
+    "1.3B": dict(n_embd=2048, n_layers=24, n_heads=16, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256,
+                 image_seq_len=1024),
+}
 HP = dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0)
 PER_GPU_BATCH = 32
 PEAK_BF16_TFLOPS = 2500.0
@@ -83,7 +88,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--model", default="dalle_example", choices=sorted(MODELS))
     args = ap.parse_args()
+    global CFG
+    CFG = MODELS[args.model]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,17 +165,17 @@ def main():
         achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
         traffic = None  # HBM bytes per launch of the same kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         tpath = os.path.join(ROOT, "profiles", "r01_traffic_vocab_gemm.json")
-        if os.path.exists(tpath) and B == PER_GPU_BATCH:
+        if os.path.exists(tpath) and B == PER_GPU_BATCH and args.model == "dalle_example":
             traffic = json.load(open(tpath)).get("traffic_bytes")
         out = {
-            "metric": "train tokens/sec (text+image) per node, dalle_example", "value": tokens_per_s, "unit": "tokens/s",
+            "metric": f"train tokens/sec (text+image) per node, {args.model}", "value": tokens_per_s, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs/dalle_example.json transformer train step (n_embd=512, 6 layers, 4 heads, "
-                                   "seq 256+1024, V=50771), synthetic captions + synthetic image-token ids",
+            "config": {"workload": f"configs/dalle_example.json transformer train step (n_embd={d}, {L} layers, "
+                                   f"{CFG['n_heads']} heads, seq 256+1024, V={V}), synthetic captions + synthetic image-token ids",
                        "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
                        "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (vocabulary projection M=B*S, N=50816, K=512)",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel (vocabulary projection M=B*S, N=50816, K={d})",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": traffic,
                          "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_vocab_gemm.json; algorithmic 4.26e9)",
@@ -175,7 +183,7 @@ def main():
                          "step_mfma_frac": train_flops_step_gpu / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "step_tflops_per_gpu": train_flops_step_gpu / (ms * 1e-3) / 1e12},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "dalle_example":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

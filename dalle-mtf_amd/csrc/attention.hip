@@ -129,13 +129,26 @@ __device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave
 // Forward v2: K and V NATURAL tiles (64 keys x 256 B each) stream by LDS-DMA into a 2-stage ring (one barrier per
 // 64-key step, loads of step j+1 in flight during the MFMAs of step j).  S^T = K Q^T reads K rows with ds_read_b128;
 // O^T += V^T P^T needs V^T fragments = hardware transpose reads of the same natural V tile (no transposed copy of V).
+extern int g_opt_attn_xcd;
+// (tile, batch*head) of this block.  With remap, hardware block b (dispatched to XCD b % 8) takes the b-th entry of a
+// per-XCD contiguous range, so the tiles of one (batch, head) share that XCD's L2 copy of K/V/Q/dO.
+__device__ __forceinline__ void attn_block(int remap, int& tile, int& bh) {
+  if (!remap) { tile = blockIdx.x; bh = blockIdx.y; return; }
+  const int n = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
+  const int xcd = L & 7, idx = L >> 3, q = n >> 3, r = n & 7;
+  const int P = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  tile = P % gridDim.x;
+  bh = P / gridDim.x;
+}
 #define QK_STAGE 32768  // K 16384 | V 16384
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                          float* __restrict__ lse, int B, int H, int S) {
+                                                          float* __restrict__ lse, int B, int H, int S, int remap) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
-  const int qt = gridDim.x - 1 - blockIdx.x;  // heaviest (latest) query tiles first
-  const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+  int tile_, bh;
+  attn_block(remap, tile_, bh);
+  const int qt = gridDim.x - 1 - tile_;  // heaviest (latest) query tiles first
+  const int b = bh / H, hh = bh % H;
   const int q0 = qt * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -301,7 +314,7 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_fwd: sequence too long for 32-bit buffer offsets");
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE); attr_done = true; }
-  attn_fwd_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S);
+  attn_fwd_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_fwd");
   return DMI_OK;
 }
@@ -343,11 +356,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // ds_read_b128; dQ^T += K^T dS^T takes K^T fragments from the SAME K tile with hardware transpose reads.
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             bf16_t* __restrict__ dqkv, int B, int H, int S) {
+                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
-  const int qt = gridDim.x - 1 - blockIdx.x;
-  const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+  int tile_, bh;
+  attn_block(remap, tile_, bh);
+  const int qt = gridDim.x - 1 - tile_;
+  const int b = bh / H, hh = bh % H;
   const int q0 = qt * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -495,11 +510,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #define DKV_NSTAGE 4
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                               const float* __restrict__ stats /* [B,H,S,2] (lse, delta) */,
-                                                              bf16_t* __restrict__ dqkv, int B, int H, int S) {
+                                                              bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
   const int d = H * HD, ld3 = 3 * d;
-  const int ktile = blockIdx.x;
-  const int bh = blockIdx.y, b = bh / H, hh = bh % H;
+  int ktile, bh;
+  attn_block(remap, ktile, bh);
+  const int b = bh / H, hh = bh % H;
   const int key0 = ktile * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -704,9 +720,9 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const 
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     attr_done = true;
   }
-  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, d_o, lse, delta, dqkv, B, H, S);
+  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, d_o, lse, delta, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dq");
-  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S);
+  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
 }

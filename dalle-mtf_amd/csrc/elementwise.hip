@@ -288,19 +288,39 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     if (c < nch) unpack8(*(const u32x4*)(g + c * 8), fg[i]);
   }
   const int64_t r0 = (int64_t)blockIdx.x * LN_BWD_RPB;
+  // software pipeline over this wave's rows: the raw loads of row it+1 are issued before the reductions of row it
+  u32x4 rdy[NC], rx[NC], rr[NC];
+  float mu_n = 0.f, rs_n = 0.f;
+  auto fetch = [&](int64_t row) {
+    if (row < rows) {
+      mu_n = mean[row];
+      rs_n = rstd[row];
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          rdy[i] = *(const u32x4*)(dy + row * d + c * 8);
+          rx[i] = *(const u32x4*)(x + row * d + c * 8);
+          if (dres) rr[i] = *(const u32x4*)(dres + row * d + c * 8);
+        }
+      }
+    }
+  };
+  fetch(r0 + wid);
   for (int it = 0; it < LN_BWD_RPB / 4; ++it) {
     const int64_t row = r0 + wid + 4 * it;
     if (row >= rows) break;
-    const float mu = mean[row], rs = rstd[row];
-    float fy[NC][8], xh[NC][8];
+    const float mu = mu_n, rs = rs_n;
+    float fy[NC][8], xh[NC][8], fr[NC][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NC; ++i) {
       const int c = lane + 64 * i;
       if (c < nch) {
         float fx[8];
-        unpack8(*(const u32x4*)(dy + row * d + c * 8), fy[i]);
-        unpack8(*(const u32x4*)(x + row * d + c * 8), fx);
+        unpack8(rdy[i], fy[i]);
+        unpack8(rx[i], fx);
+        if (dres) unpack8(rr[i], fr[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           xh[i][j] = (fx[j] - mu) * rs;
@@ -312,6 +332,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         }
       }
     }
+    if (it + 1 < LN_BWD_RPB / 4) fetch(row + 4);
     s1 = wave_sum(s1) / (float)d;
     s2 = wave_sum(s2) / (float)d;
 #pragma unroll
@@ -322,10 +343,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rs * (fy[i][j] - s1 - xh[i][j] * s2);
         if (dres) {
-          float fr[8];
-          unpack8(*(const u32x4*)(dres + row * d + c * 8), fr);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] += fr[j];
+          for (int j = 0; j < 8; ++j) o[j] += fr[i][j];
         }
         *(u32x4*)(dx + row * d + c * 8) = pack8(o);
       }

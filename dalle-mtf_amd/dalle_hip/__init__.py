@@ -14,7 +14,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdalle_hip.so")
+LIB_PATH = os.environ.get("DALLE_HIP_LIB") or os.path.join(_HERE, "libdalle_hip.so")  # override: A/B of two builds
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "dalle_hip.h")
 
 GEMM_BIAS, GEMM_RELU, GEMM_RESIDUAL, GEMM_RELU_MASK, GEMM_OUT_F32 = 1, 2, 4, 8, 16

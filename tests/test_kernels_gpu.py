@@ -326,8 +326,19 @@ def _transposes(qkv, B, H, S):
     return outs
 
 
-@pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 2, 384), (1, 1, 72)])
-def test_attention_fwd_bwd(B, H, S):
+@pytest.mark.parametrize("xcd", [1, 0])
+@pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 2, 384), (1, 1, 72), (3, 1, 384), (5, 2, 200)])
+def test_attention_fwd_bwd(B, H, S, xcd):
+    """xcd = 1: blocks of one (batch, head) are mapped to one XCD (default); 0: plain grid order.  Grids of 9 and 20
+    blocks exercise the uneven per-XCD ranges of the remap."""
+    dh.set_option("attn_xcd", xcd)
+    try:
+        _attention_fwd_bwd(B, H, S)
+    finally:
+        dh.set_option("attn_xcd", 1)
+
+
+def _attention_fwd_bwd(B, H, S):
     d = H * 128
     # q small (the reference folds 1/sqrt(k) into Wq's init), k/v O(1): logits O(1)
     g = torch.Generator().manual_seed(S)

@@ -1,0 +1,25 @@
+"""attention fwd / bwd timing with the XCD-aware block mapping on and off (alternating, same buffers)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "dalle-mtf_amd"))
+import torch, dalle_hip as dh
+from kbench import timeit, rb
+B, H, S = 32, 4, 1280
+d = H * 128
+qkv = rb(B * S, 3 * d, scale=0.3)
+o = torch.empty(B * S, d, dtype=torch.bfloat16, device="cuda")
+lse = torch.empty(B, H, S, dtype=torch.float32, device="cuda")
+d_o = rb(B * S, d)
+delta = torch.empty(3, B, H, S, dtype=torch.float32, device="cuda")
+dqkv = torch.empty(B * S, 3 * d, dtype=torch.bfloat16, device="cuda")
+ref = {}
+for rep in range(3):
+    for x in (0, 1):
+        dh.set_option("attn_xcd", x)
+        tf = timeit(lambda: dh.attention_fwd(qkv, None, o, lse, B, H, S))
+        tb = timeit(lambda: dh.attention_bwd(qkv, None, None, o, d_o, None, lse, delta, dqkv, B, H, S))
+        print(f"attn_xcd={x}: fwd {tf*1e6:7.1f} us  bwd {tb*1e6:7.1f} us", flush=True)
+        key = (o.float().sum().item(), dqkv.float().abs().sum().item())
+        ref.setdefault("k", key)
+        assert key == ref["k"], (key, ref["k"])
+dh.set_option("attn_xcd", 1)
