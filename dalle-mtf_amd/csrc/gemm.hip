@@ -27,7 +27,8 @@ static int g_opt_prio = 0;
 static int g_opt_nt4 = 1;
 static int g_opt_nt5 = 0;  // hand-scheduled 3-stage kernel (0 off, 2 = 256x128 tiles, 3 = 128x128 tiles): bit-identical, measured equal
                            // to v2/v4 within noise on every shape of the model (tools/ksweep.py) -- kept as a tested option
-int g_opt_attn_xcd = 1;  // attention kernels: all tiles of one (batch, head) on one XCD (shared K/V in that XCD's L2)
+int g_opt_dkv8 = 0;      // attention dK/dV: 8-wave block (two query-tile groups, 2 waves/SIMD)
+int g_opt_attn_xcd = 8;  // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_nt3 = 0;  // persistent variant: bit-identical, measured 5-12 % slower than per-tile launches (kept as a tested option)
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
@@ -38,6 +39,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt3")) return g_opt_nt3;
   if (!strcmp(name, "nt5")) return g_opt_nt5;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
+  if (!strcmp(name, "dkv8")) return g_opt_dkv8;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
@@ -49,6 +51,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt3")) { g_opt_nt3 = value; return 0; }
   if (!strcmp(name, "nt5")) { g_opt_nt5 = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
+  if (!strcmp(name, "dkv8")) { g_opt_dkv8 = value; return 0; }
   return -1;
 }
 
