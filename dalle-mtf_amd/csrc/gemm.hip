@@ -29,6 +29,7 @@ static int g_opt_nt5 = 0;  // hand-scheduled 3-stage kernel (0 off, 2 = 256x128 
                            // to v2/v4 within noise on every shape of the model (tools/ksweep.py) -- kept as a tested option
 int g_opt_dkv8 = 0;      // attention dK/dV: 8-wave block (two query-tile groups, 2 waves/SIMD)
 int g_opt_attn_xcd = 8;  // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
+static int g_opt_tn_streamk = 1;  // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static int g_opt_nt3 = 0;  // persistent variant: bit-identical, measured 5-12 % slower than per-tile launches (kept as a tested option)
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
@@ -38,6 +39,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt3")) return g_opt_nt3;
   if (!strcmp(name, "nt5")) return g_opt_nt5;
+  if (!strcmp(name, "tn_streamk")) return g_opt_tn_streamk;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
   if (!strcmp(name, "dkv8")) return g_opt_dkv8;
   return -1;
@@ -50,6 +52,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt3")) { g_opt_nt3 = value; return 0; }
   if (!strcmp(name, "nt5")) { g_opt_nt5 = value; return 0; }
+  if (!strcmp(name, "tn_streamk")) { g_opt_tn_streamk = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
   if (!strcmp(name, "dkv8")) { g_opt_dkv8 = value; return 0; }
   return -1;
@@ -1126,7 +1129,11 @@ extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   const int64_t Mp = round_up64(M, 64);
   const int64_t tr = ((int64_t)I * Mp + (int64_t)J * Mp) * 2;  // fallback: transposed operand copies
   const int64_t cs = ((int64_t)(M + 255) / 256) * J * 4 + (int64_t)s * J * 4;  // column-sum partials (bias gradient)
-  return round_up64(slabs, 256) + round_up64(tr, 256) + round_up64(cs, 256) + 256;
+  // unsplit shapes with a ragged last residency: row-split slabs of the tail stripe, < 512 tiles x 64 KiB (+ bias rows)
+  const int64_t tiles = (int64_t)((I + 127) / 128) * ((J + 127) / 128);
+  const int64_t tail = (s == 1 && tiles > 512) ? (512 * 65536 + 512 * 128 * 4 * (int64_t)((I + 127) / 128)) : 0;
+  const int64_t base = round_up64(slabs, 256) + round_up64(tr, 256) + round_up64(cs, 256) + 256;
+  return base > tail + 256 ? base : tail + 256;
 }
 
 struct TnArgs {
@@ -1187,19 +1194,16 @@ __device__ __forceinline__ bf16x8 tr_cat(u32x2 a, u32x2 b) {
 // row&3 is a per-lane constant of the fragment read ((l16>>2)), so the swizzle folds into 2 hoisted offsets.
 // Bias gradients (column sums of dY): blocks of the first row-tile issue one extra MFMA per k-step with an
 // all-ones A operand (D[i][j] = sum_k Y[k][j]).
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_tn[];  // [2 stages][X 16K | Y 16K]
+// One (tile, row-range) unit of work: C[i0.., j0..] (row pitch ldc) = X[mb..mb+rows, i0..]^T dY[mb..mb+rows, j0..];
+// bias_out[j0..] = column sums of that dY range (blocks of the first row-tile only).
+__device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, int tj, int mb, int rows, float* C,
+                                        int64_t ldc, float* bias_out) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wid >> 1, wj = wid & 1;
   const int h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
 
-  int ti, tj;
-  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_i, a.tiles_j, ti, tj);
   const int i0 = ti * 128, j0 = tj * 128;
-  const int mb = blockIdx.y * a.m_per_split;
-  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
-  const int rows = me > mb ? me - mb : 0;
   const int nt = (rows + TN_BKM - 1) / TN_BKM;
 
   const int wx = (a.I - i0 < 128) ? a.I - i0 : 128, wy = (a.J - j0 < 128) ? a.J - j0 : 128;
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   f32x16 bacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
-  const bool do_bias = (a.bias_part != nullptr) && (ti == 0);
+  const bool do_bias = (bias_out != nullptr) && (ti == 0);
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
@@ -1304,7 +1308,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
     }
   }
   // store: reg e -> row i = (e&3) + 8*(e>>2) + 4h ; col j = lane&31
-  float* C = a.C + (int64_t)blockIdx.y * a.slab_stride;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1314,12 +1317,61 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = i0 + wi * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row < a.I) C[(int64_t)row * a.J + col] = acc[i][j][e];
+        if (row < a.I) C[(int64_t)row * ldc + col] = acc[i][j][e];
       }
     }
   if (do_bias && h == 0) {  // row 0 of D (reg 0 of the lower half-wave) holds the column sums
     const int col = j0 + wj * 64 + wi * 32 + (lane & 31);
-    if (col < a.J) a.bias_part[(int64_t)blockIdx.y * a.J + col] = bacc[0];
+    if (col < a.J) bias_out[col] = bacc[0];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];  // [2 stages][X 16K | Y 16K]
+  int ti, tj;
+  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = blockIdx.y * a.m_per_split;
+  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  const int rows = me > mb ? me - mb : 0;
+  tn_tile(a, smem_tn, ti, tj, mb, rows, a.C + (int64_t)blockIdx.y * a.slab_stride, a.J,
+          a.bias_part ? a.bias_part + (int64_t)blockIdx.y * a.J : nullptr);
+}
+
+// Unsplit shapes whose tile count is not a multiple of the 512 resident blocks (the head: 4 x 397 = 1588 tiles = 3.1
+// residencies of ~0.85 ms blocks -> the last 52 blocks ran alone for ~20 % of the kernel, MFMA pipe 37 % busy, PMC
+// profiles/pmc/r01g_tn_*).  The first n_whole = 512 * floor(tiles / 512) tiles run as before; each remaining tile is cut
+// into S row ranges that write fp32 slabs of the tail's column range [c0, c0 + W) (tiles are numbered ti-fastest, so
+// the tail is a column stripe of dW), reduced afterwards in fixed order -- deterministic, no atomics.  (A stream-K cut
+// of the whole (tile, step) space was measured 35 % SLOWER: a block then walks the four row-tiles of one dY column
+// stripe one after another and re-streams the stripe from HBM each time instead of sharing it through L2.)
+__global__ __launch_bounds__(256, 2) void gemm_tn_tail_kernel(TnArgs a, int n_whole, int S, int m_per_split, float* tail_slabs,
+                                                              float* tail_bias, int c0, int W) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
+  int ti, tj;
+  if ((int)blockIdx.x < n_whole) {
+    tile_of_block(xcd_remap(blockIdx.x, n_whole), a.tiles_i, a.tiles_j, ti, tj);
+    tn_tile(a, smem_tn, ti, tj, 0, a.M, a.C, a.J, a.bias_part);
+    return;
+  }
+  const int r = blockIdx.x - n_whole, sp = r % S;
+  tile_of_block(n_whole + r / S, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = sp * m_per_split;
+  const int me = (mb + m_per_split < a.M) ? mb + m_per_split : a.M;
+  tn_tile(a, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, tail_slabs + (int64_t)sp * a.I * W - c0, W,
+          a.bias_part ? tail_bias + (int64_t)sp * W - c0 : nullptr);
+}
+// out[r * ldo + c] = sum_s slabs[(s * R + r) * W + c]   (W % 4 == 0, fixed order)
+__global__ __launch_bounds__(256) void reduce_slabs_2d_kernel(const float* __restrict__ slabs, float* __restrict__ out, int S,
+                                                              int R, int W, int64_t ldo) {
+  const int64_t n4 = (int64_t)R * W / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int r = (int)(i / (W / 4)), c = (int)(i % (W / 4)) * 4;
+    f32x4 acc = *(const f32x4*)(slabs + (int64_t)r * W + c);
+    for (int s = 1; s < S; ++s) {
+      const f32x4 v = *(const f32x4*)(slabs + ((int64_t)s * R + r) * W + c);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    *(f32x4*)(out + (int64_t)r * ldo + c) = acc;
   }
 }
 
@@ -1353,7 +1405,29 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     static bool attr_done = false;
     const int shm = 65536;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
-    gemm_tn_kernel<<<dim3(a.tiles_i * a.tiles_j, nsplit), dim3(256), shm, st>>>(a);
+    const int tiles = a.tiles_i * a.tiles_j;
+    const int nt_tile = (M + TN_BKM - 1) / TN_BKM;
+    const int tail_tiles = tiles % 512, n_whole = tiles - tail_tiles;
+    const int S = tail_tiles ? 512 / tail_tiles : 1;
+    // tiles are numbered ti-fastest: with tiles_i | n_whole the tail is the column stripe [c0, J) of dW
+    if (g_opt_tn_streamk && nsplit == 1 && tiles > 512 && S >= 2 && a.tiles_i <= GROUP_M && n_whole % a.tiles_i == 0 && J % 4 == 0) {
+      static bool attr_sk = false;
+      if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_tn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_sk = true; }
+      const int c0 = (n_whole / a.tiles_i) * 128, W = J - c0;
+      const int mps = (int)round_up64((M + S - 1) / S, TN_BKM);
+      float* tslab = (float*)workspace;                       // [S][I][W]
+      float* tbias = tslab + (int64_t)S * I * W;              // [S][W]
+      gemm_tn_tail_kernel<<<dim3(n_whole + tail_tiles * S), dim3(256), shm, st>>>(a, n_whole, S, mps, tslab, tbias, c0, W);
+      DMI_CHECK_LAUNCH("gemm_tn_tail");
+      reduce_slabs_2d_kernel<<<dim3(512), dim3(256), 0, st>>>(tslab, dW + c0, S, I, W, J);
+      DMI_CHECK_LAUNCH("gemm_tn_tail_reduce");
+      if (dbias) {
+        reduce_slabs_2d_kernel<<<dim3(8), dim3(256), 0, st>>>(tbias, dbias + c0, S, 1, W, J);
+        DMI_CHECK_LAUNCH("gemm_tn_tail_bias_reduce");
+      }
+    } else {
+      gemm_tn_kernel<<<dim3(tiles, nsplit), dim3(256), shm, st>>>(a);
+    }
     DMI_CHECK_LAUNCH("gemm_tn");
     if (dbias && nsplit > 1) {
       reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);

@@ -236,8 +236,11 @@ def test_gemm_nt_splitk(M, N, K, ns):
 
 
 @pytest.mark.parametrize("trread", [1, 0])
-@pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200)])
+@pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200),
+                                   (48, 128, 128), (100, 64, 72), (10000, 512, 512),
+                                   (200, 1024, 8320), (330, 640, 13320)])   # 520 / 525 tiles: the stream-K launch
 def test_gemm_tn(trread, M, I, J):
+    """trread 1: hardware-transpose-read kernel; 0: explicit transposes + NT fallback."""
     dh.set_option("tn_trread", trread)
     try:
         X, dY = rnd(M, I, seed=1), rnd(M, J, seed=2)

@@ -54,11 +54,11 @@ def bench_gemm_tn(M, I, J):
     dW = torch.empty(I, J, dtype=torch.float32, device=DEV)
     db = torch.empty(J, dtype=torch.float32, device=DEV)
     w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
-    for pr in (1, 0):
-        dh.set_option("prio", pr)
+    for v in (0, 1, 0, 1):
+        dh.set_option("tn_streamk", v)
         t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db))
-        print(f"gemm_tn M={M} I={I} J={J} prio={pr}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
-    dh.set_option("prio", 1)
+        print(f"gemm_tn M={M} I={I} J={J} streamk={v}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
+    dh.set_option("tn_streamk", 1)
 
 
 def bench_attention(B, H, S):
