@@ -30,6 +30,8 @@ static int g_opt_nt5 = 0;  // hand-scheduled 3-stage kernel (0 off, 2 = 256x128 
 int g_opt_dkv8 = 0;      // attention dK/dV: 8-wave block (two query-tile groups, 2 waves/SIMD)
 int g_opt_attn_xcd = 8;  // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn_streamk = 1;  // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
+static unsigned long long* g_dbg_buf = nullptr;
+extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
 static int g_opt_nt3 = 0;  // persistent variant: bit-identical, measured 5-12 % slower than per-tile launches (kept as a tested option)
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "glds")) return g_opt_glds;
@@ -74,6 +76,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int k_per_split;     // multiple of BK
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
+  unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
   int prio;             // raise wave priority around the MFMA clusters (co-resident blocks run at different phases)
 };
 
@@ -247,6 +250,75 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
 //    output row: full 128-B row segments instead of scattered 8-B pieces (the vocabulary projection was
 //    62 % store-wait with the direct epilogue).
 // =====================================================================================
+// bf16 epilogue shared by the v2 / v4 / v5 kernels: wave-private fp32 staging (32 rows x 64 cols, pitch 272 B) so that
+// every lane stores 16 B of one output row (full 128-B segments), with fused bias / ReLU / residual / ReLU-mask.
+// A per-block timeline (tools/phases.py) showed the epilogue taking 39 % of a block's life on the K = 512 shapes: the
+// bias vector was re-loaded (a dependent ~600-cycle L2 round trip) in each of the 16 store iterations.  Here the bias is
+// loaded once per tile and the residual / ReLU-source rows of a 32-row group are requested before that group's LDS
+// round trip, so no store iteration waits on a global load it has just issued.
+template <int FLAGS, int MI>
+__device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[MI][2], float* stg, int lane, int mrow0, int ncol0) {
+  const int r = lane & 31, h = lane >> 5;
+  const int orow = lane >> 3, ocol = (lane & 7) * 8;
+  const int n = ncol0 + ocol;
+  const bool nok = n < a.N;
+  float bias[8];
+  if constexpr (FLAGS & DMI_GEMM_BIAS) {
+    u32x4 braw = {0, 0, 0, 0};
+    if (nok) braw = *(const u32x4*)(a.bias + n);
+    unpack8(braw, bias);
+  }
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    u32x4 rres[4], rsrc[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = mrow0 + i * 32 + it * 8 + orow;
+      const int64_t off = (int64_t)m * a.ldc + n;
+      const bool ok = nok && m < a.M;
+      if constexpr (FLAGS & DMI_GEMM_RESIDUAL) rres[it] = ok ? *(const u32x4*)(a.residual + off) : u32x4{0, 0, 0, 0};
+      if constexpr (FLAGS & DMI_GEMM_RELU_MASK) rsrc[it] = ok ? *(const u32x4*)(a.relu_src + off) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
+            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = it * 8 + orow;
+      const int m = mrow0 + i * 32 + row;
+      const f32x4 lo = *(const f32x4*)(stg + row * 68 + ocol);
+      const f32x4 hi = *(const f32x4*)(stg + row * 68 + ocol + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      if constexpr (FLAGS & DMI_GEMM_BIAS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      }
+      if constexpr (FLAGS & DMI_GEMM_RELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
+        float b[8];
+        unpack8(rres[it], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b[e];
+      }
+      if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+        float b[8];
+        unpack8(rsrc[it], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
+      }
+      if (nok && m < a.M) *(u32x4*)((bf16_t*)a.C + (int64_t)m * a.ldc + n) = pack8(v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
@@ -363,55 +435,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
         }
     }
   } else {
-    // wave-private fp32 staging: 32 rows x 64 cols, pitch 272 B (16-B aligned rows)
-    float* st = (float*)(smem + wid * 8704);
-    const int orow = lane >> 3, ocol = (lane & 7) * 8;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *(f32x4*)(st + r * 68 + j * 32 + 8 * q + 4 * h) =
-              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + orow;
-        const int m = m0 + wm * 64 + i * 32 + row;
-        const int n = n0 + wn * 64 + ocol;
-        const f32x4 lo = *(const f32x4*)(st + row * 68 + ocol);
-        const f32x4 hi = *(const f32x4*)(st + row * 68 + ocol + 4);
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (m < a.M && n < a.N) {
-          const int64_t off = (int64_t)m * a.ldc + n;
-          if constexpr (FLAGS & DMI_GEMM_BIAS) {
-            float b[8];
-            unpack8(*(const u32x4*)(a.bias + n), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += b[e];
-          }
-          if constexpr (FLAGS & DMI_GEMM_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
-            float b[8];
-            unpack8(*(const u32x4*)(a.residual + off), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += b[e];
-          }
-          if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
-            float b[8];
-            unpack8(*(const u32x4*)(a.relu_src + off), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
-          }
-          *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    epilogue_bf16<FLAGS, 2>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 64, n0 + wn * 64);
   }
 }
 
@@ -676,9 +700,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
     }
   };
 
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (a.dbg) t0 = __builtin_readcyclecounter();
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (a.dbg) t1 = __builtin_readcyclecounter();
   for (int t = 0; t < nt; t += 2) {
     stage(1, (t + 1) * BK4 * 2);
     compute(0);
@@ -689,55 +716,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  if (a.dbg) t2 = __builtin_readcyclecounter();
 
-  // epilogue: wave-private fp32 staging, 32 rows x 64 cols at a time (pitch 272 B), full-row 16-B stores
-  float* stg = (float*)(smem + wid * 8704);
-  const int orow = lane >> 3, ocol = (lane & 7) * 8;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
-            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + orow;
-      const int m = m0 + wm * 128 + i * 32 + row;
-      const int n = n0 + wn * 64 + ocol;
-      const f32x4 lo = *(const f32x4*)(stg + row * 68 + ocol);
-      const f32x4 hi = *(const f32x4*)(stg + row * 68 + ocol + 4);
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if (m < a.M && n < a.N) {
-        const int64_t off = (int64_t)m * a.ldc + n;
-        if constexpr (FLAGS & DMI_GEMM_BIAS) {
-          float b[8];
-          unpack8(*(const u32x4*)(a.bias + n), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
-        }
-        if constexpr (FLAGS & DMI_GEMM_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
-          float b[8];
-          unpack8(*(const u32x4*)(a.residual + off), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
-        }
-        if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
-          float b[8];
-          unpack8(*(const u32x4*)(a.relu_src + off), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
-        }
-        *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  epilogue_bf16<FLAGS, 4>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 128, n0 + wn * 64);
+  if (a.dbg && tid == 0) {  // {start, after prologue, after main loop, end, hw id} of this block
+    const unsigned long long t3 = __builtin_readcyclecounter();  // stores issued, not necessarily retired
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned long long* d = a.dbg + (size_t)blockIdx.x * 5;
+    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = hwid;
   }
 }
 
@@ -904,56 +891,8 @@ __global__ __launch_bounds__(256, (MI == 4 ? 2 : 3)) void gemm_nt5_kernel(GemmAr
   }
 #undef NT5_STEP
 
-  // epilogue (all fragment reads were completed before the last barrier): wave-private fp32 staging, 32 rows x 64
-  // cols at a time (pitch 272 B), full-row 16-B stores
-  float* stg = (float*)(smem + wid * 8704);
-  const int orow = lane >> 3, ocol = (lane & 7) * 8;
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
-            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int row = it * 8 + orow;
-      const int m = m0 + wm * (32 * MI) + i * 32 + row;
-      const int n = n0 + wn * 64 + ocol;
-      const f32x4 lo = *(const f32x4*)(stg + row * 68 + ocol);
-      const f32x4 hi = *(const f32x4*)(stg + row * 68 + ocol + 4);
-      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if (m < a.M && n < a.N) {
-        const int64_t off = (int64_t)m * a.ldc + n;
-        if constexpr (FLAGS & DMI_GEMM_BIAS) {
-          float b[8];
-          unpack8(*(const u32x4*)(a.bias + n), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
-        }
-        if constexpr (FLAGS & DMI_GEMM_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
-          float b[8];
-          unpack8(*(const u32x4*)(a.residual + off), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += b[e];
-        }
-        if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
-          float b[8];
-          unpack8(*(const u32x4*)(a.relu_src + off), b);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
-        }
-        *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  // epilogue (all fragment reads were completed before the last barrier)
+  epilogue_bf16<FLAGS, MI>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * (32 * MI), n0 + wn * 64);
 }
 
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
@@ -1045,7 +984,7 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
   a.A = A; a.B = Bt; a.C = C; a.bias = bias; a.residual = residual; a.relu_src = relu_src;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-  a.k_per_split = K; a.slab_stride = 0; a.prio = g_opt_prio;
+  a.k_per_split = K; a.slab_stride = 0; a.prio = g_opt_prio; a.dbg = g_dbg_buf;
   hipStream_t st = (hipStream_t)stream;
   switch (flags) {
     case 0: return launch_nt<0>(a, 1, st);
@@ -1090,7 +1029,7 @@ extern "C" int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N;
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.k_per_split = (int)((((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK);
-  a.slab_stride = (int64_t)M * N; a.prio = g_opt_prio;
+  a.slab_stride = (int64_t)M * N; a.prio = g_opt_prio; a.dbg = nullptr;
   const int ns = (K + a.k_per_split - 1) / a.k_per_split;
   hipStream_t st = (hipStream_t)stream;
   rc = launch_nt<DMI_GEMM_OUT_F32>(a, ns, st);
@@ -1449,7 +1388,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     g.k_per_split = (int)round_up64((Mp + nsplit - 1) / nsplit, BK);
     g.C = (nsplit > 1) ? (void*)slabs : (void*)dW;
     g.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-    g.prio = g_opt_prio;
+    g.prio = g_opt_prio; g.dbg = nullptr;
     const int ns = (Mp + g.k_per_split - 1) / g.k_per_split;
     rc = launch_nt<DMI_GEMM_OUT_F32>(g, ns, st);
     if (rc) return rc;

@@ -197,6 +197,13 @@ def transpose(inp, out, batch, R, C):
     _check(lib().dmi_transpose_bf16(_p(inp), _p(out), batch, R, C, _stream()), "transpose")
 
 
+def set_debug_buffer(t):
+    """tools only: u64 device tensor [blocks, 5] receiving per-block phase timestamps of the 256x128 NT kernel (None: off)."""
+    fn = lib().dmi_set_debug_buffer
+    fn.restype, fn.argtypes = c_int, [c_void_p]
+    fn(_p(t))
+
+
 def transpose_batch(in_base, out_base, table, n, total_tiles):
     """table: int64 device tensor [n,5] = {in_off, out_off, R, C, first_tile}."""
     _dev(in_base, out_base, table)
