@@ -1267,13 +1267,20 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_tn[];  // [2 stages][X 16K | Y 16K]
+  // 1-D grid of tiles x splits, split-major, cut into one contiguous range per XCD: an XCD then works on whole row
+  // ranges (splits), whose X / dY slabs are fetched over the fabric once and shared by all of that split's tiles through
+  // the XCD's L2.  (With the split on gridDim.y every XCD held 1/8 of the tiles of EVERY split: each X tile crossed the
+  // fabric once per column tile -- 756 MB instead of 210 MB for the 2048 x 512 gradient.)
+  const int tiles = a.tiles_i * a.tiles_j;
+  const int P = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = P / tiles;
   int ti, tj;
-  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_i, a.tiles_j, ti, tj);
-  const int mb = blockIdx.y * a.m_per_split;
+  tile_of_block(P - split * tiles, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = split * a.m_per_split;
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
   const int rows = me > mb ? me - mb : 0;
-  tn_tile(a, smem_tn, ti, tj, mb, rows, a.C + (int64_t)blockIdx.y * a.slab_stride, a.J,
-          a.bias_part ? a.bias_part + (int64_t)blockIdx.y * a.J : nullptr);
+  tn_tile(a, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
+          a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
 }
 
 // Unsplit shapes whose tile count is not a multiple of the 512 resident blocks (the head: 4 x 397 = 1588 tiles = 3.1
@@ -1365,7 +1372,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
         DMI_CHECK_LAUNCH("gemm_tn_tail_bias_reduce");
       }
     } else {
-      gemm_tn_kernel<<<dim3(tiles, nsplit), dim3(256), shm, st>>>(a);
+      gemm_tn_kernel<<<dim3(tiles * nsplit), dim3(256), shm, st>>>(a);
     }
     DMI_CHECK_LAUNCH("gemm_tn");
     if (dbias && nsplit > 1) {
@@ -1412,3 +1419,124 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   }
   return DMI_OK;
 }
+
+// ---- grouped weight gradients --------------------------------------------------------------------------------------
+// The four weight gradients of a transformer block are independent ~100 us launches of exactly one residency (512
+// blocks) each: PMC shows 1.6 of the 2 possible waves per SIMD resident on average (launch ramp + ragged finish) and a
+// slab reduce per launch.  Grouped, they are ONE launch of 4 x 512 blocks (each problem keeps its own tiling / row split /
+// slabs) whose ragged edges overlap, followed by ONE reduce launch.
+#define TN_GROUP_MAX 8
+struct TnGroup {
+  TnArgs p[TN_GROUP_MAX];
+  int first_block[TN_GROUP_MAX + 1];
+  int tiles[TN_GROUP_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
+  int k = 0;
+  while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
+  const TnArgs& a = g.p[k];
+  const int local = blockIdx.x - g.first_block[k];
+  const int tiles = g.tiles[k];
+  const int P = xcd_remap(local, g.first_block[k + 1] - g.first_block[k]);   // per-XCD contiguous ranges of whole splits
+  const int split = P / tiles;
+  int ti, tj;
+  tile_of_block(P - split * tiles, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = split * a.m_per_split;
+  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  tn_tile(a, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, a.C + (int64_t)split * a.slab_stride, a.J,
+          a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
+}
+struct ReduceGroup {
+  const float* slabs[2 * TN_GROUP_MAX];
+  float* out[2 * TN_GROUP_MAX];
+  int nsplit[2 * TN_GROUP_MAX];
+  int64_t n4[2 * TN_GROUP_MAX];      // float4 count of one slab
+  int first_block[2 * TN_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_grouped_kernel(ReduceGroup g) {
+  int k = 0;
+  while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
+  const int nb = g.first_block[k + 1] - g.first_block[k];
+  const f32x4* sl = (const f32x4*)g.slabs[k];
+  const int64_t n4 = g.n4[k];
+  for (int64_t i = (int64_t)(blockIdx.x - g.first_block[k]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+    f32x4 acc = sl[i];
+    for (int s2 = 1; s2 < g.nsplit[k]; ++s2) {
+      const f32x4 v = sl[(int64_t)s2 * n4 + i];
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    ((f32x4*)g.out[k])[i] = acc;
+  }
+}
+
+static int64_t tn_problem_ws(int M, int I, int J) {  // slabs + bias partials of ONE grouped problem
+  const int s = tn_splits(M, I, J);
+  return (s > 1) ? round_up64((int64_t)s * I * J * 4, 256) + round_up64((int64_t)s * J * 4, 256) : 0;
+}
+extern "C" int64_t dmi_gemm_tn_grouped_workspace_bytes(const dmi_tn_problem* probs, int n) {
+  int64_t tot = 256;
+  for (int k = 0; k < n; ++k) tot += tn_problem_ws(probs[k].M, probs[k].I, probs[k].J);
+  return tot;
+}
+extern "C" int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* workspace, void* stream) {
+  DMI_REQUIRE(probs && workspace && n > 0 && n <= TN_GROUP_MAX, "gemm_tn_grouped: need 1..%d problems", TN_GROUP_MAX);
+  DMI_REQUIRE(((uintptr_t)workspace & 15) == 0, "gemm_tn_grouped: 16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  TnGroup g;
+  ReduceGroup rg;
+  g.n = n;
+  rg.n = 0;
+  int nblk = 0, rblk = 0;
+  char* wsp = (char*)workspace;
+  for (int k = 0; k < n; ++k) {
+    const dmi_tn_problem& q = probs[k];
+    DMI_REQUIRE(q.X && q.dY && q.dW, "gemm_tn_grouped: null pointer in problem %d", k);
+    DMI_REQUIRE(q.M > 0 && q.I % 8 == 0 && q.J % 8 == 0 && q.ldx % 8 == 0 && q.ldy % 8 == 0 && q.ldx >= q.I && q.ldy >= q.J,
+                "gemm_tn_grouped: I, J, ldx, ldy must be multiples of 8 (problem %d)", k);
+    DMI_REQUIRE((((uintptr_t)q.X | (uintptr_t)q.dY | (uintptr_t)q.dW) & 15) == 0, "gemm_tn_grouped: 16-byte alignment required");
+    DMI_REQUIRE((int64_t)TN_BKM * (q.ldx > q.ldy ? q.ldx : q.ldy) * 2 < 0x7fffffff, "gemm_tn_grouped: leading dimension too large");
+    const int nsplit = tn_splits(q.M, q.I, q.J);
+    TnArgs& a = g.p[k];
+    a.X = q.X; a.Y = q.dY; a.M = q.M; a.I = q.I; a.J = q.J; a.ldx = q.ldx; a.ldy = q.ldy;
+    a.tiles_i = (q.I + 127) / 128; a.tiles_j = (q.J + 127) / 128;
+    a.m_per_split = (int)round_up64((q.M + nsplit - 1) / nsplit, TN_BKM);
+    a.prio = g_opt_prio;
+    const int64_t ij = (int64_t)q.I * q.J;
+    if (nsplit > 1) {
+      float* slabs = (float*)wsp;
+      float* bpart = (float*)(wsp + round_up64((int64_t)nsplit * ij * 4, 256));
+      wsp += tn_problem_ws(q.M, q.I, q.J);
+      a.C = slabs; a.slab_stride = ij; a.bias_part = q.dbias ? bpart : nullptr;
+      DMI_REQUIRE(ij % 4 == 0 && q.J % 4 == 0, "gemm_tn_grouped: sizes must be multiples of 4");
+      int b = (int)cdiv64(ij / 4, 256 * 4);
+      if (b > 512) b = 512;
+      rg.slabs[rg.n] = slabs; rg.out[rg.n] = q.dW; rg.nsplit[rg.n] = nsplit; rg.n4[rg.n] = ij / 4; rg.first_block[rg.n] = rblk;
+      rblk += b; ++rg.n;
+      if (q.dbias) {
+        rg.slabs[rg.n] = bpart; rg.out[rg.n] = q.dbias; rg.nsplit[rg.n] = nsplit; rg.n4[rg.n] = q.J / 4; rg.first_block[rg.n] = rblk;
+        rblk += 1; ++rg.n;
+      }
+    } else {
+      a.C = q.dW; a.slab_stride = 0; a.bias_part = q.dbias;
+    }
+    g.tiles[k] = a.tiles_i * a.tiles_j;
+    g.first_block[k] = nblk;
+    nblk += g.tiles[k] * nsplit;
+  }
+  g.first_block[n] = nblk;
+  rg.first_block[rg.n] = rblk;
+  static bool attr_done = false;
+  const int shm = 65536;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
+  gemm_tn_grouped_kernel<<<dim3(nblk), dim3(256), shm, st>>>(g);
+  DMI_CHECK_LAUNCH("gemm_tn_grouped");
+  if (rg.n > 0) {
+    reduce_slabs_grouped_kernel<<<dim3(rblk), dim3(256), 0, st>>>(rg);
+    DMI_CHECK_LAUNCH("gemm_tn_grouped_reduce");
+  }
+  return DMI_OK;
+}
+

@@ -62,6 +62,8 @@ def _declare(L):
         "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P]),
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
         "dmi_gemm_tn": (I, [P, I, P, I, P, P, I, I, I, P, P]),
+        "dmi_gemm_tn_grouped_workspace_bytes": (L64, [P, I]),
+        "dmi_gemm_tn_grouped": (I, [P, I, P, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
         "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
@@ -195,6 +197,32 @@ def colsum(Y, ldy, out, M, N, ws):
 def transpose(inp, out, batch, R, C):
     _dev(inp, out)
     _check(lib().dmi_transpose_bf16(_p(inp), _p(out), batch, R, C, _stream()), "transpose")
+
+
+class TnProblem(ctypes.Structure):
+    """dmi_tn_problem (include/dalle_hip.h)."""
+    _fields_ = [("X", c_void_p), ("ldx", c_int), ("dY", c_void_p), ("ldy", c_int), ("dW", c_void_p), ("dbias", c_void_p),
+                ("M", c_int), ("I", c_int), ("J", c_int)]
+
+
+def tn_problems(items):
+    """items: iterable of (X, ldx, dY, ldy, dW, M, I, J, dbias-or-None) device tensors -> ctypes array (host side)."""
+    items = list(items)
+    arr = (TnProblem * len(items))()
+    for k, (X, ldx, dY, ldy, dW, M, I_, J, dbias) in enumerate(items):
+        _dev(X, dY, dW, dbias)
+        arr[k] = TnProblem(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias) or None, M, I_, J)
+    return arr
+
+
+def gemm_tn_grouped_workspace_bytes(probs):
+    return int(lib().dmi_gemm_tn_grouped_workspace_bytes(ctypes.byref(probs), len(probs)))
+
+
+def gemm_tn_grouped(probs, ws):
+    """All weight gradients of `probs` (tn_problems(...)) in one launch + one reduce launch; bit-identical to gemm_tn."""
+    _dev(ws)
+    _check(lib().dmi_gemm_tn_grouped(ctypes.byref(probs), len(probs), _p(ws), _stream()), "gemm_tn_grouped")
 
 
 def set_debug_buffer(t):

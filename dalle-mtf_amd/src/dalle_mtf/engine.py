@@ -19,6 +19,7 @@ Activations needed by backward are kept in bf16 per layer (no recompute; 288 GB 
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -252,6 +253,7 @@ class DalleEngine:
         self.ws_side = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
         self.side = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and self.hp.get("wgrad_side_stream", False)) else None
         self._side_done = None
+        self._group, self._group_cache, self.ws_group = None, {}, None   # grouped weight gradients (hparams['grouped_wgrad'])
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -318,6 +320,9 @@ class DalleEngine:
         """dW = X^T dY (+ fused bias gradient) on the side stream, ordered after everything enqueued so far.
         `tag` names the gradient-activation buffer (dY) this launch reads; _wait_tag(tag) must precede its reuse."""
         if self.side is None:
+            if self._group is not None:   # inside a transformer block: deferred to one grouped launch (_flush_group)
+                self._group.append((X, ldx, dY, ldy, dW, M, I, J, dbias))
+                return
             dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws, dbias=dbias)
             return
         main = torch.cuda.current_stream()
@@ -331,6 +336,22 @@ class DalleEngine:
         self._side_done = done
         if tag is not None:
             self._ev[tag] = done
+
+    def _flush_group(self, key):
+        """One launch for the weight gradients collected since the group was opened.  Every operand they read (h, xn2, o,
+        xn1 and the gradient activations dxa, dh, dxb, dqkv) is still intact at the call site: just before the block's
+        last LayerNorm backward overwrites dxa.  The ctypes problem array is built once per block and reused."""
+        items, self._group = self._group, None
+        if not items:
+            return
+        cached = self._group_cache.get(key)
+        if cached is None:
+            probs = dh.tn_problems(items)
+            need = dh.gemm_tn_grouped_workspace_bytes(probs)
+            if self.ws_group is None or self.ws_group.numel() < need:
+                self.ws_group = torch.empty(need + 1024, dtype=torch.uint8, device=self.dev)
+            cached = self._group_cache[key] = probs
+        dh.gemm_tn_grouped(cached, self.ws_group)
 
     def _wait_tag(self, tag):
         ev = self._ev.pop(tag, None)
@@ -383,6 +404,8 @@ class DalleEngine:
         for bi, l in enumerate(reversed(range(L))):
             p = f"layer_{l}/"
             st = self.stats[l]
+            if self.side is None and self.hp.get("grouped_wgrad", os.environ.get("DALLE_GROUPED_WGRAD", "0") != "0"):
+                self._group = []
             # FFN
             self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
                         dbias=self._gv(p + "mlp/mlp_linear_2/bias"), tag="dxa")
@@ -405,6 +428,8 @@ class DalleEngine:
             self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, tag="dqkv")
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
             self._wait_tag("dxa")     # this layer's W2 gradient (issued at the top) read dxa
+            if self._group is not None:
+                self._flush_group(l)
             dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
                              self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"), ws, M, d)
             pending_bucket.append((1 + bi, self._side_done))

@@ -79,6 +79,18 @@ int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, 
 int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J);
 int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias, int M, int I, int J,
                 void* workspace, void* stream);
+/* Several independent weight gradients in ONE launch (+ one reduce launch): the four dW of a transformer block
+ * (mtf.gradients over the block's einsums, reference src/optimizers.py:34).  Same results, bit for bit, as n calls of
+ * dmi_gemm_tn.  probs is a HOST array (n <= 8); workspace >= dmi_gemm_tn_grouped_workspace_bytes(probs, n). */
+typedef struct dmi_tn_problem {
+  const uint16_t* X; int ldx;
+  const uint16_t* dY; int ldy;
+  float* dW; float* dbias;   /* dbias nullable */
+  int M, I, J;
+} dmi_tn_problem;
+int64_t dmi_gemm_tn_grouped_workspace_bytes(const dmi_tn_problem* probs, int n);
+int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* workspace, void* stream);
+
 /* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
 int64_t dmi_colsum_workspace_bytes(int64_t M, int N);
 int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int N, void* workspace, void* stream);

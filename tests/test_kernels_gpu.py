@@ -258,6 +258,31 @@ def test_gemm_tn(trread, M, I, J):
         dh.set_option("tn_trread", 1)
 
 
+def test_gemm_tn_grouped_is_bit_identical():
+    """four weight gradients of different shapes (split / unsplit, with and without bias) in one grouped launch ==
+    four dmi_gemm_tn calls, bit for bit; repeated launches reuse the same host problem array."""
+    M = 2000
+    shapes = [(256, 768, True), (256, 256, True), (1024, 256, False), (256, 1024, True), (64, 72, False)]
+    items, refs = [], []
+    for k, (I, J, wb) in enumerate(shapes):
+        X, dY = rnd(M, I, seed=10 + k).to(DEV), rnd(M, J, seed=20 + k).to(DEV)
+        dW = torch.full((I, J), 5.0, dtype=torch.float32, device=DEV)
+        db = torch.full((J,), 2.0, dtype=torch.float32, device=DEV) if wb else None
+        items.append((X, I, dY, J, dW, M, I, J, db))
+        rW, rb = torch.zeros_like(dW), (torch.zeros_like(db) if wb else None)
+        dh.gemm_tn(X, I, dY, J, rW, M, I, J, ws(dh.gemm_tn_workspace_bytes(M, I, J)), dbias=rb)
+        refs.append((rW, rb))
+    probs = dh.tn_problems(items)
+    w = ws(dh.gemm_tn_grouped_workspace_bytes(probs))
+    for _ in range(2):
+        dh.gemm_tn_grouped(probs, w)
+        for (X, I, dY, J, dW, M_, I_, J_, db), (rW, rb) in zip(items, refs):
+            assert torch.equal(dW, rW), (I, J)
+            if db is not None:
+                assert torch.equal(db, rb), (I, J)
+            close(dW, X.float().t() @ dY.float(), 2e-3, 2e-3 * math.sqrt(M), "grouped tn")
+
+
 def test_colsum_and_transpose():
     M, N = 1000, 520
     Y = rnd(M, N, seed=1)
