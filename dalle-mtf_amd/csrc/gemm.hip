@@ -1067,7 +1067,7 @@ extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   const int64_t slabs = (s > 1) ? (int64_t)s * I * J * 4 : 0;
   const int64_t Mp = round_up64(M, 64);
   const int64_t tr = ((int64_t)I * Mp + (int64_t)J * Mp) * 2;  // fallback: transposed operand copies
-  const int64_t cs = ((int64_t)(M + 255) / 256) * J * 4 + (int64_t)s * J * 4;  // column-sum partials (bias gradient)
+  const int64_t cs = ((int64_t)(M + 255) / 256) * J * 4 + (int64_t)s * ((I + 127) / 128) * J * 4;  // column-sum partials (bias gradient)
   // unsplit shapes with a ragged last residency: row-split slabs of the tail stripe, < 512 tiles x 64 KiB (+ bias rows)
   const int64_t tiles = (int64_t)((I + 127) / 128) * ((J + 127) / 128);
   const int64_t tail = (s == 1 && tiles > 512) ? (512 * 65536 + 512 * 128 * 4 * (int64_t)((I + 127) / 128)) : 0;
@@ -1085,6 +1085,8 @@ struct TnArgs {
   int m_per_split;  // multiple of TN_BKM
   int64_t slab_stride;
   int prio;
+  int bias_balanced;  // 1: every row-tile block sums the dY columns of the k-steps t == ti (mod tiles_i) into its own slot
+  unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
 };
 
 // Transposed fragment fetch through inline asm: hipcc orders the ds_read_tr16_b64 INTRINSIC behind every in-flight
@@ -1181,7 +1183,12 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
   f32x16 bacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
-  const bool do_bias = (bias_out != nullptr) && (ti == 0);
+  // Bias gradient = column sums of dY, one extra all-ones MFMA per k-substep.  Done only by the ti == 0 blocks it makes
+  // those blocks 25 % longer than their neighbours, and a launch of exactly one residency then waits for them (the 512 x
+  // 2048 gradient ran 125 us with the bias vs ~95 us without).  Balanced mode spreads the k-steps of a (split, tj) column
+  // over its tiles_i row-tile blocks; each writes its own partial row, summed by the slab reduce.
+  const bool do_bias = (bias_out != nullptr) && (a.bias_balanced || ti == 0);
+  const int bias_mod = a.bias_balanced ? a.tiles_i : 1, bias_rem = a.bias_balanced ? ti : 0;
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
@@ -1196,56 +1203,71 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
     }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
-  auto compute = [&](int st) {
+  auto compute = [&](int st, int step) {
     const unsigned base = lds0 + st * 32768;
     if (a.prio) __builtin_amdgcn_s_setprio(1);
-    TrFrag f[3];  // ring of 3 fragment sets: two k-steps of transposed reads in flight ahead of the MFMAs
-    tr_issue(f[0], base + ofx[0], base + ofx[1], base + ofy[0], base + ofy[1]);
-    tr_issue(f[1], base + 4096 + ofx[0], base + 4096 + ofx[1], base + 4096 + ofy[0], base + 4096 + ofy[1]);
+    TrFrag f[4];  // all four k-substeps of the stage, then k-innermost MFMA order: four back-to-back MFMAs per accumulator (source C
+                  // forwarded inside the matrix pipe instead of a register-file round trip each); measured +2-4 % here, while the same
+                  // order costs the NT kernels registers/occupancy and was measured neutral (128x128) or worse (256x128)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      TrFrag& c = f[kk % 3];
-      if (kk < 3) tr_wait8(c); else tr_wait(c);
-      if (kk + 2 < 4) {
-        const unsigned b2 = base + (kk + 2) * 4096;
-        tr_issue(f[(kk + 2) % 3], b2 + ofx[0], b2 + ofx[1], b2 + ofy[0], b2 + ofy[1]);
-      }
-      const bf16x8 fx0 = tr_cat(c.x0a, c.x0b), fx1 = tr_cat(c.x1a, c.x1b);
-      const bf16x8 fy0 = tr_cat(c.y0a, c.y0b), fy1 = tr_cat(c.y1a, c.y1b);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx0, fy0, acc[0][0], 0, 0, 0);  // D[i][j]
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx0, fy1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx1, fy0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fx1, fy1, acc[1][1], 0, 0, 0);
-      if (do_bias) {  // wave (wi,wj) sums columns wj*64 + wi*32 ..  (wave-uniform branches)
-        if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fy0, bacc, 0, 0, 0);
-        else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fy1, bacc, 0, 0, 0);
+      const unsigned b2 = base + kk * 4096;
+      tr_issue(f[kk], b2 + ofx[0], b2 + ofx[1], b2 + ofy[0], b2 + ofy[1]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) tr_wait(f[kk]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x0a, f[kk].x0b), tr_cat(f[kk].y0a, f[kk].y0b), acc[0][0], 0, 0, 0);  // D[i][j]
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x0a, f[kk].x0b), tr_cat(f[kk].y1a, f[kk].y1b), acc[0][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x1a, f[kk].x1b), tr_cat(f[kk].y0a, f[kk].y0b), acc[1][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x1a, f[kk].x1b), tr_cat(f[kk].y1a, f[kk].y1b), acc[1][1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_bias && (step % bias_mod) == bias_rem) {  // wave (wi,wj) sums columns wj*64 + wi*32 ..  (wave-uniform branches)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, tr_cat(f[kk].y0a, f[kk].y0b), bacc, 0, 0, 0);
+        else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, tr_cat(f[kk].y1a, f[kk].y1b), bacc, 0, 0, 0);
       }
     }
     if (a.prio) __builtin_amdgcn_s_setprio(0);
   };
 
+  unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, rq0 = 0;
+  if (a.dbg) { tq0 = __builtin_readcyclecounter(); rq0 = __builtin_amdgcn_s_memrealtime(); }
   if (nt > 0) {
     // stages addressed with compile-time constants (x2 unroll): otherwise the compiler cannot prove the in-flight
     // LDS-DMA does not alias the fragment reads and drains vmcnt(0) before them.
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (a.dbg) tq1 = __builtin_readcyclecounter();
     int t = 0;
     for (; t + 2 <= nt; t += 2) {
       stage(1);
-      compute(0);
+      compute(0, t);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t + 2 < nt) stage(0);
-      compute(1);
+      compute(1, t + 1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
     if (t < nt) {
-      compute(0);
+      compute(0, t);
       __syncthreads();
     }
   }
+  if (a.dbg) tq2 = __builtin_readcyclecounter();
   // store: reg e -> row i = (e&3) + 8*(e>>2) + 4h ; col j = lane&31
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -1263,6 +1285,11 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
     const int col = j0 + wj * 64 + wi * 32 + (lane & 31);
     if (col < a.J) bias_out[col] = bacc[0];
   }
+  if (a.dbg && tid == 0) {
+    unsigned long long* dq = a.dbg + (size_t)blockIdx.x * 8;   // 100 MHz realtime stamps calibrate the cycle counter
+    dq[0] = tq0; dq[1] = tq1; dq[2] = tq2; dq[3] = __builtin_readcyclecounter(); dq[4] = (unsigned long long)nt;
+    dq[5] = rq0; dq[6] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
@@ -1279,8 +1306,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   const int mb = split * a.m_per_split;
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
   const int rows = me > mb ? me - mb : 0;
+  const int64_t bslot = a.bias_balanced ? (int64_t)split * a.tiles_i + ti : split;
   tn_tile(a, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
-          a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
+          a.bias_part ? a.bias_part + bslot * a.J : nullptr);
 }
 
 // Unsplit shapes whose tile count is not a multiple of the 512 resident blocks (the head: 4 x 397 = 1588 tiles = 3.1
@@ -1343,7 +1371,8 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
     a.C = (nsplit > 1) ? slabs : dW;
     a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-    a.prio = g_opt_prio;
+    a.prio = g_opt_prio; a.dbg = g_dbg_buf;
+    a.bias_balanced = 0;  // balanced mode measured: 512x2048 gradient 123 -> 109 us but 2048x512 116 -> 122, 512x512 53 -> 72 us and the step slower
     // bias partials live behind the transposed-copy region of the workspace (unused in this mode)
     float* bpart = (float*)((char*)workspace + slab_bytes);
     a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
@@ -1376,7 +1405,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     }
     DMI_CHECK_LAUNCH("gemm_tn");
     if (dbias && nsplit > 1) {
-      reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);
+      reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, a.bias_balanced ? nsplit * a.tiles_i : nsplit, J / 4, J / 4);
       DMI_CHECK_LAUNCH("gemm_tn_bias_reduce");
     }
   } else {
@@ -1445,8 +1474,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
   tile_of_block(P - split * tiles, a.tiles_i, a.tiles_j, ti, tj);
   const int mb = split * a.m_per_split;
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  const int64_t bslot = a.bias_balanced ? (int64_t)split * a.tiles_i + ti : split;
   tn_tile(a, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, a.C + (int64_t)split * a.slab_stride, a.J,
-          a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
+          a.bias_part ? a.bias_part + bslot * a.J : nullptr);
 }
 struct ReduceGroup {
   const float* slabs[2 * TN_GROUP_MAX];
@@ -1474,7 +1504,7 @@ __global__ __launch_bounds__(256) void reduce_slabs_grouped_kernel(ReduceGroup g
 
 static int64_t tn_problem_ws(int M, int I, int J) {  // slabs + bias partials of ONE grouped problem
   const int s = tn_splits(M, I, J);
-  return (s > 1) ? round_up64((int64_t)s * I * J * 4, 256) + round_up64((int64_t)s * J * 4, 256) : 0;
+  return (s > 1) ? round_up64((int64_t)s * I * J * 4, 256) + round_up64((int64_t)s * ((I + 127) / 128) * J * 4, 256) : 0;
 }
 extern "C" int64_t dmi_gemm_tn_grouped_workspace_bytes(const dmi_tn_problem* probs, int n) {
   int64_t tot = 256;
@@ -1503,7 +1533,8 @@ extern "C" int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* wor
     a.X = q.X; a.Y = q.dY; a.M = q.M; a.I = q.I; a.J = q.J; a.ldx = q.ldx; a.ldy = q.ldy;
     a.tiles_i = (q.I + 127) / 128; a.tiles_j = (q.J + 127) / 128;
     a.m_per_split = (int)round_up64((q.M + nsplit - 1) / nsplit, TN_BKM);
-    a.prio = g_opt_prio;
+    a.prio = g_opt_prio; a.dbg = nullptr;
+    a.bias_balanced = 0;
     const int64_t ij = (int64_t)q.I * q.J;
     if (nsplit > 1) {
       float* slabs = (float*)wsp;
@@ -1516,7 +1547,7 @@ extern "C" int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* wor
       rg.slabs[rg.n] = slabs; rg.out[rg.n] = q.dW; rg.nsplit[rg.n] = nsplit; rg.n4[rg.n] = ij / 4; rg.first_block[rg.n] = rblk;
       rblk += b; ++rg.n;
       if (q.dbias) {
-        rg.slabs[rg.n] = bpart; rg.out[rg.n] = q.dbias; rg.nsplit[rg.n] = nsplit; rg.n4[rg.n] = q.J / 4; rg.first_block[rg.n] = rblk;
+        rg.slabs[rg.n] = bpart; rg.out[rg.n] = q.dbias; rg.nsplit[rg.n] = a.bias_balanced ? nsplit * a.tiles_i : nsplit; rg.n4[rg.n] = q.J / 4; rg.first_block[rg.n] = rblk;
         rblk += 1; ++rg.n;
       }
     } else {

@@ -42,3 +42,33 @@ for s_, lst in by.items():
     ends = sorted(t3[lst]); starts = sorted(t0[lst])
     life += (t3[lst] - t0[lst]).sum()
 print(f"distinct (xcd,cu) seen: {nslots}; mean co-resident blocks per CU = total block life / (CUs x span) = {life/(nslots*(t3.max()-t0.min())):.2f}")
+
+
+def tn_phases(I, J):
+    X, dY = rb(M, I), rb(M, J)
+    dW = torch.empty(I, J, dtype=torch.float32, device="cuda")
+    w = torch.empty(dh.gemm_tn_workspace_bytes(M, I, J) + 1024, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        dh.gemm_tn(X, I, dY, J, dW, M, I, J, w)
+    dbg = torch.zeros(8192, 8, dtype=torch.int64, device="cuda")
+    dh.set_debug_buffer(dbg)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    dh.gemm_tn(X, I, dY, J, dW, M, I, J, w)
+    e1.record()
+    torch.cuda.synchronize()
+    dh.set_debug_buffer(None)
+    d = dbg.cpu().numpy().astype(np.int64)
+    d = d[d[:, 3] != 0]
+    t0, t1, t2, t3, nt = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
+    ghz = np.median((t3 - t0) / np.maximum(d[:, 6] - d[:, 5], 1) * 0.1)
+    print(f"cycle counter runs at {ghz:.3f} ticks/ns (against the 100 MHz realtime counter)")
+    print(f"TN {I}x{J}: kernel+reduce {e0.elapsed_time(e1)*1e3:.1f} us, {len(d)} blocks, {int(np.median(nt))} steps/block")
+    for name, v in (("prologue", t1 - t0), ("main loop", t2 - t1), ("per step", (t2 - t1) / np.maximum(nt, 1)), ("epilogue", t3 - t2), ("block life", t3 - t0)):
+        print(f"  {name:10s}: mean {v.mean():9.0f}  p10 {np.percentile(v,10):9.0f}  p50 {np.percentile(v,50):9.0f}  p90 {np.percentile(v,90):9.0f} ticks")
+
+
+if len(sys.argv) > 3 and sys.argv[3] == "tn":
+    tn_phases(2048, 512)
+    tn_phases(512, 1536)
+    tn_phases(512, 512)

@@ -1,0 +1,65 @@
+"""Sustained-load clock / power probe: runs one kernel in a loop for ~6 s while sampling rocm-smi."""
+import sys, os, subprocess, threading, time, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "dalle-mtf_amd"))
+import torch, dalle_hip as dh
+from kbench import rb
+M = 40960
+
+
+def sample(out, stop):
+    while not stop.is_set():
+        try:
+            txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+            p = re.search(r"Power \(W\): ([\d.]+)", txt)
+            s = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", txt)
+            out.append((float(p.group(1)) if p else -1, int(s.group(1)) if s else -1))
+        except Exception as e:
+            out.append((-1, -1))
+        time.sleep(0.3)
+
+
+def run(name, fn, flops, secs=5.0):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    out, stop = [], threading.Event()
+    th = threading.Thread(target=sample, args=(out, stop)); th.start()
+    t0 = time.time(); n = 0
+    while time.time() - t0 < secs:
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize(); n += 50
+    dt = time.time() - t0
+    stop.set(); th.join()
+    out = [o for o in out[2:] if o[0] > 0]
+    pw = sum(o[0] for o in out) / max(len(out), 1); ck = sum(o[1] for o in out) / max(len(out), 1)
+    print(f"{name:34s}: {dt/n*1e6:8.1f} us  {flops/(dt/n)/1e12:7.1f} TF/s  power {pw:6.0f} W  sclk {ck:5.0f} MHz  ({len(out)} samples)", flush=True)
+
+
+def nt(N, K, **opts):
+    A, Bt = rb(M, K), rb(N, K, scale=0.05)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    def f():
+        for k, v in opts.items(): dh.set_option(k, v)
+        dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, 0)
+    return f, 2.0 * M * N * K
+
+
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which == "accfwd":
+    for rep in range(2):
+        f, fl = nt(2048, 2048, nt4=0, nt5=0, prio=0); run("nt2 kk-outer (default)", f, fl, secs=4.0)
+        f, fl = nt(2048, 2048, nt4=0, nt5=0, prio=2); run("nt2 kk-inner (same-acc chains)", f, fl, secs=4.0)
+    dh.set_option("prio", 0)
+    sys.exit(0)
+f, fl = nt(2048, 2048, nt4=0, nt5=0); run("nt2 128x128 N=2048 K=2048", f, fl)
+f, fl = nt(2048, 2048, nt4=2, nt5=0); run("nt4 256x128 N=2048 K=2048", f, fl)
+f, fl = nt(50816, 512, nt4=1, nt5=0); run("nt4 logits N=50816 K=512", f, fl)
+dh.set_option("nt4", 1)
+X, dY = rb(M, 2048), rb(M, 512)
+dW = torch.empty(2048, 512, dtype=torch.float32, device="cuda")
+w = torch.empty(dh.gemm_tn_workspace_bytes(M, 2048, 512) + 1024, dtype=torch.uint8, device="cuda")
+run("tn 2048x512", lambda: dh.gemm_tn(X, 2048, dY, 512, dW, M, 2048, 512, w), 2.0 * M * 2048 * 512)
+x = torch.randn(1 << 28, device="cuda")
+run("torch copy 1 GiB (HBM)", lambda: x.clone(), 0.0, secs=3.0)
