@@ -164,7 +164,7 @@ def main():
         k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
         achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
         traffic = None  # HBM bytes per launch of the same kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_vocab_gemm.json")
+        tpath = os.path.join(ROOT, "profiles", "r01h_traffic_vocab_gemm.json")
         if os.path.exists(tpath) and B == PER_GPU_BATCH and args.model == "dalle_example":
             traffic = json.load(open(tpath)).get("traffic_bytes")
         out = {
@@ -178,7 +178,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel (vocabulary projection M=B*S, N=50816, K={d})",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (PMC, profiles/r01_traffic_vocab_gemm.json; algorithmic 4.26e9)",
+                         "traffic_unit": "bytes/launch (PMC, profiles/r01h_traffic_vocab_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, L2-side counters incl. Infinity-Cache hits; algorithmic 4.26e9)",
                          "launch_ms": k_avg, "launches_timed": len(k_ms),
                          "step_mfma_frac": train_flops_step_gpu / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "step_tflops_per_gpu": train_flops_step_gpu / (ms * 1e-3) / 1e12},

@@ -55,7 +55,7 @@ def initialize_vae_weights(vae, checkpoint_path):
         vae.init_params()
         return
     sd = torch.load(checkpoint_path, map_location="cpu")
-    vae.load_reference_params(sd["vae_variables"])
+    vae.load_reference_params({k: (v.numpy() if torch.is_tensor(v) else v) for k, v in sd["vae_variables"].items()})
 
 
 def serialize_num_microbatches(batch_per_replica, sequence_length, tokens_per_microbatch_per_replica=None):
@@ -133,7 +133,10 @@ def dalle_model_fn(features, labels, mode, params):
     model.mode = mode_str
     dev = eng.dev
     nmb = eng.hp.get("num_microbatches", 1) if mode == ModeKeys.TRAIN else 1
-    B, T, P = eng.B * nmb, eng.T, st["image_seq_len"]
+    T, P = eng.T, st["image_seq_len"]
+    B = labels.numel() // T   # rows handed in: n_microbatches x engine batch in TRAIN; any multiple of it in EVAL
+    assert B % eng.B == 0 and (mode != ModeKeys.TRAIN or B == eng.B * nmb), \
+        f"got {B} rows for an engine batch of {eng.B} (x {nmb} micro-batches)"
     text = labels.to(device=dev, dtype=torch.int32).reshape(B, T)
     tokens = torch.empty(B, T + P, dtype=torch.int32, device=dev)
     if st["vae"] is not None:
@@ -158,9 +161,15 @@ def dalle_model_fn(features, labels, mode, params):
         return EstimatorSpec(mode=mode, loss=eng.loss_acc[0], train_op=train_op_mb,
                              host_call=create_host_call(params["model_path"]) if params.get("model_path") else None,
                              training_hooks=[st["saver"]])
-    loss, _loss_batch = model.forward({"tokens": tokens}, return_loss=True)
     if mode == ModeKeys.EVAL:
-        return EstimatorSpec(mode=mode, loss=loss)
+        # the engine may have been sized for one training micro-batch: evaluate the batch in engine-sized chunks (equal
+        # sizes, so the mean of the chunk means is the batch mean, src/dalle_mtf/models.py:354)
+        total = None
+        for c in range(B // eng.B):
+            l, _ = model.forward({"tokens": tokens[c * eng.B:(c + 1) * eng.B]}, return_loss=True)
+            total = l.clone() if total is None else total + l
+        return EstimatorSpec(mode=mode, loss=total / (B // eng.B))
+    loss, _loss_batch = model.forward({"tokens": tokens}, return_loss=True)
     scalar_summary("loss", loss)
     scalar_summary("lr", st["lr_fn"]())
 

@@ -474,11 +474,13 @@ class DiscreteVAE:
         self.global_step += 1
 
     def state_dict(self):
-        return {"vae_variables": self.export_reference(), "m": self.m.detach().cpu(), "v": self.v.detach().cpu(),
-                "global_step": self.global_step}
+        # reference-named variables as plain tensors in a plain dict: loadable with torch.load(weights_only=True)
+        return {"vae_variables": {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in self.export_reference().items()},
+                "m": self.m.detach().cpu(), "v": self.v.detach().cpu(), "global_step": self.global_step}
 
     def load_state_dict(self, sd):
-        self.load_reference_params(sd["vae_variables"])
+        self.load_reference_params({k: (v.numpy() if torch.is_tensor(v) else np.asarray(v))
+                                    for k, v in sd["vae_variables"].items()})
         if "m" in sd:
             self.m.copy_(sd["m"]); self.v.copy_(sd["v"])
         self.global_step = int(sd.get("global_step", 0))

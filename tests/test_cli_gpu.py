@@ -1,0 +1,67 @@
+"""The reference's command-line workflow end to end on the MI355X (train_vae_tf.py:63-95 -> train_dalle.py:71-98):
+train the VAE on a TFRecord data set, let train_dalle.py pick up the newest VAE checkpoint (src/model_fns.py:11-52),
+train DALL-E with micro-batching on the same records, then resume both from their checkpoints."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(script, cfg, cwd):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--model", cfg], cwd=cwd, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout + r.stderr
+
+
+def _shards(tmp_path, n=16, size=32):
+    import io
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "dalle-mtf_amd"))
+    from src.data.create_tfrecords import TFRecordWriter, serialize_example
+    rng = np.random.default_rng(0)
+    for k in range(2):
+        w = TFRecordWriter(str(tmp_path / f"pairs_{k}.tfrecords"))
+        for _ in range(n // 2):
+            buf = io.BytesIO()
+            Image.fromarray(rng.integers(0, 256, size=(size, size, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=90)
+            w.write(serialize_example(buf.getvalue(), rng.integers(0, 50257, size=int(rng.integers(1, 300))).tolist()))
+        w.close()
+    return str(tmp_path / "pairs_*.tfrecords")
+
+
+def test_train_vae_then_dalle_cli_with_resume(tmp_path):
+    glob = _shards(tmp_path)
+    ds = {"train_path": glob, "eval_path": glob, "image_size": 32, "tfrecords": True}
+    vae = json.load(open(os.path.join(ROOT, "configs", "vae_example.json")))
+    vae.update(dataset=ds, train_batch_size=4, eval_batch_size=4, train_steps=4, steps_per_checkpoint=2, eval_steps=1,
+               model_path=str(tmp_path / "vae_run"), iterations=2)
+    vcfg = str(tmp_path / "vae_small.json")
+    json.dump(vae, open(vcfg, "w"))
+    out = _run("train_vae_tf.py", vcfg, str(tmp_path))
+    cks = sorted(os.listdir(tmp_path / "vae_run"))
+    assert "model.ckpt-4.pt" in cks, cks
+    # resume: already at train_steps -> nothing to do, exits cleanly
+    out = _run("train_vae_tf.py", vcfg, str(tmp_path))
+    assert "Current step" in out and "4" in out
+
+    dalle = json.load(open(os.path.join(ROOT, "configs", "dalle_example.json")))
+    dalle.update(dataset=ds, vae_model=vcfg, train_batch_size=4, eval_batch_size=4, train_steps=3, steps_per_checkpoint=3,
+                 eval_steps=1, model_path=str(tmp_path / "dalle_run"), iterations=1, n_layers=1, n_embd=256, n_heads=2,
+                 warmup_steps=1, tokens_per_mb_per_replica=600)   # S = 256 + 16 -> 2 sequences per micro-batch
+    dcfg = str(tmp_path / "dalle_small.json")
+    json.dump(dalle, open(dcfg, "w"))
+    out = _run("train_dalle.py", dcfg, str(tmp_path))
+    assert "step 3" in out or "step 3:" in out, out[-1500:]
+    assert os.listdir(tmp_path / "dalle_run")
+    dalle["train_steps"] = 5
+    json.dump(dalle, open(dcfg, "w"))
+    out = _run("train_dalle.py", dcfg, str(tmp_path))       # resumes from step 3
+    assert "Current step: 3" in out, out[-1500:]

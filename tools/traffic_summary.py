@@ -6,7 +6,7 @@ import json
 import sys
 
 fetch_csv, write_csv, out_json = sys.argv[1:4]
-KERNEL = "gemm_nt2_kernel<1>"
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "gemm_nt4_kernel<1>"   # the kernel the vocabulary projection dispatches to
 
 
 def mean_counter(path, name):
