@@ -28,9 +28,13 @@ typedef enum {
 
 const char* dmi_last_error_string(void);
 int dmi_version(void);
-/* 1 if the kernel variant is compiled in / selected: name in {"glds","tn_trread"} */
+/* Kernel-variant switches (tests and A/B measurements; every variant computes the same results): "glds", "tn_trread",
+ * "nt2", "nt3", "nt4", "nt5", "prio", "tn_streamk", "attn_xcd", "dkv8".  Unknown name -> -1. */
 int dmi_get_option(const char* name);
 int dmi_set_option(const char* name, int value);
+/* Diagnostics (tools/phases.py): u64 device buffer [blocks][5 or 8] that the 256x128 NT kernel and the weight-gradient
+ * kernel fill with per-block phase cycle stamps; NULL (default) disables the stamps. */
+int dmi_set_debug_buffer(void* device_buffer);
 
 /* ---- K1  embedding: mtf.gather(wte, tokens) + wpe[0..S)   src/dalle_mtf/models.py:186-219 ---- */
 int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
