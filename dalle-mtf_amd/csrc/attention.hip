@@ -155,7 +155,6 @@ __device__ __forceinline__ void fr3_wait(Fr3& f) {
 }
 
 extern int g_opt_attn_xcd;
-extern int g_opt_dkv8;
 // (tile, batch*head) of this block.  remap = 0: plain grid order.  remap = G >= 1: hardware block b (dispatched to XCD
 // b % 8) takes the b-th entry of a per-XCD contiguous range of the sequence below, so the tiles of one (batch, head)
 // share that XCD's L2 copy of K/V/Q/dO; inside the range, groups of G (batch, head) pairs are visited tile-major
@@ -753,197 +752,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   }
 }
 
-// ---- dK/dV kernel, 8-wave variant ---------------------------------------------------------------------------------
-// The 4-wave kernel needs 256 VGPR + 165 AGPR per wave, i.e. ONE wave per SIMD: every LDS / MFMA dependency stall is
-// exposed (MFMA pipe ~18 % busy).  Here two groups of 4 waves share one block, its V tile and its Q/dO ring: both
-// groups compute the same S / dP tiles (duplicated QK^T and dO V^T MFMAs and softmax), but group g accumulates only
-// head dims [64g, 64g+64) of dV^T / dK^T -- half the accumulators and transposed fragments, so a wave fits the
-// 256-register budget of 2 waves / SIMD and the two instruction streams fill each other's stalls.  24 instead of 32
-// MFMAs per wave-step (48 per key-slice instead of 32), no cross-group reduction, no atomics.
-__global__ __launch_bounds__(512, 1) void attn_bwd_dkv8_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                              const float* __restrict__ stats /* [B,H,S,2] (lse, delta) */,
-                                                              bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
-  const int d = H * HD, ld3 = 3 * d;
-  int ktile, bh;
-  attn_block(remap, ktile, bh);
-  const int b = bh / H, hh = bh % H;
-  const int key0 = ktile * 128;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wid8 >> 2, wid = wid8 & 3;   // grp = which 64 of the 128 head dims this wave accumulates; wid = key slice
-  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
-  const int krow = key0 + wid * 32 + r;
-  const int krow_c = krow < S ? krow : S - 1;
-  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
-  const bf16_t* kb = qb + d;
-  const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
-
-  // buffer descriptors: num_records ends with the last valid row so tail rows read as zeros
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(((int64_t)(S - 1) * d + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)(stats + (int64_t)bh * S * 2), 0, S * 8, 0x00020000);
-
-  bf16x8 kf[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kb + (int64_t)krow_c * ld3 + 16 * kk + 8 * h);
-
-  // resident V tile: 128 rows x 16 chunks = 2048 chunks, 8 per thread; rows past S clamp (their keys are never stored)
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + 512 * i, row = c >> 4, pc = c & 15;
-    int gr = key0 + row;
-    gr = gr < S ? gr : S - 1;
-    dma16(rv, sm + (wid8 * 64 + 512 * i) * 16, (gr * ld3 + 8 * (pc ^ swz(row))) * 2);
-  }
-  // per-step DMA offsets (1 chunk of Q, 1 of dO per thread over 512 threads; tile row = tid>>4, rows advance by 32 per step)
-  const int voq = ((tid >> 4) * ld3 + 8 * ((tid & 15) ^ swz(tid >> 4))) * 2;
-  const int vod = ((tid >> 4) * d + 8 * ((tid & 15) ^ swz(tid >> 4))) * 2;
-  auto stage = [&](int st, int q0) {
-    char* base = sm + 32768 + st * DKV_STAGE;
-    dma16(rq, base + wid8 * 1024, voq + q0 * ld3 * 2);
-    dma16(rdo, base + 8192 + wid8 * 1024, vod + q0 * d * 2);
-    dma4(rst, base + 16384, (q0 * 2 + lane) * 4);  // 32 (lse, delta) pairs; every wave (identical bytes): uniform DMA count
-  };
-  // hoisted fragment offsets
-  int ofa[8];  // natural A operand: row r, chunk (2kk+h) ^ swz(r)
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) ofa[kk] = r * 256 + (((2 * kk + h) ^ swz(r)) << 4);
-  // transposed A operand: rows 16*s2 + 4h + (l16>>2) [+8], byte in row (dt*64 + 32*(g4&1) + 8*(l16&3)) swizzled
-  const int rr = l16 >> 2;
-  unsigned oft[2][2];  // this group's two 32-wide d tiles: dt = 2*grp + i
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int w2 = 0; w2 < 2; ++w2) {
-      const int row = 4 * h + rr + 8 * w2;  // + 16*s2 does not change swz
-      const int chunk = (2 * grp + i) * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);
-      oft[i][w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
-    }
-
-  f32x16 dv[2], dk[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dv[i][e] = dk[i][e] = 0.f;
-
-  const int wave_kmin = key0 + wid * 32;
-  const int nqi = (S + 31) / 32;
-  const int qi0 = key0 / 32;
-
-  auto compute = [&](int st, int qi) {
-    if (32 * qi + 31 < wave_kmin) return;  // wave-uniform: every query of the tile precedes every key of this wave
-    const char* base = sm + 32768 + st * DKV_STAGE;
-    const unsigned lb = lds0 + 32768 + st * DKV_STAGE;
-    const float* sst = (const float*)(base + 16384);
-    f32x16 s, dp;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const bf16x8 qa = *(const bf16x8*)(base + ofa[kk]);
-      const bf16x8 da = *(const bf16x8*)(base + 8192 + ofa[kk]);
-      const bf16x8 vf = *(const bf16x8*)(sm + wid * 8192 + ofa[kk]);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);   // S[q][key]
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf, dp, 0, 0, 0);     // dP[q][key]
-    }
-    Tr2 tdo, tq;  // first 16 queries (s2 = 0): dO^T then Q^T fragments, issued before the softmax VALU work
-    tr2_issue(tdo, lb + 8192 + oft[0][0], lb + 8192 + oft[0][1], lb + 8192 + oft[1][0], lb + 8192 + oft[1][1]);
-    // (lse, delta) pairs of this lane's 16 query rows: rows (e&3) + 8*(e>>2) + 4h -> 4 consecutive pairs per e>>2.
-    // Loaded unconditionally with vector reads; the exponential is unconditional too (exp(-inf) = 0 for masked
-    // entries) -- a ternary around exp() is compiled into per-element branches with an LDS wait inside each.
-    float pv[16], ds[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 st0 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h));
-      const f32x4 st1 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h) + 4);
-      const float lq[4] = {st0[0], st0[2], st1[0], st1[2]};
-      const float dl[4] = {st0[1], st0[3], st1[1], st1[3]};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = 4 * g + j;
-        const int qg = 32 * qi + 8 * g + 4 * h + j;
-        const bool masked = (krow > qg) || (qg >= S);
-        const float x = masked ? -INFINITY : (s[e] - lq[j]);
-        const float pe = __expf(x);
-        pv[e] = pe;
-        ds[e] = pe * (dp[e] - dl[j]);
-      }
-    }
-    bf16x8 pb[2], dsb[2];
-    pb[0] = pack_bf8(pv);
-    pb[1] = pack_bf8(pv + 8);
-    dsb[0] = pack_bf8(ds);
-    dsb[1] = pack_bf8(ds + 8);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const unsigned o = lb + s2 * 4096;
-      tr2_wait(tdo);
-      tr2_issue(tq, o + oft[0][0], o + oft[0][1], o + oft[1][0], o + oft[1][1]);
-      dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.a0, tdo.a1), pb[s2], dv[0], 0, 0, 0);   // dV^T[d][key]
-      dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.b0, tdo.b1), pb[s2], dv[1], 0, 0, 0);
-      tr2_wait(tq);
-      if (s2 == 0) {
-        const unsigned o2 = lb + 8192 + 4096;
-        tr2_issue(tdo, o2 + oft[0][0], o2 + oft[0][1], o2 + oft[1][0], o2 + oft[1][1]);
-      }
-      dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.a0, tq.a1), dsb[s2], dk[0], 0, 0, 0);    // dK^T[d][key]
-      dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.b0, tq.b1), dsb[s2], dk[1], 0, 0, 0);
-    }
-  };
-
-  // 4-stage DMA ring, loads issued 3 steps ahead; counted vmcnt (3 DMA per wave per stage) + raw barriers so the
-  // loads stay in flight across barriers; ONE barrier per step:
-  //   [barrier: everyone finished compute(t-1) and everyone's stage-t data landed] issue t+3 -> compute t -> wait t+1
-  const int nsteps = nqi - qi0;
-#define DKV_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define DKV_BARRIER()                                  \
-  do {                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                      \
-  } while (0)
-  if (nsteps > 0) stage(0, 32 * qi0);
-  if (nsteps > 1) stage(1, 32 * (qi0 + 1));
-  if (nsteps > 2) stage(2, 32 * (qi0 + 2));
-  if (nsteps > 2) DKV_WAIT(6); else if (nsteps > 1) DKV_WAIT(3); else DKV_WAIT(0);
-  DKV_BARRIER();
-  int t = 0;
-#define DKV_STEP(ST)                                                        \
-  {                                                                         \
-    if (t + 3 < nsteps) stage((ST + 3) & 3, 32 * (qi0 + t + 3));            \
-    compute(ST, qi0 + t);                                                   \
-    const int rem = nsteps - 1 - t; /* steps after this one */              \
-    if (rem >= 3) DKV_WAIT(6); else if (rem == 2) DKV_WAIT(3); else DKV_WAIT(0);  \
-    DKV_BARRIER();                                                          \
-    ++t;                                                                    \
-  }
-  while (t + 4 <= nsteps) {
-    DKV_STEP(0) DKV_STEP(1) DKV_STEP(2) DKV_STEP(3)
-  }
-  if (t < nsteps) DKV_STEP(0)
-  if (t < nsteps) DKV_STEP(1)
-  if (t < nsteps) DKV_STEP(2)
-#undef DKV_STEP
-#undef DKV_WAIT
-#undef DKV_BARRIER
-
-  if (krow < S) {
-    bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
-    bf16_t* ovp = okp + d;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int dd = (2 * grp + dt) * 32 + 8 * q4 + 4 * h;
-        *(u32x2*)(okp + dd) = u32x2{pack2bf(dk[dt][4 * q4], dk[dt][4 * q4 + 1]), pack2bf(dk[dt][4 * q4 + 2], dk[dt][4 * q4 + 3])};
-        *(u32x2*)(ovp + dd) = u32x2{pack2bf(dv[dt][4 * q4], dv[dt][4 * q4 + 1]), pack2bf(dv[dt][4 * q4 + 2], dv[dt][4 * q4 + 3])};
-      }
-  }
-}
-
 extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
                                  const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
                                  uint16_t* dqkv, int B, int H, int S, void* stream) {
@@ -964,14 +772,7 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const 
   }
   attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, d_o, lse, delta, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dq");
-  if (g_opt_dkv8) {
-    const int shm8 = 32768 + DKV_NSTAGE * DKV_STAGE;
-    static bool attr8 = false;
-    if (!attr8) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkv8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm8); attr8 = true; }
-    attn_bwd_dkv8_kernel<<<dim3((S + 127) / 128, B * H), dim3(512), shm8, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
-  } else {
-    attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
-  }
+  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
 }

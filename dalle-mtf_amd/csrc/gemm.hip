@@ -27,7 +27,6 @@ static int g_opt_prio = 0;
 static int g_opt_nt4 = 1;
 static int g_opt_nt5 = 0;  // hand-scheduled 3-stage kernel (0 off, 2 = 256x128 tiles, 3 = 128x128 tiles): bit-identical, measured equal
                            // to v2/v4 within noise on every shape of the model (tools/ksweep.py) -- kept as a tested option
-int g_opt_dkv8 = 0;      // attention dK/dV: 8-wave block (two query-tile groups, 2 waves/SIMD)
 int g_opt_attn_xcd = 8;  // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn_streamk = 1;  // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;
@@ -43,7 +42,6 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt5")) return g_opt_nt5;
   if (!strcmp(name, "tn_streamk")) return g_opt_tn_streamk;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
-  if (!strcmp(name, "dkv8")) return g_opt_dkv8;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
@@ -56,7 +54,6 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt5")) { g_opt_nt5 = value; return 0; }
   if (!strcmp(name, "tn_streamk")) { g_opt_tn_streamk = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
-  if (!strcmp(name, "dkv8")) { g_opt_dkv8 = value; return 0; }
   return -1;
 }
 

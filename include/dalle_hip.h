@@ -29,7 +29,7 @@ typedef enum {
 const char* dmi_last_error_string(void);
 int dmi_version(void);
 /* Kernel-variant switches (tests and A/B measurements; every variant computes the same results): "glds", "tn_trread",
- * "nt2", "nt3", "nt4", "nt5", "prio", "tn_streamk", "attn_xcd", "dkv8".  Unknown name -> -1. */
+ * "nt2", "nt3", "nt4", "nt5", "prio", "tn_streamk", "attn_xcd".  Unknown name -> -1. */
 int dmi_get_option(const char* name);
 int dmi_set_option(const char* name, int value);
 /* Diagnostics (tools/phases.py): u64 device buffer [blocks][5 or 8] that the 256x128 NT kernel and the weight-gradient

@@ -354,19 +354,16 @@ def _transposes(qkv, B, H, S):
     return outs
 
 
-@pytest.mark.parametrize("xcd,dkv8", [(8, 0), (1, 1), (0, 1), (3, 0)])
+@pytest.mark.parametrize("xcd", [8, 1, 0, 3])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 2, 384), (1, 1, 72), (3, 1, 384), (5, 2, 200)])
-def test_attention_fwd_bwd(B, H, S, xcd, dkv8):
+def test_attention_fwd_bwd(B, H, S, xcd):
     """xcd = G >= 1: per-XCD block ranges, groups of G (batch, head) pairs visited heaviest-tile-first (default 8);
     0: plain grid order.  Grids of 9 and 20 blocks exercise uneven per-XCD ranges and partial groups."""
-    saved = dh.get_option("dkv8")
     dh.set_option("attn_xcd", xcd)
-    dh.set_option("dkv8", dkv8)   # 1: 8-wave dK/dV block (two head-dim halves, 2 waves / SIMD); 0: 4-wave block
     try:
         _attention_fwd_bwd(B, H, S)
     finally:
         dh.set_option("attn_xcd", 8)
-        dh.set_option("dkv8", saved)
 
 
 def _attention_fwd_bwd(B, H, S):
