@@ -31,6 +31,8 @@ CFG = dict(n_embd=512, n_layers=6, n_heads=4, text_vocab_size=50258, image_vocab
            image_seq_len=1024)
 MODELS = {  # --model: the default is BASELINE.json's metric config; "1.3B" is SURVEY.md §8(d) C5 (secondary datapoint)
     "dalle_example": CFG,
+    "dalle_coco": dict(n_embd=1024, n_layers=12, n_heads=8, text_vocab_size=50258, image_vocab_size=2048, text_seq_len=256,
+                       image_seq_len=1024),   # configs/dalle_coco.json (16 sequences per GPU on 8 GPUs: --batch 16)
     "1.3B": dict(n_embd=2048, n_layers=24, n_heads=16, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256,
                  image_seq_len=1024),
 }
@@ -159,7 +161,7 @@ def main():
         tokens_per_s = B * world * S * args.steps / dt
         d, L, V = CFG["n_embd"], CFG["n_layers"], eng.V
         train_flops_step_gpu = 3 * fwd_flops_per_token(d, L, S, V) * B * S
-        gemm_flops = 2.0 * B * S * d * V
+        gemm_flops = 2.0 * B * S * d * V   # algorithmic (unpadded vocabulary)
         k_ms = [a.elapsed_time(b) for a, b in evs]
         k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
         achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
@@ -171,11 +173,11 @@ def main():
             "metric": f"train tokens/sec (text+image) per node, {args.model}", "value": tokens_per_s, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"configs/dalle_example.json transformer train step (n_embd={d}, {L} layers, "
+            "config": {"workload": f"configs/{args.model if args.model != '1.3B' else 'dalle_example (1.3B dimensions, SURVEY §8(d) C5)'}.json transformer train step (n_embd={d}, {L} layers, "
                                    f"{CFG['n_heads']} heads, seq 256+1024, V={V}), synthetic captions + synthetic image-token ids",
                        "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
                        "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel (vocabulary projection M=B*S, N=50816, K={d})",
+            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel (vocabulary projection M=B*S, N={eng.Vp}, K={d})",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": traffic,
                          "traffic_unit": "bytes/launch (PMC, profiles/r01h_traffic_vocab_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, L2-side counters incl. Infinity-Cache hits; algorithmic 4.26e9)",
