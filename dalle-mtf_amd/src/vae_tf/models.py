@@ -168,6 +168,11 @@ class DiscreteVAE:
                 max_col = max(max_col, B * c.H * c.W * _ru(4 * c.cin, 64), B * c.H * c.W * _ru(16 * c.cout, 64))
         self.codebook_t = torch.zeros(self.num_tokens, self.n_hid, **b16)
         self.col = torch.empty(max_col, **b16)
+        # im2col matrices of the forward convolutions kept for their weight gradients (288 GB HBM: ~8 GB for vae_coco at 16
+        # images) -- the backward pass then gathers only dy; allocated on first use in train mode
+        self.col_keep = {}
+        self._col_valid = set()
+        self.keep_cols = (self.mode == "train")
         # activations
         self.x_img = torch.empty(B * self.H * self.W, IMG_CP, **b16)
         self.act_in = [None] * len(self.convs)     # input of each conv (kept for the weight gradients)
@@ -296,8 +301,14 @@ class DiscreteVAE:
             K = c.kk * c.cin
             Kp = _ru(K, 64)
             taps, s = {"down": (TAPS4, 2), "res": (TAPS3, 1), "final": ([(0, 0)], 1)}[c.kind]
-            dh.im2col(x, self.col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
-            dh.gemm_nt(self.col, Kp, self.wf[c.name], Kp, out, c.cout, B * c.Ho * c.Wo, c.cout, Kp, flags | dh.GEMM_BIAS,
+            col = self.col
+            if self.keep_cols and c.kind != "final":
+                col = self.col_keep.get(c.name)
+                if col is None:
+                    col = self.col_keep[c.name] = torch.empty(B * c.Ho * c.Wo * Kp, dtype=torch.bfloat16, device=self.dev)
+                self._col_valid.add(c.name)
+            dh.im2col(x, col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
+            dh.gemm_nt(col, Kp, self.wf[c.name], Kp, out, c.cout, B * c.Ho * c.Wo, c.cout, Kp, flags | dh.GEMM_BIAS,
                        bias=bias, residual=residual)
         else:  # up: 4 output-parity GEMMs + interleave
             Kp = _ru(4 * c.cin, 64)
@@ -318,6 +329,7 @@ class DiscreteVAE:
         B = self.B
         assert img.shape == (B, self.H, self.W, self.num_ch), f"expected {(B, self.H, self.W, self.num_ch)}, got {tuple(img.shape)}"
         self.img = img
+        self._col_valid.clear()
         dh.pad_channels(img, self.x_img, B * self.H * self.W, self.num_ch, IMG_CP)
         x = self.x_img
         convs = self.convs
@@ -389,8 +401,12 @@ class DiscreteVAE:
         K = c.kk * c.cin
         Kp = _ru(K, 64)
         taps, s = (TAPS4, 2) if c.kind == "down" else (TAPS3, 1)
-        dh.im2col(x_in, self.col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
-        dh.gemm_tn(self.col, Kp, dy, c.cout, self._gv(c.name + "/kernel"), B * c.Ho * c.Wo, K, c.cout, self.ws,
+        col = self.col
+        if c.name in self._col_valid:        # the forward pass of this step left col(x_in) in its kept buffer
+            col = self.col_keep[c.name]
+        else:
+            dh.im2col(x_in, col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
+        dh.gemm_tn(col, Kp, dy, c.cout, self._gv(c.name + "/kernel"), B * c.Ho * c.Wo, K, c.cout, self.ws,
                    dbias=self._gv(c.name + "/bias"))
 
     def _dgrad3(self, c: _Conv, dy, out, flags=0, residual=None, relu_src=None):
