@@ -1568,3 +1568,167 @@ extern "C" int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* wor
   return DMI_OK;
 }
 
+// =====================================================================================
+// Implicit-im2col convolution GEMM (VAE, src/vae_tf/models.py:59-78 conv_block / conv2d_transpose lowering):
+//   out[(b,oy,ox)][n] = sum_t sum_c x[b, oy*s + dy_t, ox*s + dx_t, c] * Wt[n][t*C + c]   (+ bias / ReLU / residual / mask)
+// i.e. dmi_im2col + dmi_gemm_nt without the K^2-times-larger column matrix in HBM (im2col was 39 % of the vae_coco step
+// in the rocprofv3 profile).  Same tiling / swizzle / epilogue as gemm_nt2_kernel; only the A stager differs: a 64-wide
+// k-step lies inside ONE tap (C % 64 == 0), so a lane's source address is its output pixel's base offset plus a
+// wave-uniform tap offset, and taps that fall outside the image are steered past the buffer descriptor's end (reads as 0
+// = the SAME zero padding).  The k order (tap-major, channel) and all arithmetic equal the materialised path: results
+// are bit-identical to im2col + gemm_nt.
+// =====================================================================================
+#define CONV_MAX_TAPS 16
+struct ConvGeom {
+  int H, W, C, Ho, Wo, stride, ntaps;
+  int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
+};
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nt = a.K / BK;
+
+  // A: the whole activation tensor behind one descriptor (num_records = its size: anything past it reads as zero)
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, a.lda /* bytes of x */, 0x00020000);
+  const bf16_t* Bb = a.B + (int64_t)n0 * a.ldb;
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, 0x7fffffff, 0x00020000);
+  int pix[4], vob[4];
+  unsigned mask[4];
+  {
+    const int chp = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int src_ch = chp ^ ((row >> 1) & 7);
+      const int m = m0 + row;
+      const int ox = m % g.Wo, oy = (m / g.Wo) % g.Ho, b = m / (g.Wo * g.Ho);
+      pix[i] = (((b * g.H + oy * g.stride) * g.W + ox * g.stride) * g.C + 8 * src_ch) * 2;
+      unsigned mk = 0;
+      if (m < a.M) {
+        for (int t = 0; t < g.ntaps; ++t) {
+          const int iy = oy * g.stride + g.dy[t], ix = ox * g.stride + g.dx[t];
+          if (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) mk |= 1u << t;
+        }
+      }
+      mask[i] = mk;
+      const int rb_ = n0 + row < a.N ? row : a.N - 1 - n0;
+      vob[i] = (rb_ * a.ldb + 8 * src_ch) * 2;
+    }
+  }
+  int offa[4], offb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    offa[kk] = lds_chunk_off(wm * 64 + r, kk * 2 + h);
+    offb[kk] = 16384 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stage = [&](int st, int t) {   // k-step t: tap = t*64 / C, channel offset (t*64) % C  (wave-uniform scalars)
+    char* base = smem + st * 32768 + wid * 1024;
+    const int k0 = t * BK;
+    const int tap = k0 / g.C, c0 = k0 - tap * g.C;
+    const int tapoff = ((g.dy[tap] * g.W + g.dx[tap]) * g.C + c0) * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int voa = ((mask[i] >> tap) & 1u) ? pix[i] + tapoff : 0x7ffffff0;
+      glds16(ra, base + i * 4096, voa, 0);
+      glds16(rb, base + 16384 + i * 4096, vob[i], k0 * 2);
+    }
+  };
+  auto compute = [&](int st) {
+    const char* cur = smem + st * 32768;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
+        fb[i] = *(const bf16x8*)(cur + offb[kk] + i * 4096);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int t = 0;
+  for (; t + 2 <= nt; t += 2) {
+    if (t + 1 < nt) stage(1, t + 1);
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < nt) stage(0, t + 2);
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (t < nt) {  // odd tail (stage 0 holds it)
+    compute(0);
+    __syncthreads();
+  }
+  epilogue_bf16<FLAGS, 2>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 64, n0 + wn * 64);
+}
+
+template <int FLAGS>
+static int launch_conv(const GemmArgs& a, const ConvGeom& g, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_gemm_nt_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_done = true; }
+  conv_gemm_nt_kernel<FLAGS><<<dim3(a.tiles_m * a.tiles_n), dim3(256), 65536, st>>>(a, g);
+  DMI_CHECK_LAUNCH("conv_gemm_nt");
+  return DMI_OK;
+}
+
+extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps,
+                                const int* dy, const int* dx, const uint16_t* Wt, int ldw, uint16_t* out, int ldc, int N,
+                                int flags, const uint16_t* bias, const uint16_t* residual, const uint16_t* relu_src,
+                                void* stream) {
+  DMI_REQUIRE(x && Wt && out && dy && dx, "conv_gemm_nt: null pointer");
+  DMI_REQUIRE(C % 64 == 0 && ntaps >= 1 && ntaps <= CONV_MAX_TAPS && N % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && ldw >= ntaps * C && ldc >= N,
+              "conv_gemm_nt: need C%%64==0, 1..16 taps, N/ldw/ldc multiples of 8 (C=%d ntaps=%d N=%d)", C, ntaps, N);
+  DMI_REQUIRE(B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1, "conv_gemm_nt: bad geometry");
+  const int64_t xbytes = (int64_t)B * H * W * C * 2, Ml = (int64_t)B * Ho * Wo;
+  DMI_REQUIRE(xbytes < 0x7ffffff0 && Ml < 0x7fffffff, "conv_gemm_nt: activation tensor too large for 32-bit buffer offsets");
+  DMI_REQUIRE((((uintptr_t)x | (uintptr_t)Wt | (uintptr_t)out) & 15) == 0, "conv_gemm_nt: operands must be 16-byte aligned");
+  DMI_REQUIRE(!(flags & DMI_GEMM_BIAS) || bias, "conv_gemm_nt: bias flag without pointer");
+  DMI_REQUIRE(!(flags & DMI_GEMM_RESIDUAL) || residual, "conv_gemm_nt: residual flag without pointer");
+  DMI_REQUIRE(!(flags & DMI_GEMM_RELU_MASK) || relu_src, "conv_gemm_nt: relu-mask flag without pointer");
+  GemmArgs a;
+  a.A = x; a.B = Wt; a.C = out; a.bias = bias; a.residual = residual; a.relu_src = relu_src;
+  a.M = (int)Ml; a.N = N; a.K = ntaps * C; a.lda = (int)xbytes /* descriptor size */; a.ldb = ldw; a.ldc = ldc;
+  a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+  a.k_per_split = a.K; a.slab_stride = 0; a.prio = 0; a.dbg = nullptr;
+  ConvGeom g;
+  g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
+  for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }
+  hipStream_t st = (hipStream_t)stream;
+  switch (flags) {
+    case 0: return launch_conv<0>(a, g, st);
+    case DMI_GEMM_BIAS: return launch_conv<DMI_GEMM_BIAS>(a, g, st);
+    case DMI_GEMM_BIAS | DMI_GEMM_RELU: return launch_conv<DMI_GEMM_BIAS | DMI_GEMM_RELU>(a, g, st);
+    case DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL: return launch_conv<DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL>(a, g, st);
+    case DMI_GEMM_RESIDUAL: return launch_conv<DMI_GEMM_RESIDUAL>(a, g, st);
+    case DMI_GEMM_RELU_MASK: return launch_conv<DMI_GEMM_RELU_MASK>(a, g, st);
+    default: DMI_REQUIRE(false, "conv_gemm_nt: unsupported epilogue flags %d", flags);
+  }
+  return DMI_OK;
+}

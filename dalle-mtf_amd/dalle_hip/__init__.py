@@ -81,6 +81,7 @@ def _declare(L):
         "dmi_transpose_bf16_padded": (I, [P, P, I, I, I, P]),
         "dmi_transpose_bf16_batch": (I, [P, P, P, I, L64, P]),
         "dmi_im2col": (I, [P, P, I, I, I, I, I, I, I, I, P, P, I, P]),
+        "dmi_conv_gemm_nt": (I, [P, I, I, I, I, I, I, I, I, P, P, P, I, P, I, I, I, P, P, P, P]),
         "dmi_weight_gather": (I, [P, P, I, I, I, P, I, P]),
         "dmi_pixel_interleave": (I, [P, P, I, I, I, I, P]),
         "dmi_pad_channels": (I, [P, P, L64, I, I, P]),
@@ -304,6 +305,15 @@ def transpose_padded(inp, out, R_valid, R_pitch, C):
 
 def _iarr(vals):
     return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def conv_gemm_nt(x, B, H, W, C, Ho, Wo, stride, taps, Wt, ldw, out, ldc, N, flags=0, bias=None, residual=None, relu_src=None):
+    """implicit-im2col convolution GEMM (include/dalle_hip.h: dmi_conv_gemm_nt); taps = [(dy, dx), ...]; C % 64 == 0."""
+    _dev(x, Wt, out)
+    dy, dx = _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps])
+    _check(lib().dmi_conv_gemm_nt(_p(x), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p),
+                                  ctypes.cast(dx, c_void_p), _p(Wt), ldw, _p(out), ldc, N, flags,
+                                  _p(bias), _p(residual), _p(relu_src), _stream()), "conv_gemm_nt")
 
 
 def im2col(x, out, B, H, W, C, Ho, Wo, stride, taps, ldo):

@@ -315,6 +315,10 @@ class DiscreteVAE:
             Mi = B * c.H * c.W
             for p in range(4):
                 taps = [(t[1], t[2]) for t in _parity(p)]
+                if c.cin % 64 == 0:
+                    dh.conv_gemm_nt(x, B, c.H, c.W, c.cin, c.H, c.W, 1, taps, self.wp[c.name][p], Kp, self.par[p * Mi * c.cout:],
+                                    c.cout, c.cout, dh.GEMM_BIAS, bias=bias)
+                    continue
                 dh.im2col(x, self.col, B, c.H, c.W, c.cin, c.H, c.W, 1, taps, Kp)
                 dh.gemm_nt(self.col, Kp, self.wp[c.name][p], Kp, self.par[p * Mi * c.cout:], c.cout, Mi, c.cout, Kp, dh.GEMM_BIAS, bias=bias)
             dh.pixel_interleave(self.par, out, B, c.H, c.W, c.cout)
@@ -411,6 +415,10 @@ class DiscreteVAE:
 
     def _dgrad3(self, c: _Conv, dy, out, flags=0, residual=None, relu_src=None):
         Kp = _ru(9 * c.cout, 64)
+        if c.cout % 64 == 0:   # implicit im2col: the 9x column matrix of dy never exists in HBM (bit-identical results)
+            dh.conv_gemm_nt(dy, self.B, c.H, c.W, c.cout, c.H, c.W, 1, TAPS3_REV, self.wd[c.name], Kp, out, c.cin, c.cin, flags,
+                            residual=residual, relu_src=relu_src)
+            return
         dh.im2col(dy, self.col, self.B, c.H, c.W, c.cout, c.H, c.W, 1, TAPS3_REV, Kp)
         dh.gemm_nt(self.col, Kp, self.wd[c.name], Kp, out, c.cin, self.B * c.H * c.W, c.cin, Kp, flags, residual=residual, relu_src=relu_src)
 
@@ -458,6 +466,10 @@ class DiscreteVAE:
                     Kp = _ru(4 * c.cout, 64)
                     for p in range(4):
                         taps = [(t[1], t[2]) for t in _parity(p)]
+                        if c.cout % 64 == 0:
+                            dh.conv_gemm_nt(d, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, self.wp[c.name][p], Kp,
+                                            self.par[p * Mo * c.cin:], c.cin, c.cin)
+                            continue
                         dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, Kp)
                         dh.gemm_nt(self.col, Kp, self.wp[c.name][p], Kp, self.par[p * Mo * c.cin:], c.cin, Mo, c.cin, Kp)
                     nd = spare[0]

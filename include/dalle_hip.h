@@ -161,6 +161,14 @@ int dmi_transpose_bf16_padded(const uint16_t* in, uint16_t* out, int R_valid, in
 /* ================= discrete VAE (src/vae_tf/models.py:81-163, src/vae_tf/layers.py:4-25) =================
  * K11 convolutions = tap-list im2col + dmi_gemm_nt / dmi_gemm_tn (round-1 lowering, see csrc/vae.hip).
  * activations NHWC bf16 [B*H*W, C], C % 8 == 0. */
+/* Implicit-im2col convolution: dmi_im2col + dmi_gemm_nt in one kernel, no column matrix in HBM, bit-identical results.
+ *   out[(b,oy,ox)][n] = sum_t sum_c x[b, oy*stride + dy[t], ox*stride + dx[t], c] * Wt[n][t*C + c]  (+ epilogue flags)
+ * x NHWC bf16 [B,H,W,C] with C % 64 == 0 (zero outside the image = TF SAME padding, src/vae_tf/models.py:67-68);
+ * Wt [N, ldw] (ldw >= ntaps*C), out [B*Ho*Wo, ldc]; flags/bias/residual/relu_src as dmi_gemm_nt. */
+int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps,
+                     const int* dy, const int* dx, const uint16_t* Wt, int ldw, uint16_t* out, int ldc, int N,
+                     int flags, const uint16_t* bias, const uint16_t* residual, const uint16_t* relu_src, void* stream);
+
 /* out[(b,oy,ox)][t*C + c] = x[b, oy*stride + dy[t], ox*stride + dx[t], c] (0 outside); row pitch ldo, tail zero-filled.
  * dy/dx are HOST arrays (ntaps <= 16). */
 int dmi_im2col(const uint16_t* x, uint16_t* out, int B, int H, int W, int C, int Ho, int Wo, int stride,

@@ -486,3 +486,35 @@ def test_sumsq_adam_cast():
     c = torch.zeros(n, dtype=torch.bfloat16, device=DEV)
     dh.cast_f32_bf16(pd, c, n)
     assert torch.equal(c.cpu(), pd[:n].cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("B,H,W,C,N,stride,kind,flags", [
+    (2, 12, 12, 64, 128, 1, "3x3", 0), (1, 16, 20, 128, 72, 1, "3x3rev", 4), (3, 8, 8, 64, 64, 1, "3x3", 8),
+    (2, 16, 16, 64, 136, 2, "4x4", 1), (2, 9, 7, 64, 64, 1, "par0", 1), (1, 10, 6, 128, 64, 1, "par3", 0), (2, 6, 6, 192, 64, 1, "3x3", 3)])
+def test_conv_gemm_nt_equals_im2col_gemm(B, H, W, C, N, stride, kind, flags):
+    """implicit-im2col convolution == dmi_im2col + dmi_gemm_nt, bit for bit (same k order and kernel arithmetic): 3x3 SAME,
+    reversed taps (input gradient), 4x4 stride-2 SAME, 2x2 output-parity taps of the transposed conv; ragged M / N tiles;
+    every epilogue used by the VAE."""
+    taps = {"3x3": [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)],
+            "3x3rev": [(1 - ky, 1 - kx) for ky in range(3) for kx in range(3)],
+            "4x4": [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)],
+            "par0": [(0, 0), (0, -1), (-1, 0), (-1, -1)], "par3": [(1, 1), (1, 0), (0, 1), (0, 0)]}[kind]
+    Ho, Wo = (H // stride, W // stride)
+    K = len(taps) * C
+    x = rnd(B * H * W, C, seed=1).to(DEV)
+    Wt = rnd(N, K, scale=0.1, seed=2).to(DEV)
+    bias, res = rnd(N, seed=3).to(DEV), rnd(B * Ho * Wo, N, seed=4).to(DEV)
+    src = torch.relu(rnd(B * Ho * Wo, N, seed=5)).to(DEV)
+    kw = dict(bias=bias if flags & 1 else None, residual=res if flags & 4 else None, relu_src=src if flags & 8 else None)
+    col = torch.zeros(B * Ho * Wo, K, dtype=torch.bfloat16, device=DEV)
+    dh.im2col(x, col, B, H, W, C, Ho, Wo, stride, taps, K)
+    ref = torch.zeros(B * Ho * Wo, N, dtype=torch.bfloat16, device=DEV)
+    dh.set_option("nt4", 0)
+    try:
+        dh.gemm_nt(col, K, Wt, K, ref, N, B * Ho * Wo, N, K, flags, **kw)
+    finally:
+        dh.set_option("nt4", 1)
+    out = torch.zeros_like(ref)
+    dh.conv_gemm_nt(x, B, H, W, C, Ho, Wo, stride, taps, Wt, K, out, N, N, flags, **kw)
+    assert torch.equal(out, ref)
+    assert float(out.float().abs().max()) > 0
