@@ -1072,6 +1072,13 @@ extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   return base > tail + 256 ? base : tail + 256;
 }
 
+#define CONV_MAX_TAPS 16
+struct ConvGeom {   // convolution geometry of the implicit-im2col kernels (dmi_conv_gemm_nt, dmi_conv_wgrad_tn)
+  int H, W, C, Ho, Wo, stride, ntaps;
+  int lw, lh;       // log2(Wo), log2(Ho) (weight-gradient kernel only: output dims are powers of two there)
+  int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
+};
+
 struct TnArgs {
   const bf16_t* X;
   const bf16_t* Y;
@@ -1134,8 +1141,11 @@ __device__ __forceinline__ bf16x8 tr_cat(u32x2 a, u32x2 b) {
 // all-ones A operand (D[i][j] = sum_k Y[k][j]).
 // One (tile, row-range) unit of work: C[i0.., j0..] (row pitch ldc) = X[mb..mb+rows, i0..]^T dY[mb..mb+rows, j0..];
 // bias_out[j0..] = column sums of that dY range (blocks of the first row-tile only).
-__device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, int tj, int mb, int rows, float* C,
-                                        int64_t ldc, float* bias_out) {
+// CONV: X is the virtual im2col matrix of an NHWC activation tensor (a.X = tensor base, a.ldx = its size in bytes, cg = the
+// geometry): a lane's column chunk belongs to one tap for the whole tile, its rows are output pixels decoded with shifts.
+template <bool CONV>
+__device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, char* smem_tn, int ti, int tj, int mb, int rows,
+                                        float* C, int64_t ldc, float* bias_out) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wid >> 1, wj = wid & 1;
@@ -1147,7 +1157,8 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
   const int wx = (a.I - i0 < 128) ? a.I - i0 : 128, wy = (a.J - j0 < 128) ? a.J - j0 : 128;
   const int64_t nbx = rows > 0 ? ((int64_t)(rows - 1) * a.ldx + wx) * 2 : 0;
   const int64_t nby = rows > 0 ? ((int64_t)(rows - 1) * a.ldy + wy) * 2 : 0;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)mb * a.ldx + i0), 0, (int)(nbx > 0x7fffffff ? 0x7fffffff : nbx), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = CONV ? __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, a.ldx, 0x00020000)
+                                         : __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)mb * a.ldx + i0), 0, (int)(nbx > 0x7fffffff ? 0x7fffffff : nbx), 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (int64_t)mb * a.ldy + j0), 0, (int)(nby > 0x7fffffff ? 0x7fffffff : nby), 0x00020000);
   // DMA: linear LDS chunk c = tid + 256 i -> row c>>4, physical chunk c&15 holds source chunk (c&15) ^ 4*(row&3)
   int vox[4], voy[4];
@@ -1159,6 +1170,20 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
     voy[i] = (8 * sch < wy) ? (row * a.ldy + 8 * sch) * 2 : 0x7ffffff0;
   }
   const int stepx = TN_BKM * a.ldx * 2, stepy = TN_BKM * a.ldy * 2;
+  // CONV: per-lane constants (the source chunk, hence the tap and channel, do not depend on i: 16 i keeps row & 3)
+  int cv_dy = 0, cv_dx = 0, cv_coff = 0, cv_m = 0;
+  bool cv_colok = false;
+  if constexpr (CONV) {
+    const int row0 = tid >> 4;
+    const int sch = (tid & 15) ^ (4 * (row0 & 3));
+    const int kcol = i0 + 8 * sch;
+    cv_colok = 8 * sch < wx;
+    const int tap = cv_colok ? kcol / cg->C : 0;
+    cv_dy = cg->dy[tap];
+    cv_dx = cg->dx[tap];
+    cv_coff = (kcol - tap * cg->C) * 2;
+    cv_m = mb + row0;   // output pixel of this lane's first row in the next stage
+  }
   // fragment read offsets (bytes): row 8h + (l16>>2) [+16kk, +4], byte in row = (w*128 + i*64 + 32*(g4&1) + 8*(l16&3)) ^ 64*(row&3)
   const int rr = l16 >> 2;
   const int rowb = (8 * h + rr) * 256;
@@ -1193,11 +1218,21 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, char* smem_tn, int ti, 
     char* base = smem_tn + st * 32768 + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16(rx, base + i * 4096, vox[i], 0);
+      if constexpr (CONV) {
+        const int m = cv_m + 16 * i;
+        const int ox = m & (cg->Wo - 1), oy = (m >> cg->lw) & (cg->Ho - 1), b = m >> (cg->lw + cg->lh);
+        const int iy = oy * cg->stride + cv_dy, ix = ox * cg->stride + cv_dx;
+        const bool ok = cv_colok && (m < mb + rows) && ((unsigned)iy < (unsigned)cg->H) && ((unsigned)ix < (unsigned)cg->W);
+        const int vo = ok ? ((b * cg->H + iy) * cg->W + ix) * cg->C * 2 + cv_coff : 0x7ffffff0;
+        glds16(rx, base + i * 4096, vo, 0);
+      } else {
+        glds16(rx, base + i * 4096, vox[i], 0);
+        vox[i] += stepx;
+      }
       glds16(ry, base + 16384 + i * 4096, voy[i], 0);
-      vox[i] += stepx;
       voy[i] += stepy;
     }
+    if constexpr (CONV) cv_m += TN_BKM;
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
   auto compute = [&](int st, int step) {
@@ -1304,7 +1339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
   const int rows = me > mb ? me - mb : 0;
   const int64_t bslot = a.bias_balanced ? (int64_t)split * a.tiles_i + ti : split;
-  tn_tile(a, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
+  tn_tile<false>(a, nullptr, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
           a.bias_part ? a.bias_part + bslot * a.J : nullptr);
 }
 
@@ -1321,14 +1356,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_tail_kernel(TnArgs a, int n_wh
   int ti, tj;
   if ((int)blockIdx.x < n_whole) {
     tile_of_block(xcd_remap(blockIdx.x, n_whole), a.tiles_i, a.tiles_j, ti, tj);
-    tn_tile(a, smem_tn, ti, tj, 0, a.M, a.C, a.J, a.bias_part);
+    tn_tile<false>(a, nullptr, smem_tn, ti, tj, 0, a.M, a.C, a.J, a.bias_part);
     return;
   }
   const int r = blockIdx.x - n_whole, sp = r % S;
   tile_of_block(n_whole + r / S, a.tiles_i, a.tiles_j, ti, tj);
   const int mb = sp * m_per_split;
   const int me = (mb + m_per_split < a.M) ? mb + m_per_split : a.M;
-  tn_tile(a, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, tail_slabs + (int64_t)sp * a.I * W - c0, W,
+  tn_tile<false>(a, nullptr, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, tail_slabs + (int64_t)sp * a.I * W - c0, W,
           a.bias_part ? tail_bias + (int64_t)sp * W - c0 : nullptr);
 }
 // out[r * ldo + c] = sum_s slabs[(s * R + r) * W + c]   (W % 4 == 0, fixed order)
@@ -1472,7 +1507,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
   const int mb = split * a.m_per_split;
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
   const int64_t bslot = a.bias_balanced ? (int64_t)split * a.tiles_i + ti : split;
-  tn_tile(a, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, a.C + (int64_t)split * a.slab_stride, a.J,
+  tn_tile<false>(a, nullptr, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, a.C + (int64_t)split * a.slab_stride, a.J,
           a.bias_part ? a.bias_part + bslot * a.J : nullptr);
 }
 struct ReduceGroup {
@@ -1578,11 +1613,6 @@ extern "C" int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* wor
 // = the SAME zero padding).  The k order (tap-major, channel) and all arithmetic equal the materialised path: results
 // are bit-identical to im2col + gemm_nt.
 // =====================================================================================
-#define CONV_MAX_TAPS 16
-struct ConvGeom {
-  int H, W, C, Ho, Wo, stride, ntaps;
-  int dy[CONV_MAX_TAPS], dx[CONV_MAX_TAPS];
-};
 template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
@@ -1718,7 +1748,7 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.k_per_split = a.K; a.slab_stride = 0; a.prio = 0; a.dbg = nullptr;
   ConvGeom g;
-  g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps;
+  g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = 0; g.lh = 0;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }
   hipStream_t st = (hipStream_t)stream;
   switch (flags) {
@@ -1729,6 +1759,73 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
     case DMI_GEMM_RESIDUAL: return launch_conv<DMI_GEMM_RESIDUAL>(a, g, st);
     case DMI_GEMM_RELU_MASK: return launch_conv<DMI_GEMM_RELU_MASK>(a, g, st);
     default: DMI_REQUIRE(false, "conv_gemm_nt: unsupported epilogue flags %d", flags);
+  }
+  return DMI_OK;
+}
+
+// ---- implicit-im2col weight gradient: dW[(t,c)][n] = sum_pixels x[pixel + tap t][c] * dy[pixel][n] -------------------
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tn_kernel(TnArgs a, ConvGeom g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
+  const int tiles = a.tiles_i * a.tiles_j;
+  const int P = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = P / tiles;
+  int ti, tj;
+  tile_of_block(P - split * tiles, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = split * a.m_per_split;
+  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  tn_tile<true>(a, &g, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, a.C + (int64_t)split * a.slab_stride, a.J,
+                a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
+}
+
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return ((1 << l) == v) ? l : -1;
+}
+extern "C" int64_t dmi_conv_wgrad_tn_workspace_bytes(int M, int K, int N) { return dmi_gemm_tn_workspace_bytes(M, K, N); }
+extern "C" int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps,
+                                 const int* dy, const int* dx, const uint16_t* dY, int ldy, int N, float* dW, float* dbias,
+                                 void* workspace, void* stream) {
+  DMI_REQUIRE(x && dY && dW && dy && dx && workspace, "conv_wgrad_tn: null pointer");
+  DMI_REQUIRE(C % 64 == 0 && ntaps >= 1 && ntaps <= CONV_MAX_TAPS && N % 8 == 0 && ldy % 8 == 0 && ldy >= N,
+              "conv_wgrad_tn: need C%%64==0, 1..16 taps, N/ldy multiples of 8 (C=%d ntaps=%d N=%d)", C, ntaps, N);
+  const int lw = ilog2_exact(Wo), lh = ilog2_exact(Ho);
+  DMI_REQUIRE(lw >= 0 && lh >= 0 && B > 0 && H > 0 && W > 0 && stride >= 1, "conv_wgrad_tn: output dims must be powers of two (Ho=%d Wo=%d)", Ho, Wo);
+  const int64_t xbytes = (int64_t)B * H * W * C * 2, Ml = (int64_t)B * Ho * Wo;
+  DMI_REQUIRE(xbytes < 0x7ffffff0 && Ml < 0x7fffffff, "conv_wgrad_tn: activation tensor too large for 32-bit buffer offsets");
+  DMI_REQUIRE((((uintptr_t)x | (uintptr_t)dY | (uintptr_t)dW | (uintptr_t)workspace) & 15) == 0, "conv_wgrad_tn: 16-byte alignment required");
+  DMI_REQUIRE((int64_t)TN_BKM * ldy * 2 < 0x7fffffff, "conv_wgrad_tn: leading dimension too large");
+  hipStream_t st = (hipStream_t)stream;
+  const int M = (int)Ml, I = ntaps * C, J = N;
+  const int nsplit = tn_splits(M, I, J);
+  float* slabs = (float*)workspace;
+  const int64_t slab_bytes = (nsplit > 1) ? round_up64((int64_t)nsplit * I * J * 4, 256) : 0;
+  TnArgs a;
+  a.X = x; a.Y = dY; a.M = M; a.I = I; a.J = J; a.ldx = (int)xbytes /* descriptor size */; a.ldy = ldy;
+  a.tiles_i = (I + 127) / 128; a.tiles_j = (J + 127) / 128;
+  a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
+  a.C = (nsplit > 1) ? slabs : dW;
+  a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
+  a.prio = 0; a.dbg = nullptr; a.bias_balanced = 0;
+  float* bpart = (float*)((char*)workspace + slab_bytes);
+  a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
+  ConvGeom g;
+  g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = lw; g.lh = lh;
+  for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_done = true; }
+  conv_wgrad_tn_kernel<<<dim3(a.tiles_i * a.tiles_j * nsplit), dim3(256), 65536, st>>>(a, g);
+  DMI_CHECK_LAUNCH("conv_wgrad_tn");
+  if (nsplit > 1) {
+    if (dbias) {
+      reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);
+      DMI_CHECK_LAUNCH("conv_wgrad_tn_bias_reduce");
+    }
+    const int64_t n4 = (int64_t)I * J / 4;
+    int64_t blocks = cdiv64(n4, 256);
+    if (blocks > 2048) blocks = 2048;
+    reduce_slabs_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(slabs, dW, nsplit, n4, n4);
+    DMI_CHECK_LAUNCH("conv_wgrad_tn_reduce");
   }
   return DMI_OK;
 }

@@ -82,6 +82,8 @@ def _declare(L):
         "dmi_transpose_bf16_batch": (I, [P, P, P, I, L64, P]),
         "dmi_im2col": (I, [P, P, I, I, I, I, I, I, I, I, P, P, I, P]),
         "dmi_conv_gemm_nt": (I, [P, I, I, I, I, I, I, I, I, P, P, P, I, P, I, I, I, P, P, P, P]),
+        "dmi_conv_wgrad_tn_workspace_bytes": (L64, [I, I, I]),
+        "dmi_conv_wgrad_tn": (I, [P, I, I, I, I, I, I, I, I, P, P, P, I, I, P, P, P, P]),
         "dmi_weight_gather": (I, [P, P, I, I, I, P, I, P]),
         "dmi_pixel_interleave": (I, [P, P, I, I, I, I, P]),
         "dmi_pad_channels": (I, [P, P, L64, I, I, P]),
@@ -314,6 +316,18 @@ def conv_gemm_nt(x, B, H, W, C, Ho, Wo, stride, taps, Wt, ldw, out, ldc, N, flag
     _check(lib().dmi_conv_gemm_nt(_p(x), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p),
                                   ctypes.cast(dx, c_void_p), _p(Wt), ldw, _p(out), ldc, N, flags,
                                   _p(bias), _p(residual), _p(relu_src), _stream()), "conv_gemm_nt")
+
+
+def conv_wgrad_tn_workspace_bytes(M, K, N):
+    return int(lib().dmi_conv_wgrad_tn_workspace_bytes(M, K, N))
+
+
+def conv_wgrad_tn(x, B, H, W, C, Ho, Wo, stride, taps, dY, ldy, N, dW, ws, dbias=None):
+    """implicit-im2col weight gradient (include/dalle_hip.h: dmi_conv_wgrad_tn); Ho, Wo powers of two, C % 64 == 0."""
+    _dev(x, dY, dW, ws)
+    dy, dx = _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps])
+    _check(lib().dmi_conv_wgrad_tn(_p(x), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p),
+                                   ctypes.cast(dx, c_void_p), _p(dY), ldy, N, _p(dW), _p(dbias), _p(ws), _stream()), "conv_wgrad_tn")
 
 
 def im2col(x, out, B, H, W, C, Ho, Wo, stride, taps, ldo):

@@ -292,6 +292,12 @@ class DiscreteVAE:
     def _w(self, name):
         return self.view(self.pb, name)
 
+    @staticmethod
+    def _implicit_ok(c: _Conv):
+        """layers whose im2col can stay implicit in all three GEMMs: 64-channel-aligned input, power-of-two output grid."""
+        p2 = lambda v: v > 0 and (v & (v - 1)) == 0
+        return c.cin % 64 == 0 and p2(c.Ho) and p2(c.Wo)
+
     def _conv_fwd(self, c: _Conv, x, out, flags=0, residual=None):
         B = self.B
         bias = self._w(c.name + "/bias")
@@ -301,6 +307,11 @@ class DiscreteVAE:
             K = c.kk * c.cin
             Kp = _ru(K, 64)
             taps, s = {"down": (TAPS4, 2), "res": (TAPS3, 1), "final": ([(0, 0)], 1)}[c.kind]
+            if c.kind != "final" and self._implicit_ok(c):
+                # implicit im2col in forward, input gradient and weight gradient: no column matrix for this layer at all
+                dh.conv_gemm_nt(x, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, self.wf[c.name], Kp, out, c.cout, c.cout,
+                                flags | dh.GEMM_BIAS, bias=bias, residual=residual)
+                return
             col = self.col
             if self.keep_cols and c.kind != "final":
                 col = self.col_keep.get(c.name)
@@ -405,6 +416,10 @@ class DiscreteVAE:
         K = c.kk * c.cin
         Kp = _ru(K, 64)
         taps, s = (TAPS4, 2) if c.kind == "down" else (TAPS3, 1)
+        if self._implicit_ok(c):
+            dh.conv_wgrad_tn(x_in, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, dy, c.cout, c.cout, self._gv(c.name + "/kernel"),
+                             self.ws, dbias=self._gv(c.name + "/bias"))
+            return
         col = self.col
         if c.name in self._col_valid:        # the forward pass of this step left col(x_in) in its kept buffer
             col = self.col_keep[c.name]

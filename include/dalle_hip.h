@@ -169,6 +169,15 @@ int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, int Ho, int 
                      const int* dy, const int* dx, const uint16_t* Wt, int ldw, uint16_t* out, int ldc, int N,
                      int flags, const uint16_t* bias, const uint16_t* residual, const uint16_t* relu_src, void* stream);
 
+/* Implicit-im2col weight gradient: dW[(t*C + c)][n] = sum_{b,oy,ox} x[b, oy*stride+dy[t], ox*stride+dx[t], c] * dY[(b,oy,ox)][n]
+ * (+ dbias[n] = column sums of dY, nullable) = dmi_im2col + dmi_gemm_tn without the column matrix; lands in the TF kernel
+ * layout [kh*kw*Cin, Cout] of tf.layers.conv2d (src/vae_tf/models.py:67).  C % 64 == 0, Ho and Wo powers of two.
+ * workspace >= dmi_conv_wgrad_tn_workspace_bytes(B*Ho*Wo, ntaps*C, N). */
+int64_t dmi_conv_wgrad_tn_workspace_bytes(int M, int K, int N);
+int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps,
+                      const int* dy, const int* dx, const uint16_t* dY, int ldy, int N, float* dW, float* dbias,
+                      void* workspace, void* stream);
+
 /* out[(b,oy,ox)][t*C + c] = x[b, oy*stride + dy[t], ox*stride + dx[t], c] (0 outside); row pitch ldo, tail zero-filled.
  * dy/dx are HOST arrays (ntaps <= 16). */
 int dmi_im2col(const uint16_t* x, uint16_t* out, int B, int H, int W, int C, int Ho, int Wo, int stride,

@@ -518,3 +518,29 @@ def test_conv_gemm_nt_equals_im2col_gemm(B, H, W, C, N, stride, kind, flags):
     dh.conv_gemm_nt(x, B, H, W, C, Ho, Wo, stride, taps, Wt, K, out, N, N, flags, **kw)
     assert torch.equal(out, ref)
     assert float(out.float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,H,W,C,N,stride,kind,bias", [(2, 16, 16, 64, 128, 1, "3x3", True), (3, 8, 32, 128, 72, 1, "3x3", False),
+                                                        (2, 32, 32, 64, 64, 2, "4x4", True), (1, 64, 64, 192, 136, 1, "3x3", True)])
+def test_conv_wgrad_tn_equals_im2col_gemm_tn(B, H, W, C, N, stride, kind, bias):
+    """implicit-im2col weight gradient == dmi_im2col + dmi_gemm_tn, bit for bit (same row split, same k order), incl. the
+    fused bias gradient, 64-channel layers (a 128-wide tile spans two taps) and partial last k-tiles."""
+    taps = {"3x3": [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)],
+            "4x4": [(ky - 1, kx - 1) for ky in range(4) for kx in range(4)]}[kind]
+    Ho, Wo = H // stride, W // stride
+    K, M = len(taps) * C, B * Ho * Wo
+    x = rnd(B * H * W, C, seed=1).to(DEV)
+    dY = rnd(M, N, seed=2).to(DEV)
+    col = torch.zeros(M, K, dtype=torch.bfloat16, device=DEV)
+    dh.im2col(x, col, B, H, W, C, Ho, Wo, stride, taps, K)
+    ref = torch.zeros(K, N, dtype=torch.float32, device=DEV)
+    rb = torch.zeros(N, dtype=torch.float32, device=DEV) if bias else None
+    w = ws(dh.gemm_tn_workspace_bytes(M, K, N))
+    dh.gemm_tn(col, K, dY, N, ref, M, K, N, w, dbias=rb)
+    out = torch.full((K, N), 3.0, dtype=torch.float32, device=DEV)
+    ob = torch.full((N,), 3.0, dtype=torch.float32, device=DEV) if bias else None
+    dh.conv_wgrad_tn(x, B, H, W, C, Ho, Wo, stride, taps, dY, N, N, out, ws(dh.conv_wgrad_tn_workspace_bytes(M, K, N)), dbias=ob)
+    assert torch.equal(out, ref)
+    if bias:
+        assert torch.equal(ob, rb)
+    assert float(out.abs().max()) > 0
