@@ -467,11 +467,19 @@ class DiscreteVAE:
                 Mi = B * c.H * c.W
                 Kz = 16 * c.cout
                 Kzp = _ru(Kz, 64)
-                dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, Kzp)     # stride-2 conv view of dz
-                dh.gemm_tn(self.col, Kzp, self.act_in[i], c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, self.ws)
-                dh.colsum(d, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+                p2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 nd = spare[0]
-                dh.gemm_nt(self.col, Kzp, self.wd[c.name], Kzp, nd, c.cin, Mi, c.cin, Kzp)
+                if c.cout % 64 == 0 and p2(c.H) and p2(c.W):
+                    # the transposed conv's backward is a stride-2 4x4 conv of dz: both GEMMs gather dz implicitly
+                    dh.conv_wgrad_tn(d, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, self.act_in[i], c.cin, c.cin,
+                                     self._gv(c.name + "/kernel"), self.ws)
+                    dh.colsum(d, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+                    dh.conv_gemm_nt(d, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, self.wd[c.name], Kzp, nd, c.cin, c.cin)
+                else:
+                    dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, Kzp)     # stride-2 conv view of dz
+                    dh.gemm_tn(self.col, Kzp, self.act_in[i], c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, self.ws)
+                    dh.colsum(d, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+                    dh.gemm_nt(self.col, Kzp, self.wd[c.name], Kzp, nd, c.cin, Mi, c.cin, Kzp)
                 spare[0], d = d, nd
                 i -= 1
             else:  # down
