@@ -1,9 +1,11 @@
 // vae.hip -- data-movement and pointwise kernels of the discrete-VAE path (reference
 // src/vae_tf/models.py:81-163, src/vae_tf/layers.py:4-25).
 //
-// Round-1 lowering of the convolutions: every flavour the reference uses (tf.layers.conv2d 4x4 s2 / 3x3 s1 / 1x1
-// SAME, conv2d_transpose 4x4 s2 SAME; forward, input gradient, weight gradient) is an im2col gather with an
-// explicit tap list followed by the MFMA GEMMs of gemm.hip (NT for fwd / dgrad, TN for wgrad):
+// Convolution lowering: every flavour the reference uses (tf.layers.conv2d 4x4 s2 / 3x3 s1 / 1x1 SAME,
+// conv2d_transpose 4x4 s2 SAME; forward, input gradient, weight gradient) is a tap list feeding the MFMA GEMMs of
+// gemm.hip (NT for fwd / dgrad, TN for wgrad).  Layers with C_in % 64 == 0 gather implicitly inside the GEMM
+// (dmi_conv_gemm_nt / dmi_conv_wgrad_tn); the materialised im2col below serves the 3-channel input layer and is the
+// bit-exact reference of the implicit kernels in the tests:
 //   conv s1/s2 fwd      : taps (ky-pad, kx-pad), stride s           -> Y = col(X) . W^T
 //   conv s1 dgrad       : taps (pad-ky, pad-kx) on dY               -> dX = col(dY) . Wd^T ,  Wd[ci][(k,co)]
 //   conv s2 dgrad / conv-transpose fwd : 4 output-parity classes, 2x2 taps each, then a pixel interleave

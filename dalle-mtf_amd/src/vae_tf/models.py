@@ -1,6 +1,7 @@
 """DiscreteVAE -- same constructor / forward surface as the reference (src/vae_tf/models.py:46-184), re-hosted on
-libdalle_hip: every convolution is a tap-list im2col (dmi_im2col) feeding the MFMA GEMMs (dmi_gemm_nt / dmi_gemm_tn),
-Gumbel-softmax and MSE are dedicated kernels (csrc/vae.hip).  bf16 activations/weights, fp32 accumulation, fp32
+libdalle_hip: every convolution is a tap list feeding the MFMA GEMMs -- gathered implicitly inside the GEMM
+(dmi_conv_gemm_nt / dmi_conv_wgrad_tn) for 64-channel-aligned layers, through a materialised im2col (dmi_im2col +
+dmi_gemm_nt / dmi_gemm_tn) otherwise; Gumbel-softmax and MSE are dedicated kernels (csrc/vae.hip).  bf16 activations/weights, fp32 accumulation, fp32
 master weights and Adam state; the codebook logits are produced in fp32 (reference: fp32 matmul, models.py:113-118).
 
 Layer structure (reference lines): encoder 81-120: per block a 4x4 s2 SAME conv (no activation) then (stack-1) x

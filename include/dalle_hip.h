@@ -159,7 +159,8 @@ int dmi_transpose_bf16_batch(const uint16_t* in_base, uint16_t* out_base, const 
 int dmi_transpose_bf16_padded(const uint16_t* in, uint16_t* out, int R_valid, int R_pitch, int C, void* stream);
 
 /* ================= discrete VAE (src/vae_tf/models.py:81-163, src/vae_tf/layers.py:4-25) =================
- * K11 convolutions = tap-list im2col + dmi_gemm_nt / dmi_gemm_tn (round-1 lowering, see csrc/vae.hip).
+ * K11 convolutions = implicit-im2col GEMMs (dmi_conv_gemm_nt / dmi_conv_wgrad_tn) for 64-channel-aligned layers; the
+ * tap-list dmi_im2col + dmi_gemm_nt / dmi_gemm_tn path serves the 3-channel input layer and is the tested reference.
  * activations NHWC bf16 [B*H*W, C], C % 8 == 0. */
 /* Implicit-im2col convolution: dmi_im2col + dmi_gemm_nt in one kernel, no column matrix in HBM, bit-identical results.
  *   out[(b,oy,ox)][n] = sum_t sum_c x[b, oy*stride + dy[t], ox*stride + dx[t], c] * Wt[n][t*C + c]  (+ epilogue flags)
