@@ -393,10 +393,21 @@ class DalleEngine:
         # measured on MI355X: no gain at dalle_example (22.0 vs 21.7 ms/step; dynamic block dispatch already smooths the
         # partial last round), so split-K is opt-in (hparams["dlogits_splitk"])
         nsplit = 2 if (self.hp.get("dlogits_splitk") and tiles >= 256 and 0.4 <= frac <= 0.75) else 1
+        tail_rows = 0
+        if nsplit == 1 and tiles > 512 and 0.25 <= frac <= 0.75 and os.environ.get("DALLE_DGRAD_TAIL", "1") != "0":
+            # ragged last residency of long (K = vocabulary) blocks: the rows of the last partial round are computed by a
+            # second launch with K split in two, so they also run two blocks per CU (same idea as gemm_tn_tail_kernel)
+            tail_rows = (tiles % 512) // ((d + 127) // 128) * 128
+            tail_rows = min(tail_rows, M) // 128 * 128
+        Wk = self._w("to_logits/linear_out/kernel")
         if nsplit > 1:
-            dh.gemm_nt_splitk(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, M, d, Vp, nsplit, self.ws)
+            dh.gemm_nt_splitk(dz, Vp, Wk, Vp, self.dxn, M, d, Vp, nsplit, self.ws)
+        elif tail_rows > 0 and dh.gemm_nt_splitk_workspace_bytes(tail_rows, d, 2) <= self.ws.numel():
+            head_rows = M - tail_rows
+            dh.gemm_nt(dz, Vp, Wk, Vp, self.dxn, d, head_rows, d, Vp)
+            dh.gemm_nt_splitk(dz[head_rows:], Vp, Wk, Vp, self.dxn[head_rows:], tail_rows, d, Vp, 2, self.ws)
         else:
-            dh.gemm_nt(dz, Vp, self._w("to_logits/linear_out/kernel"), Vp, self.dxn, d, M, d, Vp)
+            dh.gemm_nt(dz, Vp, Wk, Vp, self.dxn, d, M, d, Vp)
         dxa, dxb = self.dx
         dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                          self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)

@@ -82,3 +82,27 @@ def test_microbatched_step_equals_full_batch_step():
     Pt = OrderedDict((k, torch.tensor(v)) for k, v in P0.items())
     ref_loss, _ = do.forward(Pt, tokens, cfg, bf16=False)[:2]
     assert abs(loss_mb - float(ref_loss)) <= 1e-2 * abs(float(ref_loss))
+
+
+def test_head_dgrad_tail_split_matches_single_launch(monkeypatch):
+    """M = 768 row tiles of the [M, d] head input gradient = 1.5 residencies: the last 256 tiles run as a second launch
+    with K split in two.  Same gradients as the single launch up to the fp32 summation order of the two K halves."""
+    from oracle import dalle_oracle as do
+    from src.dalle_mtf.engine import DalleEngine
+    B, T, P = 96, 24, 1000          # S = 1024, M = 98304 = 768 x 128
+    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(B, T, 300, seed=1),
+                                                 do.synthetic_image_tokens(B, P, 40, seed=2), 300)).cuda()
+    grads = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DALLE_DGRAD_TAIL", flag)
+        eng = DalleEngine(128, 1, 1, 300, 40, T, P, batch_size=B, hparams=dict(lr=1e-3, train_steps=10))
+        eng.init_params(seed=7)
+        loss = float(eng.forward(tokens, need_grad=True))
+        eng.backward()
+        torch.cuda.synchronize()
+        grads.append((loss, eng.g.clone()))
+        del eng
+    assert grads[0][0] == grads[1][0]
+    num, den = float((grads[0][1] - grads[1][1]).norm()), float(grads[0][1].norm())
+    assert 0 < den and num <= 5e-3 * den, (num, den)
+    assert num > 0, "the tail-split launch was not taken (identical bits)"
