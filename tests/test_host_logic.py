@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's training scaffolding, on CPU: Estimator loop / checkpoint hooks
+(train_dalle.py:71-98, src/model_fns.py:204-229), config loading (src/utils/utils.py:13-17), mesh-shape parsing, schedules
+(src/model_fns_tf.py:40-45), summaries (src/utils/utils.py:103-161) -- and the rule that the product path has no CPU
+fallback."""
+import json
+import os
+
+import pytest
+import torch
+
+from src import utils
+from src.estimator import (CheckpointSaverHook, Estimator, EstimatorSpec, latest_checkpoint,
+                           load_global_step_from_checkpoint_dir)
+from src.utils import ModeKeys
+
+
+def test_fetch_model_params_by_name_and_path(tmp_path):
+    p = utils.fetch_model_params("dalle_example")
+    assert p["n_embd"] == 512 and p["n_layers"] == 6 and p["text_seq_len"] == 256
+    assert p["this_key_does_not_exist"] is None            # reference: defaultdict(lambda: None)
+    f = tmp_path / "my.json"
+    f.write_text(json.dumps({"model_type": "vae", "lr": 0.5}))
+    q = utils.fetch_model_params(str(f))
+    assert q["lr"] == 0.5 and q["model_type"] == "vae" and q["missing"] is None
+    for name in ("dalle_example", "dalle_coco", "vae_example", "vae_coco"):
+        cfg = utils.fetch_model_params(name)
+        assert cfg["model_type"] in ("dalle", "vae") and cfg["train_batch_size"] > 0
+
+
+def test_parse_mesh_shape_and_mode_to_str():
+    assert utils.parse_mesh_shape("data:16,model:2") == {"data": 16, "model": 2}
+    assert utils.parse_mesh_shape("data:8") == {"data": 8}
+    assert utils.parse_mesh_shape("") == {} and utils.parse_mesh_shape(None) == {}
+    assert [utils.mode_to_str(m) for m in (ModeKeys.TRAIN, ModeKeys.EVAL, ModeKeys.PREDICT)] == ["train", "eval", "predict"]
+
+
+def test_param_count_helper(capsys):
+    n = utils.get_n_trainable_vars({"a": (3, 4), "b": (5,), "c": ()})
+    assert n == 12 + 5 + 1
+    assert "N PARAMS" in capsys.readouterr().out
+
+
+def test_temperature_schedule():
+    from src.model_fns_tf import temperature_schedule as ts
+    p = {"temp_start": 1.0, "temp": 0.05, "temp_anneal_steps": 100}
+    assert ts(0, p) == 1.0 and abs(ts(50, p) - 0.525) < 1e-12 and abs(ts(100, p) - 0.05) < 1e-12 and abs(ts(10 ** 6, p) - 0.05) < 1e-12
+    assert ts(7, {"temp": 0.3}) == 0.3 and ts(7, {}) == 1.0
+
+
+def test_checkpoint_hook_retention_and_latest(tmp_path):
+    d = str(tmp_path / "run")
+    assert latest_checkpoint(d) is None and load_global_step_from_checkpoint_dir(d) == 0
+    state = {"n": 0}
+    hook = CheckpointSaverHook(d, save_steps=2, get_state=lambda: {"w": torch.full((3,), float(state["n"]))}, max_to_keep=3)
+    for step in range(1, 12):
+        state["n"] = step
+        hook.after_step(step)
+    names = sorted(os.listdir(d), key=lambda s: int(s.split("-")[1].split(".")[0]))
+    assert names == ["model.ckpt-6.pt", "model.ckpt-8.pt", "model.ckpt-10.pt"]     # every 2 steps, newest 3 kept
+    assert load_global_step_from_checkpoint_dir(d) == 10
+    sd = torch.load(latest_checkpoint(d))                                            # weights_only default must work
+    assert torch.equal(sd["w"], torch.full((3,), 10.0))
+    assert not [f for f in os.listdir(d) if f.endswith(".tmp")]
+    CheckpointSaverHook(d, 1, lambda: {"w": torch.zeros(1)}, is_chief=False).after_step(11)   # non-chief ranks never write
+    assert load_global_step_from_checkpoint_dir(d) == 10
+    CheckpointSaverHook(None, 1, lambda: {}).after_step(5)                           # no model_dir: silently no checkpoints
+
+
+def test_estimator_loop_contract(tmp_path):
+    """train(): model_fn(features, labels, TRAIN, params) per batch, train_op() returns the global step, hooks see every
+    step, a final checkpoint is written at max_steps, the input iterator is closed; evaluate() averages the loss."""
+    calls = {"train": 0, "eval": 0, "closed": 0, "host": []}
+    state = {"step": 0}
+    saver = CheckpointSaverHook(str(tmp_path / "m"), save_steps=1000, get_state=lambda: {"step": torch.tensor(state["step"])})
+
+    class Feed:
+        def __init__(self):
+            self.i = 0
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            self.i += 1
+            return torch.full((2,), float(self.i)), torch.zeros(2)
+
+        def close(self):
+            calls["closed"] += 1
+
+    def model_fn(features, labels, mode, params):
+        assert params["marker"] == 42
+        if mode == ModeKeys.EVAL:
+            calls["eval"] += 1
+            return EstimatorSpec(mode=mode, loss=features.mean())
+
+        def train_op():
+            calls["train"] += 1
+            state["step"] += 1
+            return state["step"]
+        return EstimatorSpec(mode=mode, loss=features.mean(), train_op=train_op,
+                             host_call=(lambda step, **kv: calls["host"].append((step, sorted(kv))), {"loss": features.mean()}),
+                             training_hooks=[saver])
+
+    logs = []
+
+    class L:
+        info = staticmethod(logs.append)
+
+    est = Estimator(model_fn, str(tmp_path / "m"), {"marker": 42}, log_every=2, logger=L)
+    assert est.train(lambda params: Feed(), max_steps=5) == 5
+    assert calls["train"] == 5 and calls["closed"] == 1
+    assert load_global_step_from_checkpoint_dir(str(tmp_path / "m")) == 5          # final save although 5 % 1000 != 0
+    assert [h[0] for h in calls["host"]] == [2, 4] and any("step 4" in m for m in logs)
+    assert est.train(lambda params: Feed(), max_steps=7) == 7                       # continues from the model's own step
+    out = est.evaluate(lambda params: Feed(), steps=3)
+    assert calls["eval"] == 3 and abs(out["loss"] - 2.0) < 1e-6 and calls["closed"] == 3
+
+
+def test_scalar_summaries_to_jsonl(tmp_path):
+    utils.scalar_summary("loss", torch.tensor(1.5))
+    utils.scalar_summary("lr", 0.25)
+    fn, tensors = utils.create_host_call(str(tmp_path))
+    fn(7, **tensors)
+    rec = json.loads(open(tmp_path / "summaries.jsonl").read().strip().splitlines()[-1])
+    assert rec["step"] == 7 and rec["loss"] == 1.5 and rec["lr"] == 0.25
+
+
+def test_product_path_has_no_cpu_fallback():
+    import dalle_hip as dh
+    cpu = torch.zeros(8, 8, dtype=torch.bfloat16)
+    with pytest.raises(dh.DalleHipError):
+        dh.gemm_nt(cpu, 8, cpu, 8, cpu, 8, 8, 8, 64)
+    with pytest.raises(dh.DalleHipError):
+        dh.layernorm_fwd(cpu, cpu, cpu, cpu, torch.zeros(8), torch.zeros(8), 8, 8)
+    if not torch.cuda.is_available():
+        from src.dalle_mtf.engine import DalleEngine
+        from src.vae_tf import DiscreteVAE
+        with pytest.raises(Exception):
+            DalleEngine(128, 1, 1, 40, 8, 8, 8, batch_size=1, hparams=dict(lr=1e-3, train_steps=10))
+        with pytest.raises(dh.DalleHipError):
+            DiscreteVAE(num_tokens=64, dimensions=16, convblocks=[[2, 64]], batch_size=1)
+
+
+def test_tokenizer_contract_offline():
+    from src.data import get_tokenizer
+    tok = get_tokenizer(None, vocab_size=50258)
+    assert len(tok) == 50258 and tok.encode(tok.pad_token)[0] == 50257     # train_dalle.py:47-49 contract
+    with pytest.raises(NotImplementedError):
+        get_tokenizer("some_other_tokenizer")
