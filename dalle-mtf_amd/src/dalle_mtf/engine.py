@@ -254,6 +254,9 @@ class DalleEngine:
         self.side = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and self.hp.get("wgrad_side_stream", False)) else None
         self._side_done = None
         self._group, self._group_cache, self.ws_group = None, {}, None   # grouped weight gradients (hparams['grouped_wgrad'])
+        # tuning switches: hparams win, environment variables give the default (A/B runs: tools/ab_env.sh)
+        self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
+        self.hp.setdefault("grouped_wgrad", os.environ.get("DALLE_GROUPED_WGRAD", "0") != "0")
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -394,7 +397,7 @@ class DalleEngine:
         # partial last round), so split-K is opt-in (hparams["dlogits_splitk"])
         nsplit = 2 if (self.hp.get("dlogits_splitk") and tiles >= 256 and 0.4 <= frac <= 0.75) else 1
         tail_rows = 0
-        if nsplit == 1 and tiles > 512 and 0.25 <= frac <= 0.75 and os.environ.get("DALLE_DGRAD_TAIL", "1") != "0":
+        if nsplit == 1 and tiles > 512 and 0.25 <= frac <= 0.75 and self.hp["dgrad_tail_split"]:
             # ragged last residency of long (K = vocabulary) blocks: the rows of the last partial round are computed by a
             # second launch with K split in two, so they also run two blocks per CU (same idea as gemm_tn_tail_kernel)
             tail_rows = (tiles % 512) // ((d + 127) // 128) * 128
@@ -415,7 +418,7 @@ class DalleEngine:
         for bi, l in enumerate(reversed(range(L))):
             p = f"layer_{l}/"
             st = self.stats[l]
-            if self.side is None and self.hp.get("grouped_wgrad", os.environ.get("DALLE_GROUPED_WGRAD", "0") != "0"):
+            if self.side is None and self.hp["grouped_wgrad"]:
                 self._group = []
             # FFN
             self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
