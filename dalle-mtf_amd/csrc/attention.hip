@@ -356,40 +356,14 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16
 // =====================================================================================
 // backward
 // =====================================================================================
-// delta[b,h,s] = sum_d dO[b,s,h,d] * O[b,s,h,d];  also stats[b,h,s] = (lse, delta) pairs for the dK/dV kernel's DMA
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ d_o,
-                                                         const float* __restrict__ lse, float* __restrict__ delta,
-                                                         float* __restrict__ stats, int B, int H, int S) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
-  if (row >= (int64_t)B * S) return;
-  const int d = H * HD;
-  const int b = (int)(row / S), s = (int)(row % S);
-  for (int c0 = 0; c0 < d / 8; c0 += 64) {
-    const int c = c0 + lane;
-    float acc = 0.f;
-    if (c < d / 8) {
-      float fo[8], fd[8];
-      unpack8(*(const u32x4*)(o + row * d + c * 8), fo);
-      unpack8(*(const u32x4*)(d_o + row * d + c * 8), fd);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc += fo[j] * fd[j];
-    }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((lane & 15) == 0 && c < d / 8) {
-      const int64_t idx = ((int64_t)b * H + c / 16) * S + s;
-      delta[idx] = acc;
-      stats[2 * idx] = lse[idx];
-      stats[2 * idx + 1] = acc;
-    }
-  }
-}
-
 // dQ kernel v2: same K / V natural-tile DMA ring as the forward.  S^T = K Q^T and dP^T = V dO^T read tile rows with
 // ds_read_b128; dQ^T += K^T dS^T takes K^T fragments from the SAME K tile with hardware transpose reads.
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+// The kernel also produces delta[q] = sum_d dO[q,d] O[q,d] itself (a lane pair holds the whole dO row of its query as MFMA
+// fragments; O is read in the same layout) and publishes the (lse, delta) pairs the dK/dV kernel streams in -- the
+// separate delta pass (17 us per layer) is gone.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
+                                                             const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, float* __restrict__ stats,
                                                              bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
@@ -417,7 +391,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     dof[kk] = *(const bf16x8*)(dob + (int64_t)qrow_c * d + 16 * kk + 8 * h);
   }
   const float lse_q = lse[(int64_t)bh * S + qrow_c];
-  const float delta_q = delta[(int64_t)bh * S + qrow_c];
+  float delta_q = 0.f;
+  {
+    const bf16_t* ob = o + (int64_t)b * S * d + hh * HD;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      float fo[8], fd[8];
+      unpack8(*(const u32x4*)(ob + (int64_t)qrow_c * d + 16 * kk + 8 * h), fo);
+      unpack8(__builtin_bit_cast(u32x4, dof[kk]), fd);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) delta_q += fo[j] * fd[j];
+    }
+    delta_q += __shfl_xor(delta_q, 32, 64);   // the other half of the row lives in lane ^ 32
+    if (h == 0 && qrow < S) {
+      const int64_t idx = (int64_t)bh * S + qrow;
+      delta[idx] = delta_q;
+      stats[2 * idx] = lse_q;
+      stats[2 * idx + 1] = delta_q;
+    }
+  }
 
   int vo[4];
 #pragma unroll
@@ -761,8 +753,6 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const 
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_bwd: sequence too long for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
   float* stats = delta + (int64_t)B * H * S;  // delta scratch is [3][B,H,S]: delta | (lse, delta) pairs
-  attn_delta_kernel<<<dim3((unsigned)cdiv64((int64_t)B * S, 4)), dim3(256), 0, st>>>(o, d_o, lse, delta, stats, B, H, S);
-  DMI_CHECK_LAUNCH("attention_delta");
   static bool attr_done = false;
   const int shm = 32768 + DKV_NSTAGE * DKV_STAGE;
   if (!attr_done) {
@@ -770,7 +760,7 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const 
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     attr_done = true;
   }
-  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, d_o, lse, delta, dqkv, B, H, S, g_opt_attn_xcd);
+  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dq");
   attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
