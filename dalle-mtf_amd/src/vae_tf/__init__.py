@@ -1,1 +1,4 @@
-from .models import DiscreteVAE  # noqa: F401
+"""Discrete VAE on libdalle_hip (implicit-im2col MFMA convolutions, Gumbel-softmax, MSE)."""
+from .models import DiscreteVAE
+
+__all__ = ["DiscreteVAE"]
