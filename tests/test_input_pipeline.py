@@ -290,3 +290,44 @@ def test_missing_and_too_small_datasets_fail_loudly(tmp_path):
     _make_dataset(tmp_path, n=3, per_file=5)
     with pytest.raises(ValueError):
         next(input_fns.dalle_input_fn(_params(tmp_path, batch_size=4), eval=True))
+
+
+# ---------------------------------------------------------------- property tests (hypothesis)
+
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+_i64 = st.integers(min_value=-(2 ** 63), max_value=2 ** 63 - 1)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.dictionaries(st.text(st.characters(min_codepoint=33, max_codepoint=126), min_size=1, max_size=12),
+                       st.one_of(st.lists(st.binary(max_size=40), min_size=1, max_size=4),
+                                 st.lists(_i64, min_size=1, max_size=20)),
+                       max_size=5))
+def test_example_codec_roundtrip_property(features):
+    """any mix of bytes / int64 features survives encode -> decode, and the real protobuf runtime reads the same values."""
+    buf = tfr.encode_example(features)
+    assert tfr.decode_example(buf) == {k: list(v) for k, v in features.items()}
+    ex = _example_class()()
+    ex.ParseFromString(buf)
+    for k, v in features.items():
+        f = ex.features.feature[k]
+        got = list(f.bytes_list.value) if isinstance(v[0], bytes) else list(f.int64_list.value)
+        assert got == list(v)
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.lists(st.binary(max_size=300), max_size=12))
+def test_record_container_roundtrip_property(tmp_path_factory, records):
+    p = str(tmp_path_factory.mktemp("rec") / "x.tfrecords")
+    tfr.write_records(p, records)
+    assert list(tfr.read_records(p, verify_crc=True)) == records
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.lists(st.integers(min_value=0, max_value=50256), max_size=600), st.integers(min_value=1, max_value=300))
+def test_truncate_or_pad_label_property(ids, T):
+    out = input_fns.truncate_or_pad_label(ids, {"text_seq_len": T, "padding_id": 50257})
+    assert out.shape == (T,) and out.dtype == np.int32
+    n = min(len(ids), T)
+    assert out[:n].tolist() == ids[:n] and (out[n:] == 50257).all()
