@@ -340,9 +340,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }
 }
 
-extern "C" int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16_t* o, float* lse, int B, int H,
-                                 int S, void* stream) {
-  (void)vt;  // v2 reads V^T fragments with hardware transpose reads of the natural V tile
+extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int H, int S, void* stream) {
   DMI_REQUIRE(qkv && o && lse, "attention_fwd: null pointer");
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_fwd: S must be a multiple of 8 (S=%d)", S);
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_fwd: sequence too long for 32-bit buffer offsets");
@@ -744,10 +742,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   }
 }
 
-extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
-                                 const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
+extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta,
                                  uint16_t* dqkv, int B, int H, int S, void* stream) {
-  (void)qt; (void)kt; (void)dot;  // v2 kernels fetch every transposed fragment with hardware transpose reads
   DMI_REQUIRE(qkv && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_bwd: S must be a multiple of 8 (S=%d)", S);
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_bwd: sequence too long for 32-bit buffer offsets");

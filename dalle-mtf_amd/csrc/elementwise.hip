@@ -69,47 +69,105 @@ __global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const bf16_t* __rest
     *(f32x4*)(o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
   }
 }
-// dwte[tok, :] += dx[row, :]   (fp32 hardware atomics; scatter-add = gradient of gather, Appendix A.6)
-__global__ __launch_bounds__(256) void embed_bwd_wte_kernel(const int* __restrict__ tokens,
-                                                            const bf16_t* __restrict__ dx, float* __restrict__ dwte,
-                                                            int64_t rows, int d, int vocab) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
-  if (row >= rows) return;
-  int tok = tokens[row];
-  tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-  float* dst = dwte + (int64_t)tok * d;
-  for (int c = lane; c < d / 8; c += 64) {
-    float f[8];
-    unpack8(*(const u32x4*)(dx + row * d + c * 8), f);
+// ---- stable sort of the token ids (index plumbing for the scatter-add below) -----------------------------------------
+// One 1024-thread block, LSD radix sort with 4-bit digits: thread t owns the contiguous chunk [t*cpt, (t+1)*cpt) of the
+// current order, counts its digits into its own column of hist[16][1024] (no atomics), a block-wide exclusive scan in
+// (digit, thread) order turns the counts into destinations, and the thread scatters its chunk in order -> stable and
+// deterministic.  ceil(log2(vocab) / 4) passes ping-pong between (sorted, perm) and the workspace; the last pass lands in
+// the outputs.  The ids are known when the forward starts, so the engine runs this on a side stream under the forward.
+#define SORT_T 1024
+__global__ __launch_bounds__(SORT_T) void sort_tokens_kernel(const int* __restrict__ tokens, int* __restrict__ out_key,
+                                                             int* __restrict__ out_perm, int* __restrict__ tmp_key,
+                                                             int* __restrict__ tmp_perm, int n, int vocab, int npass) {
+  extern __shared__ __attribute__((aligned(16))) char sort_sm[];
+  int* hist = (int*)sort_sm;              // [16][SORT_T]
+  int* wtot = hist + 16 * SORT_T;         // [16] wave totals
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  const int cpt = (n + SORT_T - 1) / SORT_T;
+  const int i0 = t * cpt < n ? t * cpt : n;
+  const int i1 = i0 + cpt < n ? i0 + cpt : n;
+  for (int p = 0; p < npass; ++p) {
+    const int shift = 4 * p;
+    const bool to_out = ((npass - 1 - p) & 1) == 0;
+    const int* sk = (p == 0) ? tokens : (to_out ? tmp_key : out_key);
+    const int* sp = to_out ? tmp_perm : out_perm;
+    int* dk = to_out ? out_key : tmp_key;
+    int* dp = to_out ? out_perm : tmp_perm;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dst + c * 8 + j, f[j]);
+    for (int d = 0; d < 16; ++d) hist[d * SORT_T + t] = 0;
+    for (int i = i0; i < i1; ++i) {
+      int k = sk[i];
+      k = k < 0 ? 0 : (k >= vocab ? vocab - 1 : k);
+      hist[((k >> shift) & 15) * SORT_T + t] += 1;
+    }
+    __syncthreads();
+    // exclusive scan over the 16 * 1024 counts in linear (digit-major) order; thread t owns entries [16 t, 16 t + 16)
+    int loc[16], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      loc[j] = hist[16 * t + j];
+      tot += loc[j];
+    }
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += v;
+    }
+    if (lane == 63) wtot[wid] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int w = 0; w < wid; ++w) base += wtot[w];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      hist[16 * t + j] = base;
+      base += loc[j];
+    }
+    __syncthreads();
+    for (int i = i0; i < i1; ++i) {
+      int k = sk[i];
+      k = k < 0 ? 0 : (k >= vocab ? vocab - 1 : k);
+      const int slot = ((k >> shift) & 15) * SORT_T + t;
+      const int pos = hist[slot];
+      hist[slot] = pos + 1;
+      dk[pos] = k;
+      dp[pos] = (p == 0) ? i : sp[i];
+    }
+    __threadfence_block();
+    __syncthreads();
   }
 }
-
-extern "C" int dmi_embed_bwd(const int32_t* tokens, const uint16_t* dx, float* dwte, float* dwpe, int B, int S,
-                             int d, int vocab, void* stream) {
-  DMI_REQUIRE(tokens && dx && dwte && dwpe, "embed_bwd: null pointer");
-  DMI_REQUIRE(d % 8 == 0 && B > 0 && S > 0, "embed_bwd: bad sizes");
-  hipStream_t st = (hipStream_t)stream;
-  embed_bwd_wpe_kernel<<<dim3((S + 3) / 4), dim3(256), 0, st>>>(dx, dwpe, B, S, d);
-  DMI_CHECK_LAUNCH("embed_bwd_wpe");
-  const int64_t rows = (int64_t)B * S;
-  embed_bwd_wte_kernel<<<dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, st>>>(tokens, dx, dwte, rows, d, vocab);
-  DMI_CHECK_LAUNCH("embed_bwd_wte");
+extern "C" int64_t dmi_sort_tokens_workspace_bytes(int64_t n) { return 2 * n * 4 + 256; }
+extern "C" int dmi_sort_tokens(const int32_t* tokens, int32_t* sorted_tokens, int32_t* perm, int64_t n, int vocab,
+                               void* workspace, void* stream) {
+  DMI_REQUIRE(tokens && sorted_tokens && perm && workspace, "sort_tokens: null pointer");
+  DMI_REQUIRE(n > 0 && n < (1ll << 30) && vocab > 0, "sort_tokens: bad sizes");
+  int bits = 1;
+  while ((1ll << bits) < vocab) ++bits;
+  const int npass = (bits + 3) / 4;
+  static bool attr_done = false;
+  const int shm = 16 * SORT_T * 4 + 64;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)sort_tokens_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
+  int* tk = (int*)workspace;
+  sort_tokens_kernel<<<dim3(1), dim3(SORT_T), shm, (hipStream_t)stream>>>(tokens, sorted_tokens, perm, tk, tk + n, (int)n, vocab, npass);
+  DMI_CHECK_LAUNCH("sort_tokens");
   return DMI_OK;
 }
 
-// Sorted scatter-add: positions are visited in token-id order (sorted_tok ascending, perm = source row).
-// One wave per chunk of 32 sorted positions accumulates each run of equal ids in registers; a run that
-// lies entirely inside the chunk is stored directly (single writer), only runs crossing a chunk border
-// use fp32 atomics -> the hot padding id costs n/32 atomics per column instead of n.
+// ---- scatter-add = gradient of mtf.gather (Appendix A.6), deterministic, no atomics -------------------------------
+// Positions are visited in token-id order (sorted_tok ascending, perm = source row).  One wave per chunk of 32 sorted
+// positions accumulates each run of equal ids in registers.  A run that lies entirely inside its chunk is stored
+// directly (single writer).  The chunk's first / last run may continue in the neighbouring chunks (the padding id fills
+// hundreds of chunks): those partial sums go to part[chunk][0 / 1][d], and a second kernel lets the wave of the chunk
+// where such a run STARTS add the partials of the following chunks in chunk order.  dwte is zeroed here (ids absent
+// from the batch have zero gradient).
 #define EB_CH 32
+__device__ __forceinline__ int eb_clamp(int t, int vocab) { return t < 0 ? 0 : (t >= vocab ? vocab - 1 : t); }
 __global__ __launch_bounds__(256) void embed_bwd_wte_sorted_kernel(const int* __restrict__ sorted_tok,
                                                                    const int* __restrict__ perm,
                                                                    const bf16_t* __restrict__ dx,
-                                                                   float* __restrict__ dwte, int64_t n, int d,
-                                                                   int vocab) {
+                                                                   float* __restrict__ dwte, float* __restrict__ part,
+                                                                   int64_t n, int d, int vocab) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
   const int64_t i0 = chunk * EB_CH;
@@ -120,23 +178,19 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_sorted_kernel(const int* __
   for (int c = lane; c < d / 8; c += 64) {
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int cur = first_tok;
-    bool open = head_open;
+    bool open = head_open;   // the run being accumulated started before this chunk
+    bool first = true;       // ... and is the chunk's first run
     for (int64_t i = i0; i < i1; ++i) {
       const int t = sorted_tok[i];
-      if (t != cur) {
-        const int tc = cur < 0 ? 0 : (cur >= vocab ? vocab - 1 : cur);
-        float* dst = dwte + (int64_t)tc * d + c * 8;
-        if (open) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dst + j, acc[j]);
-        } else {
-          *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
-          *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-        }
+      if (t != cur) {   // run [.., i) ended inside the chunk
+        float* dst = open ? part + ((int64_t)chunk * 2 + 0) * d + c * 8 : dwte + (int64_t)eb_clamp(cur, vocab) * d + c * 8;
+        *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         cur = t;
         open = false;
+        first = false;
       }
       float f[8];
       unpack8(*(const u32x4*)(dx + (int64_t)perm[i] * d + c * 8), f);
@@ -144,29 +198,59 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_sorted_kernel(const int* __
       for (int j = 0; j < 8; ++j) acc[j] += f[j];
     }
     const bool tail_open = (i1 < n) && (sorted_tok[i1] == cur);
-    const int tc = cur < 0 ? 0 : (cur >= vocab ? vocab - 1 : cur);
-    float* dst = dwte + (int64_t)tc * d + c * 8;
-    if (open || tail_open) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) unsafeAtomicAdd(dst + j, acc[j]);
-    } else {
-      *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
-      *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    float* dst;
+    if (open || tail_open) dst = part + ((int64_t)chunk * 2 + (first ? 0 : 1)) * d + c * 8;
+    else dst = dwte + (int64_t)eb_clamp(cur, vocab) * d + c * 8;
+    *(f32x4*)dst = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+// the chunk's LAST run, if it continues into the next chunk and did not start before this chunk, owns the row: add the
+// slot-0 partials of the following chunks while they continue the same id (fixed order -> deterministic)
+__global__ __launch_bounds__(256) void embed_bwd_wte_combine_kernel(const int* __restrict__ sorted_tok, float* __restrict__ dwte,
+                                                                    const float* __restrict__ part, int64_t n, int d, int vocab) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + wid;
+  const int64_t i0 = chunk * EB_CH;
+  if (i0 >= n) return;
+  const int64_t i1 = (i0 + EB_CH < n) ? i0 + EB_CH : n;
+  if (i1 >= n) return;                                  // last chunk: nothing continues
+  const int tok = sorted_tok[i1 - 1];
+  if (sorted_tok[i1] != tok) return;                    // last run is closed at the tail
+  const bool single = sorted_tok[i0] == tok;            // the whole chunk is one run
+  if (single && i0 > 0 && sorted_tok[i0 - 1] == tok) return;   // a continuation, not a start
+  const int slot = single ? 0 : 1;
+  const int64_t nchunks = (n + EB_CH - 1) / EB_CH;
+  for (int c = lane; c < d / 4; c += 64) {
+    f32x4 acc = *(const f32x4*)(part + ((int64_t)chunk * 2 + slot) * d + c * 4);
+    for (int64_t k = chunk + 1; k < nchunks; ++k) {
+      const int64_t k0 = k * EB_CH, k1 = (k0 + EB_CH < n) ? k0 + EB_CH : n;
+      if (sorted_tok[k0] != tok) break;
+      const f32x4 v = *(const f32x4*)(part + ((int64_t)k * 2 + 0) * d + c * 4);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      if (sorted_tok[k1 - 1] != tok || k1 >= n || sorted_tok[k1] != tok) break;   // the run ends in chunk k
     }
+    *(f32x4*)(dwte + (int64_t)eb_clamp(tok, vocab) * d + c * 4) = acc;
   }
 }
 
-extern "C" int dmi_embed_bwd_sorted(const int32_t* sorted_tokens, const int32_t* perm, const uint16_t* dx, float* dwte,
-                                    float* dwpe, int B, int S, int d, int vocab, void* stream) {
-  DMI_REQUIRE(sorted_tokens && perm && dx && dwte && dwpe, "embed_bwd_sorted: null pointer");
-  DMI_REQUIRE(d % 8 == 0 && B > 0 && S > 0, "embed_bwd_sorted: bad sizes");
+extern "C" int64_t dmi_embed_bwd_workspace_bytes(int B, int S, int d) {
+  return (((int64_t)B * S + EB_CH - 1) / EB_CH) * 2 * d * 4 + 256;
+}
+extern "C" int dmi_embed_bwd(const int32_t* sorted_tokens, const int32_t* perm, const uint16_t* dx, float* dwte,
+                             float* dwpe, int B, int S, int d, int vocab, void* workspace, void* stream) {
+  DMI_REQUIRE(sorted_tokens && perm && dx && dwte && dwpe && workspace, "embed_bwd: null pointer");
+  DMI_REQUIRE(d % 8 == 0 && B > 0 && S > 0 && vocab > 0, "embed_bwd: bad sizes");
   hipStream_t st = (hipStream_t)stream;
   embed_bwd_wpe_kernel<<<dim3((S + 3) / 4), dim3(256), 0, st>>>(dx, dwpe, B, S, d);
   DMI_CHECK_LAUNCH("embed_bwd_wpe");
+  DMI_REQUIRE(hipMemsetAsync(dwte, 0, (size_t)vocab * d * 4, st) == hipSuccess, "embed_bwd: memset failed");
   const int64_t n = (int64_t)B * S;
   const int64_t chunks = cdiv64(n, EB_CH);
-  embed_bwd_wte_sorted_kernel<<<dim3((unsigned)cdiv64(chunks, 4)), dim3(256), 0, st>>>(sorted_tokens, perm, dx, dwte, n, d, vocab);
+  embed_bwd_wte_sorted_kernel<<<dim3((unsigned)cdiv64(chunks, 4)), dim3(256), 0, st>>>(sorted_tokens, perm, dx, dwte, (float*)workspace, n, d, vocab);
   DMI_CHECK_LAUNCH("embed_bwd_wte_sorted");
+  embed_bwd_wte_combine_kernel<<<dim3((unsigned)cdiv64(chunks, 4)), dim3(256), 0, st>>>(sorted_tokens, dwte, (const float*)workspace, n, d, vocab);
+  DMI_CHECK_LAUNCH("embed_bwd_wte_combine");
   return DMI_OK;
 }
 
@@ -540,7 +624,7 @@ extern "C" int dmi_transpose_bf16_batch(const uint16_t* in_base, uint16_t* out_b
   return DMI_OK;
 }
 
-int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int Rv, int Rp, int C,
+static int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int Rv, int Rp, int C,
                          int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride, void* stream) {
   DMI_REQUIRE(in && out, "transpose: null pointer");
   DMI_REQUIRE(Rp % 8 == 0 && Rp >= Rv && C % 8 == 0 && in_r_stride % 8 == 0 && in_h_stride % 8 == 0 && in_b_stride % 8 == 0,
@@ -550,16 +634,11 @@ int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int 
   DMI_CHECK_LAUNCH("transpose");
   return DMI_OK;
 }
-extern "C" int dmi_transpose_bf16_strided(const uint16_t* in, uint16_t* out, int nb, int nh, int R, int C,
-                                          int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride,
-                                          void* stream) {
-  return dmi_transpose_padded(in, out, nb, nh, R, R, C, in_b_stride, in_h_stride, in_r_stride, stream);
-}
 extern "C" int dmi_transpose_bf16_padded(const uint16_t* in, uint16_t* out, int R_valid, int R_pitch, int C, void* stream) {
   return dmi_transpose_padded(in, out, 1, 1, R_valid, R_pitch, C, 0, 0, C, stream);
 }
 extern "C" int dmi_transpose_bf16(const uint16_t* in, uint16_t* out, int batch, int R, int C, void* stream) {
-  return dmi_transpose_bf16_strided(in, out, batch, 1, R, C, (int64_t)R * C, 0, C, stream);
+  return dmi_transpose_padded(in, out, batch, 1, R, R, C, (int64_t)R * C, 0, C, stream);
 }
 
 // =====================================================================================
@@ -789,6 +868,188 @@ extern "C" int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, fl
     cross_entropy_kernel<<<dim3((unsigned)M), dim3(256), 0, st>>>(z, ldz, labels, loss_rows, lse, V, dz_scale);
   }
   DMI_CHECK_LAUNCH("cross_entropy");
+  return DMI_OK;
+}
+
+// =====================================================================================
+// Fused softmax head (training path): the cross entropy of models.py:348-359 without a logits round trip.
+//   dmi_label_logit      zl[m] = x[m,:] . Wt[label[m],:] + bias[label[m]]        (fp32; also the per-row shift of the exponent)
+//   dmi_gemm_nt_softmax  E[m,v] = bf16(exp(logit[m,v] - zl[m])) + partial row sums  (gemm.hip)
+//   dmi_softmax_finish   S[m] = sum_v exp(.) ;  loss_row[m] = log S[m]  (= logsumexp - label logit, exactly the reference's
+//                        loss_batch);  rowscale[m] = dz_scale / S[m];  E[m,label] -= S[m]  (so that dlogits = rowscale * E);
+//                        Xs[m,:] = bf16(rowscale[m] * x[m,:])  (the weight-gradient GEMM's left operand: dW = Xs^T E)
+// label logit as the shift: exp(logit - zl) cannot underflow for any entry that matters (the label entry itself is 1) and
+// overflows only if some logit exceeds the label's by > 88, i.e. the row's loss is > 88 nats; such rows (sum = inf) are
+// flagged and redone exactly by softmax_fixup_kernel with the row maximum as the shift.
+// =====================================================================================
+__global__ __launch_bounds__(256) void label_logit_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Wt,
+                                                          int ldw, const bf16_t* __restrict__ bias, const int* __restrict__ labels,
+                                                          float* __restrict__ zl, int* __restrict__ flag, int64_t M, int K, int V) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0) flag[0] = 0;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wid;
+  if (row >= M) return;
+  int lab = labels[row];
+  lab = lab < 0 ? 0 : (lab >= V ? V - 1 : lab);
+  const bf16_t* xr = X + row * ldx;
+  const bf16_t* wr = Wt + (int64_t)lab * ldw;
+  float acc = 0.f;
+  for (int c = lane; c < K / 8; c += 64) {
+    float a[8], b[8];
+    unpack8(*(const u32x4*)(xr + c * 8), a);
+    unpack8(*(const u32x4*)(wr + c * 8), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(a[j], b[j], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) zl[row] = acc + bf2f(bias[lab]);
+}
+extern "C" int dmi_label_logit(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
+                               const int32_t* labels, float* zl, int32_t* flag, int64_t M, int K, int V, void* stream) {
+  DMI_REQUIRE(X && Wt && bias && labels && zl && flag, "label_logit: null pointer");
+  DMI_REQUIRE(M > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 && V > 0, "label_logit: bad sizes");
+  label_logit_kernel<<<dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream>>>(X, ldx, Wt, ldw, bias, labels, zl, flag, M, K, V);
+  DMI_CHECK_LAUNCH("label_logit");
+  return DMI_OK;
+}
+
+struct SoftmaxFinishArgs {
+  const float* part; int nparts;
+  const int* labels;
+  const bf16_t* X; int ldx;
+  bf16_t* E; int lde;
+  float* loss_rows; float* rowscale; bf16_t* rowscale_bf16; bf16_t* Xs;
+  int* flag;
+  int64_t M; int K, V;
+  float dz_scale;
+};
+__global__ __launch_bounds__(256) void softmax_finish_kernel(SoftmaxFinishArgs a) {
+  __shared__ float sm[4][64];
+  __shared__ float sc[64];
+  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * 64, m = m0 + r;
+  float s = 0.f;
+  if (m < a.M)
+    for (int p = q; p < a.nparts; p += 4) s += a.part[(int64_t)p * a.M + m];   // fixed order: deterministic
+  sm[q][r] = s;
+  __syncthreads();
+  if (q == 0) {
+    float scale = 0.f;
+    if (m < a.M) {
+      const float S = ((sm[0][r] + sm[1][r]) + sm[2][r]) + sm[3][r];
+      const bool bad = !(S > 0.f && S < 3.0e38f);   // inf / nan (an exponent overflowed) or an empty row
+      if (bad) a.flag[0] = 1;
+      a.loss_rows[m] = bad ? INFINITY : __logf(S);
+      scale = bad ? 0.f : a.dz_scale / S;
+      if (a.dz_scale != 0.f) {
+        a.rowscale[m] = scale;
+        a.rowscale_bf16[m] = f2bf(scale);
+        int lab = a.labels[m];
+        lab = lab < 0 ? 0 : (lab >= a.V ? a.V - 1 : lab);
+        bf16_t* el = a.E + m * a.lde + lab;
+        *el = f2bf(bf2f(*el) - S);   // dlogits[m, label] = rowscale * (e_label - S) = dz_scale * (p_label - 1)
+      }
+    }
+    sc[r] = scale;
+  }
+  __syncthreads();
+  if (a.dz_scale == 0.f) return;
+  const int cpr = a.K / 8;
+  for (int idx = tid; idx < 64 * cpr; idx += 256) {
+    const int rr = idx / cpr, ch = idx - rr * cpr;
+    const int64_t mm = m0 + rr;
+    if (mm >= a.M) break;
+    float f[8];
+    unpack8(*(const u32x4*)(a.X + mm * a.ldx + ch * 8), f);
+    const float k = sc[rr];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= k;
+    *(u32x4*)(a.Xs + mm * a.K + ch * 8) = pack8(f);
+  }
+}
+// Exact redo of the flagged rows (loss_rows[m] == inf): logits recomputed from x and Wt with the row maximum as the shift.
+#define FIX_MAXK 8192
+__global__ __launch_bounds__(256) void softmax_fixup_kernel(SoftmaxFinishArgs a, const bf16_t* __restrict__ Wt, int ldw,
+                                                            const bf16_t* __restrict__ bias, int N) {
+  if (a.flag[0] == 0) return;
+  __shared__ float xs[FIX_MAXK];
+  __shared__ float red[4];
+  __shared__ float zlab;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int64_t m = blockIdx.x; m < a.M; m += gridDim.x) {
+    if (a.loss_rows[m] < 3.0e38f) continue;   // block-uniform
+    __syncthreads();
+    for (int k = tid; k < a.K; k += 256) xs[k] = bf2f(a.X[m * a.ldx + k]);
+    int lab = a.labels[m];
+    lab = lab < 0 ? 0 : (lab >= a.V ? a.V - 1 : lab);
+    __syncthreads();
+    auto logit = [&](int v) {
+      const bf16_t* wr = Wt + (int64_t)v * ldw;
+      float acc = 0.f;
+      for (int c = lane; c < a.K / 8; c += 64) {
+        float b[8];
+        unpack8(*(const u32x4*)(wr + c * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_fmaf(xs[c * 8 + j], b[j], acc);
+      }
+      return wave_sum(acc) + bf2f(bias[v]);
+    };
+    float mx = -INFINITY;
+    for (int v = wid; v < a.V; v += 4) {
+      const float z = logit(v);
+      mx = fmaxf(mx, z);
+      if (v == lab && lane == 0) zlab = z;
+    }
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float zl = zlab;
+    __syncthreads();
+    float sum = 0.f;
+    for (int v = wid; v < N; v += 4) {
+      const float e = (v < a.V) ? __expf(logit(v) - mx) : 0.f;
+      sum += e;
+      if (lane == 0) a.E[m * a.lde + v] = f2bf(e);
+    }
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    const float S = ((red[0] + red[1]) + red[2]) + red[3];
+    const float scale = a.dz_scale / S;
+    __syncthreads();   // E row complete (block scope) before the label entry is patched
+    if (tid == 0) {
+      a.loss_rows[m] = mx + __logf(S) - zl;
+      if (a.dz_scale != 0.f) {
+        a.rowscale[m] = scale;
+        a.rowscale_bf16[m] = f2bf(scale);
+        a.E[m * a.lde + lab] = f2bf(__expf(zl - mx) - S);
+      }
+    }
+    if (a.dz_scale != 0.f)
+      for (int k = tid * 8; k < a.K; k += 256 * 8) {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = xs[k + j] * scale;
+        *(u32x4*)(a.Xs + m * a.K + k) = pack8(f);
+      }
+  }
+}
+extern "C" int dmi_softmax_finish(const float* rowsum_part, int nparts, const int32_t* labels, const uint16_t* X, int ldx,
+                                  const uint16_t* Wt, int ldw, const uint16_t* bias, uint16_t* E, int lde, int N,
+                                  float* loss_rows, float* rowscale, uint16_t* rowscale_bf16, uint16_t* Xs, int32_t* flag,
+                                  int64_t M, int K, int V, float dz_scale, void* stream) {
+  DMI_REQUIRE(rowsum_part && labels && X && Wt && bias && E && loss_rows && flag, "softmax_finish: null pointer");
+  DMI_REQUIRE(dz_scale == 0.f || (rowscale && rowscale_bf16 && Xs), "softmax_finish: gradient outputs missing");
+  DMI_REQUIRE(M > 0 && K % 8 == 0 && K <= FIX_MAXK && ldx % 8 == 0 && ldw % 8 == 0 && nparts > 0 && V > 0 && V <= N && N <= lde,
+              "softmax_finish: bad sizes (K <= %d)", FIX_MAXK);
+  SoftmaxFinishArgs a;
+  a.part = rowsum_part; a.nparts = nparts; a.labels = labels; a.X = X; a.ldx = ldx; a.E = E; a.lde = lde;
+  a.loss_rows = loss_rows; a.rowscale = rowscale; a.rowscale_bf16 = rowscale_bf16; a.Xs = Xs; a.flag = flag;
+  a.M = M; a.K = K; a.V = V; a.dz_scale = dz_scale;
+  hipStream_t st = (hipStream_t)stream;
+  softmax_finish_kernel<<<dim3((unsigned)cdiv64(M, 64)), dim3(256), 0, st>>>(a);
+  DMI_CHECK_LAUNCH("softmax_finish");
+  softmax_fixup_kernel<<<dim3(256), dim3(256), 0, st>>>(a, Wt, ldw, bias, N);   // returns at once unless a row was flagged
+  DMI_CHECK_LAUNCH("softmax_fixup");
   return DMI_OK;
 }
 

@@ -1,58 +1,41 @@
-// gemm.hip -- MFMA GEMMs for the dense layers of the DALL-E step (SURVEY.md §2.2 K3,K5,K6,K7).
+// gemm.hip -- MFMA GEMMs for the dense layers of the DALL-E step (SURVEY.md §2.2 K3,K5,K6,K7) and the VAE convolutions.
 //
-// NT kernel:  C[M,N] = A[M,K] . Bt[N,K]^T, bf16 operands (both K-contiguous), fp32 accumulate on
-//   v_mfma_f32_32x32x16_bf16.  128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles.
-//   LDS: two stages x (A 16 KiB + B 16 KiB) = 64 KiB -> 2 blocks / CU.  Rows are 128 B (8 x 16-B chunks);
-//   chunk index is XOR-swizzled with (row>>1)&7 so that the ds_read_b128 fragment reads of a 16-lane group
-//   hit 16 distinct 16-B slots of the 256-B bank row (conflict-free).  Staging is either
-//     GLDS=1: global_load_lds_dwordx4 (LDS-DMA; destination lane-linear, swizzle applied on the SOURCE
-//             address -- cdna_hip_programming.md §5.4 rule 21), or
-//     GLDS=0: global_load_dwordx4 -> registers -> ds_write_b128 (issue before compute, write after).
-//   The MFMA operand roles are swapped (weights as the A-operand) so each lane ends up with ONE output row
-//   and 4 consecutive columns per accumulator quad -> 8-byte bf16 / 16-byte fp32 stores.
-//   blockIdx -> tile: bijective XCD remap (block b runs on XCD b%8) then GROUP_M-grouped ordering so the
-//   8 A-tiles x all-B-tiles of a group stay in that XCD's 4 MiB L2.
-//   Split-K (gridDim.y) writes fp32 partial slabs reduced deterministically by reduce_slabs_kernel.
+// NT kernels:  C[M,N] = A[M,K] . Bt[N,K]^T, bf16 operands (both K-contiguous), fp32 accumulate on
+//   v_mfma_f32_32x32x16_bf16.  Two tilings share one epilogue:
+//     gemm_nt2_kernel  128x128x64 block tile, 4 waves (2x2) of 64x64, 2 LDS stages x 32 KiB -> 2 blocks / CU;
+//     gemm_nt4_kernel  256x128x32 block tile, 4 waves of 128x64, 2 stages x 24 KiB (K <= 1024 and >= 3 residencies).
+//   Staging is LDS-DMA (buffer_load_dwordx4 ... lds) through a per-block buffer descriptor: the destination is
+//   lane-linear, so the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied on the SOURCE
+//   address (cdna_hip_programming.md §5.4 rule 21).  The MFMA operand roles are swapped (weights as the A-operand) so
+//   each lane ends up with ONE output row.  blockIdx -> tile: bijective XCD remap (block b runs on XCD b%8) then
+//   GROUP_M-grouped ordering so the 8 A-tiles x all-B-tiles of a group stay in that XCD's 4 MiB L2.
+//   Split-K (gridDim.y) writes fp32 partial slabs reduced deterministically.
+//   Epilogues (compile-time flags): bias, ReLU, residual, ReLU-mask, per-row scale, and the softmax-numerator epilogue
+//   of the vocabulary projection (see gemm_nt_softmax below).
 //
 // TN kernel (weight gradients): dW[I,J] = sum_m X[m,I] dY[m,J].  The contraction index is the ROW of both
 //   operands, so fragments are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose read) from
 //   natural-layout LDS tiles filled by LDS-DMA (XOR-swizzled on the source side => conflict-free).
+//
+// The measured-slower generations of these kernels (register-staged v1, persistent v3, hand-scheduled 3-stage v5,
+// grouped / stream-K weight gradients) live on the git branch `r01-kernel-variants`, not in the product library.
 #include "common.h"
 #include <string.h>
 
-static int g_opt_glds = 1;
-static int g_opt_tn_trread = 1;
-static int g_opt_nt2 = 1;
-static int g_opt_prio = 0;
-static int g_opt_nt4 = 1;
-static int g_opt_nt5 = 0;  // hand-scheduled 3-stage kernel (0 off, 2 = 256x128 tiles, 3 = 128x128 tiles): bit-identical, measured equal
-                           // to v2/v4 within noise on every shape of the model (tools/ksweep.py) -- kept as a tested option
-int g_opt_attn_xcd = 8;  // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
-static int g_opt_tn_streamk = 1;  // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
+static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
+int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
+static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;
 extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
-static int g_opt_nt3 = 0;  // persistent variant: bit-identical, measured 5-12 % slower than per-tile launches (kept as a tested option)
 extern "C" int dmi_get_option(const char* name) {
-  if (!strcmp(name, "glds")) return g_opt_glds;
-  if (!strcmp(name, "tn_trread")) return g_opt_tn_trread;
-  if (!strcmp(name, "nt2")) return g_opt_nt2;
-  if (!strcmp(name, "prio")) return g_opt_prio;
   if (!strcmp(name, "nt4")) return g_opt_nt4;
-  if (!strcmp(name, "nt3")) return g_opt_nt3;
-  if (!strcmp(name, "nt5")) return g_opt_nt5;
-  if (!strcmp(name, "tn_streamk")) return g_opt_tn_streamk;
+  if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
-  if (!strcmp(name, "glds")) { g_opt_glds = value; return 0; }
-  if (!strcmp(name, "tn_trread")) { g_opt_tn_trread = value; return 0; }
-  if (!strcmp(name, "nt2")) { g_opt_nt2 = value; return 0; }
-  if (!strcmp(name, "prio")) { g_opt_prio = value; return 0; }
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
-  if (!strcmp(name, "nt3")) { g_opt_nt3 = value; return 0; }
-  if (!strcmp(name, "nt5")) { g_opt_nt5 = value; return 0; }
-  if (!strcmp(name, "tn_streamk")) { g_opt_tn_streamk = value; return 0; }
+  if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
   return -1;
 }
@@ -69,13 +52,16 @@ struct GemmArgs {
   const bf16_t* bias;
   const bf16_t* residual;
   const bf16_t* relu_src;
+  const float* rowscale;   // DMI_GEMM_ROWSCALE: fp32 [M], C[m, :] *= rowscale[m]
+  const float* rowshift;   // GEMM_SOFTMAX: fp32 [M], C[m, n] = exp(acc + bias - rowshift[m])
+  float* rowsum_part;      // GEMM_SOFTMAX: fp32 [ceil(N/64)][M] partial row sums of the fp32 exponentials
   int M, N, K, lda, ldb, ldc;
   int tiles_m, tiles_n;
   int k_per_split;     // multiple of BK
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
-  int prio;             // raise wave priority around the MFMA clusters (co-resident blocks run at different phases)
 };
+#define GEMM_SOFTMAX 64   // internal epilogue flag of dmi_gemm_nt_softmax (not part of the public flag set)
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
@@ -92,150 +78,6 @@ __device__ __forceinline__ void tile_of_block(int L, int tiles_m, int tiles_n, i
 
 // byte offset inside a [128][64] bf16 LDS tile of the 16-B chunk `ch` (0..7) of row `row`
 __device__ __forceinline__ int lds_chunk_off(int row, int ch) { return (row * 8 + (ch ^ ((row >> 1) & 7))) * 16; }
-
-template <bool GLDS>
-struct Stager {
-  u32x4 r[4];
-  // tile rows [row0, row0+128) of a [rows_total, ld] bf16 matrix, k range [k0, k0+64)
-  __device__ __forceinline__ void issue(const bf16_t* __restrict__ base, int ld, int row0, int rows_total, int k0,
-                                        char* lds_tile, int tid) {
-    const int chp = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid >> 3) + 32 * i;
-      int gr = row0 + row;
-      gr = gr < rows_total ? gr : rows_total - 1;
-      const int src_ch = chp ^ ((row >> 1) & 7);
-      const bf16_t* gp = base + (int64_t)gr * ld + k0 + 8 * src_ch;
-      if constexpr (GLDS) {
-        // wave-uniform LDS base; each lane lands at base + lane*16  (chunk c = tid + 256 i)
-        char* lbase = lds_tile + ((tid & ~63) + 256 * i) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
-                                         (__attribute__((address_space(3))) void*)lbase, 16, 0, 0);
-      } else {
-        r[i] = *(const u32x4*)gp;
-      }
-    }
-  }
-  __device__ __forceinline__ void commit(char* lds_tile, int tid) {
-    if constexpr (!GLDS) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) *(u32x4*)(lds_tile + (tid + 256 * i) * 16) = r[i];
-    }
-  }
-};
-
-template <int FLAGS, bool GLDS>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int r = lane & 31, h = lane >> 5;
-
-  int tm, tn;
-  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kb = blockIdx.y * a.k_per_split;
-  const int ke = (kb + a.k_per_split < a.K) ? kb + a.k_per_split : a.K;
-  const int nt = (ke - kb) / BK;
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  Stager<GLDS> sa, sb;
-  sa.issue(a.A, a.lda, m0, a.M, kb, smem, tid);
-  sb.issue(a.B, a.ldb, n0, a.N, kb, smem + 16384, tid);
-  sa.commit(smem, tid);
-  sb.commit(smem + 16384, tid);
-  if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    char* cur = smem + (t & 1) * 32768;
-    char* nxt = smem + ((t + 1) & 1) * 32768;
-    const bool more = (t + 1 < nt);
-    if (more) {
-      sa.issue(a.A, a.lda, m0, a.M, kb + (t + 1) * BK, nxt, tid);
-      sb.issue(a.B, a.ldb, n0, a.N, kb + (t + 1) * BK, nxt + 16384, tid);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
-      const int ch = kk * 2 + h;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *(const bf16x8*)(cur + lds_chunk_off(wm * 64 + i * 32 + r, ch));
-        fb[i] = *(const bf16x8*)(cur + 16384 + lds_chunk_off(wn * 64 + i * 32 + r, ch));
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
-    }
-    if (more) {
-      sa.commit(nxt, tid);
-      sb.commit(nxt + 16384, tid);
-      if constexpr (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-  }
-
-  // epilogue: lane owns row m = ..+r ; acc quad q holds columns n = ..+8q+4h+{0..3}
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + r;
-    if (m >= a.M) continue;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
-        if (n >= a.N) continue;
-        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        const int64_t off = (int64_t)m * a.ldc + n;
-        if constexpr (FLAGS & DMI_GEMM_BIAS) {
-          const u32x2 bb = *(const u32x2*)(a.bias + n);
-          v[0] += __uint_as_float(bb[0] << 16);
-          v[1] += __uint_as_float(bb[0] & 0xffff0000u);
-          v[2] += __uint_as_float(bb[1] << 16);
-          v[3] += __uint_as_float(bb[1] & 0xffff0000u);
-        }
-        if constexpr (FLAGS & DMI_GEMM_RELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-        }
-        if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
-          const u32x2 rr = *(const u32x2*)(a.residual + off);
-          v[0] += __uint_as_float(rr[0] << 16);
-          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-          v[2] += __uint_as_float(rr[1] << 16);
-          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-        }
-        if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
-          const u32x2 hh = *(const u32x2*)(a.relu_src + off);
-          // relu'(x) = (x > 0): post-relu activations are >= 0, so "> 0" <=> nonzero and sign clear
-          v[0] = (__uint_as_float(hh[0] << 16) > 0.f) ? v[0] : 0.f;
-          v[1] = (__uint_as_float(hh[0] & 0xffff0000u) > 0.f) ? v[1] : 0.f;
-          v[2] = (__uint_as_float(hh[1] << 16) > 0.f) ? v[2] : 0.f;
-          v[3] = (__uint_as_float(hh[1] & 0xffff0000u) > 0.f) ? v[3] : 0.f;
-        }
-        if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
-          float* cp = (float*)a.C + (int64_t)blockIdx.y * a.slab_stride + off;
-          *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          bf16_t* cp = (bf16_t*)a.C + off;
-          *(u32x2*)cp = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-        }
-      }
-    }
-  }
-}
 
 // =====================================================================================
 // NT kernel v2: same tiling/swizzle as gemm_nt_kernel, with
@@ -259,6 +101,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
   const int orow = lane >> 3, ocol = (lane & 7) * 8;
   const int n = ncol0 + ocol;
   const bool nok = n < a.N;
+  constexpr float LOG2E = 1.4426950408889634f;
   float bias[8];
   if constexpr (FLAGS & DMI_GEMM_BIAS) {
     u32x4 braw = {0, 0, 0, 0};
@@ -268,6 +111,8 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     u32x4 rres[4], rsrc[4];
+    float rsc[4];   // per-row fp32 scalars (row scale / softmax shift) of the 4 store iterations
+    float psum[4];  // softmax: fp32 sum of this lane's 8 exponentials per store iteration
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int m = mrow0 + i * 32 + it * 8 + orow;
@@ -275,6 +120,8 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
       const bool ok = nok && m < a.M;
       if constexpr (FLAGS & DMI_GEMM_RESIDUAL) rres[it] = ok ? *(const u32x4*)(a.residual + off) : u32x4{0, 0, 0, 0};
       if constexpr (FLAGS & DMI_GEMM_RELU_MASK) rsrc[it] = ok ? *(const u32x4*)(a.relu_src + off) : u32x4{0, 0, 0, 0};
+      if constexpr (FLAGS & DMI_GEMM_ROWSCALE) rsc[it] = (m < a.M) ? a.rowscale[m] : 0.f;
+      if constexpr (FLAGS & GEMM_SOFTMAX) rsc[it] = (m < a.M) ? a.rowshift[m] * LOG2E : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -310,7 +157,33 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
       }
+      if constexpr (FLAGS & DMI_GEMM_ROWSCALE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= rsc[it];
+      }
+      if constexpr (FLAGS & GEMM_SOFTMAX) {  // exp(v - shift) as one fma + v_exp_f32; the fp32 values feed the row sum
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], LOG2E, -rsc[it]));
+          ps += v[e];
+        }
+        psum[it] = nok ? ps : 0.f;
+      }
       if (nok && m < a.M) *(u32x4*)((bf16_t*)a.C + (int64_t)m * a.ldc + n) = pack8(v);
+    }
+    if constexpr (FLAGS & GEMM_SOFTMAX) {
+      // the 8 lanes of a row (lane & 7) hold its 64 columns: butterfly over xor 1, 2, 4 (fixed order -> deterministic),
+      // then lane (orow, 0) writes the row's partial to slot ncol0 / 64 of the [slots][M] table.
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float ps = psum[it];
+        ps += __shfl_xor(ps, 1, 64);
+        ps += __shfl_xor(ps, 2, 64);
+        ps += __shfl_xor(ps, 4, 64);
+        const int m = mrow0 + i * 32 + it * 8 + orow;
+        if ((lane & 7) == 0 && m < a.M && ncol0 < a.N) a.rowsum_part[(int64_t)(ncol0 >> 6) * a.M + m] = ps;
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -379,7 +252,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
   };
   auto compute = [&](int st) {
     const char* cur = smem + st * 32768;
-    if (a.prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[2], fb[2];
@@ -394,7 +266,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
-    if (a.prio) __builtin_amdgcn_s_setprio(0);
   };
 
   stage(0, 0);
@@ -434,189 +305,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
   } else {
     epilogue_bf16<FLAGS, 2>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 64, n0 + wn * 64);
   }
-}
-
-// =====================================================================================
-// NT kernel v3 (persistent): grid = min(#tiles, 2 x 256 CUs); a block walks tiles b, b+grid, ... (same XCD remap /
-// grouped order, so co-resident blocks still share operand panels in L2).  The first K-stage of the NEXT tile is
-// DMA-issued before the LAST MFMA block of the current tile, so the per-tile prologue latency hides behind compute
-// and the epilogue, and the epilogue's global stores drain under the next tile's first MFMA block.
-// Requirements: bf16 output, no split-K, K/64 even (stage parity is compile-time).  Epilogue staging lives in the
-// stage-1 half of LDS (wave-private 32 x 64 fp32, XOR-swizzled 16-B chunks instead of padding).
-// =====================================================================================
-template <int FLAGS>
-__global__ __launch_bounds__(256, 2) void gemm_nt3_kernel(GemmArgs a, int ntiles) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int r = lane & 31, h = lane >> 5;
-  const int nt = a.K / BK;  // even
-
-  int offa[4], offb[4];
-#pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    offa[kk] = lds_chunk_off(wm * 64 + r, kk * 2 + h);
-    offb[kk] = 16384 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
-  }
-  const int chp = tid & 7;
-  int rowv[4], swzv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    rowv[i] = (tid >> 3) + 32 * i;
-    swzv[i] = 16 * (chp ^ ((rowv[i] >> 1) & 7));
-  }
-
-  f32x16 acc[2][2];
-  auto zero_acc = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  };
-  auto compute = [&](int st) {
-    const char* cur = smem + st * 32768;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
-        fb[i] = *(const bf16x8*)(cur + offb[kk] + i * 4096);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
-    }
-  };
-
-  struct Tile {
-    int m0, n0;
-    __amdgpu_buffer_rsrc_t ra, rb;
-    int voa[4], vob[4];
-  };
-  auto setup = [&](int vb, Tile& t) {
-    int tm, tn;
-    tile_of_block(xcd_remap(vb, ntiles), a.tiles_m, a.tiles_n, tm, tn);
-    t.m0 = tm * BM;
-    t.n0 = tn * BN;
-    t.ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)t.m0 * a.lda), 0, 0x7fffffff, 0x00020000);
-    t.rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)t.n0 * a.ldb), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ra_ = t.m0 + rowv[i] < a.M ? rowv[i] : a.M - 1 - t.m0;
-      const int rb_ = t.n0 + rowv[i] < a.N ? rowv[i] : a.N - 1 - t.n0;
-      t.voa[i] = ra_ * a.lda * 2 + swzv[i];
-      t.vob[i] = rb_ * a.ldb * 2 + swzv[i];
-    }
-  };
-  auto stage = [&](const Tile& t, int st, int soff) {
-    char* base = smem + st * 32768 + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(t.ra, base + i * 4096, t.voa[i], soff);
-      glds16(t.rb, base + 16384 + i * 4096, t.vob[i], soff);
-    }
-  };
-#define NT3_RAW_BARRIER()                              \
-  do {                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                      \
-  } while (0)
-
-  int vb = blockIdx.x;
-  Tile cur, nxt;
-  setup(vb, cur);
-  stage(cur, 0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  while (true) {
-    const int vbn = vb + gridDim.x;
-    const bool has_next = vbn < ntiles;
-    zero_acc();
-    for (int t = 0; t < nt; t += 2) {
-      stage(cur, 1, (t + 1) * BK * 2);
-      compute(0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (t + 2 < nt) {
-        stage(cur, 0, (t + 2) * BK * 2);
-        compute(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      } else {
-        if (has_next) {
-          setup(vbn, nxt);
-          stage(nxt, 0, 0);  // next tile's first K-stage: in flight during the last MFMA block and the epilogue
-        }
-        compute(1);
-        NT3_RAW_BARRIER();   // everyone finished reading stage 1 (it becomes the epilogue staging area); DMA stays in flight
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // only the prefetch DMA is outstanding here (issued one MFMA block ago)
-
-    // ---- epilogue: wave-private fp32 staging in the stage-1 half, 32 rows x 64 cols, chunk ^= (row & 15)
-    float* stg = (float*)(smem + 32768 + wid * 8192);
-    const int orow = lane >> 3, oc2 = (lane & 7) * 2;  // read: row it*8+orow, 16-B chunks oc2, oc2+1
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ch = j * 8 + 2 * q + h;  // 16-B chunk (4 fp32) of columns j*32 + 8q + 4h ..
-          *(f32x4*)(stg + r * 64 + ((ch ^ (r & 15)) << 2)) =
-              f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = it * 8 + orow;
-        const int m = cur.m0 + wm * 64 + i * 32 + row;
-        const int n = cur.n0 + wn * 64 + oc2 * 4;
-        const f32x4 lo = *(const f32x4*)(stg + row * 64 + ((oc2 ^ (row & 15)) << 2));
-        const f32x4 hi = *(const f32x4*)(stg + row * 64 + (((oc2 + 1) ^ (row & 15)) << 2));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (m < a.M && n < a.N) {
-          const int64_t off = (int64_t)m * a.ldc + n;
-          if constexpr (FLAGS & DMI_GEMM_BIAS) {
-            float b[8];
-            unpack8(*(const u32x4*)(a.bias + n), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += b[e];
-          }
-          if constexpr (FLAGS & DMI_GEMM_RELU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-          if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
-            float b[8];
-            unpack8(*(const u32x4*)(a.residual + off), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += b[e];
-          }
-          if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
-            float b[8];
-            unpack8(*(const u32x4*)(a.relu_src + off), b);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (b[e] > 0.f) ? v[e] : 0.f;
-          }
-          *(u32x4*)((bf16_t*)a.C + off) = pack8(v);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (!has_next) break;
-    NT3_RAW_BARRIER();  // staging reads done everywhere + everyone's share of the prefetched stage 0 landed (vmcnt(0) above)
-    vb = vbn;
-    cur = nxt;
-  }
-#undef NT3_RAW_BARRIER
 }
 
 // =====================================================================================
@@ -725,173 +413,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   }
 }
 
-// =====================================================================================
-// NT GEMM v5: hand-scheduled main loop.  hipcc schedules the fragment ds_reads of v2/v4 with a minimal register
-// footprint (4 reads -> wait -> 1 MFMA -> wait -> 3 MFMAs -> 2 reads -> wait ...), exposing an LDS round trip three
-// times per 8 MFMAs, and both kernels prefetch only one k-step ahead (vmcnt(0) + barrier every step).  Here:
-//   * fragment reads are inline-asm ds_read_b128 into two register sets; the set for k-substep s+1 is issued before
-//     the 8 (MI=4) / 4 (MI=2) MFMAs of substep s and waited for (lgkmcnt) after them;
-//   * a ring of 3 LDS stages (BK = 32) with counted vmcnt keeps two stages of LDS-DMA in flight; one raw s_barrier per
-//     step, placed between the two substeps so the DMA issue + next reads are covered by the second MFMA cluster.
-// Tile = (64*MI) x 128: MI = 4 -> 256x128, 72 KiB LDS, 2 blocks / CU; MI = 2 -> 128x128, 48 KiB, 3 blocks / CU.
-// =====================================================================================
-template <int MI>
-struct Frag5 {
-  u32x4 a[MI];
-  u32x4 b[2];
-};
-template <int OFF>
-__device__ __forceinline__ void f5_issue(Frag5<4>& f, unsigned va, unsigned vb) {
-  asm volatile(
-      "ds_read_b128 %4, %7 offset:%8\n\t"
-      "ds_read_b128 %0, %6 offset:%8\n\t"
-      "ds_read_b128 %5, %7 offset:%9\n\t"
-      "ds_read_b128 %1, %6 offset:%9\n\t"
-      "ds_read_b128 %2, %6 offset:%10\n\t"
-      "ds_read_b128 %3, %6 offset:%11"
-      : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.a[2]), "=&v"(f.a[3]), "=&v"(f.b[0]), "=&v"(f.b[1])
-      : "v"(va), "v"(vb), "i"(OFF), "i"(OFF + 2048), "i"(OFF + 4096), "i"(OFF + 6144)
-      : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void f5_issue(Frag5<2>& f, unsigned va, unsigned vb) {
-  asm volatile(
-      "ds_read_b128 %2, %5 offset:%6\n\t"
-      "ds_read_b128 %0, %4 offset:%6\n\t"
-      "ds_read_b128 %3, %5 offset:%7\n\t"
-      "ds_read_b128 %1, %4 offset:%7"
-      : "=&v"(f.a[0]), "=&v"(f.a[1]), "=&v"(f.b[0]), "=&v"(f.b[1])
-      : "v"(va), "v"(vb), "i"(OFF), "i"(OFF + 2048)
-      : "memory");
-}
-// Ordering pins (hipcc freely moves the pure MFMA builtins across asm statements otherwise -- it sank the fragment
-// issue below 6 of the 8 MFMAs it was meant to hide under):
-//   f5_pin(cur):        names the set the next MFMAs consume as "+v" -> those MFMAs are scheduled after this point;
-//   f5_wait(f, acc...): names the accumulators as "+v" -> every MFMA issued so far is scheduled before the wait.
-__device__ __forceinline__ void f5_pin(Frag5<4>& f) {
-  asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
-}
-__device__ __forceinline__ void f5_pin(Frag5<2>& f) {
-  asm volatile("" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]) : : "memory");
-}
-__device__ __forceinline__ void f5_wait(Frag5<4>& f, f32x16 (&c)[4][2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]),
-                 "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1]), "+v"(c[2][0]), "+v"(c[2][1]), "+v"(c[3][0]), "+v"(c[3][1])
-               :
-               : "memory");
-}
-__device__ __forceinline__ void f5_wait(Frag5<2>& f, f32x16 (&c)[2][2]) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.b[0]), "+v"(f.b[1]), "+v"(c[0][0]), "+v"(c[0][1]), "+v"(c[1][0]), "+v"(c[1][1])
-               :
-               : "memory");
-}
-
-template <int FLAGS, int MI>
-__global__ __launch_bounds__(256, (MI == 4 ? 2 : 3)) void gemm_nt5_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][A (64*MI rows x 64 B) | B 8 KiB]
-  constexpr int TM = 64 * MI;            // tile rows
-  constexpr int ASZ = TM * 64;           // bytes of the A part of a stage
-  constexpr int STG = ASZ + 8192;
-  constexpr int NL = MI + 2;             // LDS-DMA instructions per wave per stage
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int r = lane & 31, h = lane >> 5;
-
-  int tm, tn;
-  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
-  const int m0 = tm * TM, n0 = tn * BN;
-  const int nt = a.K / BK4;
-
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)n0 * a.ldb), 0, 0x7fffffff, 0x00020000);
-  int voa[MI], vob[2];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
-    const int rr = m0 + row < a.M ? row : a.M - 1 - m0;
-    voa[i] = (rr * a.lda + 8 * (pc ^ ((row >> 2) & 3))) * 2;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
-    const int rn = n0 + row < a.N ? row : a.N - 1 - n0;
-    vob[i] = (rn * a.ldb + 8 * (pc ^ ((row >> 2) & 3))) * 2;
-  }
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  unsigned va[2], vb[2];  // per-lane fragment addresses of k-substep 0 / 1 inside a stage
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    va[kk] = lds0 + lds4_off(wm * (32 * MI) + r, kk * 2 + h);
-    vb[kk] = lds0 + ASZ + lds4_off(wn * 64 + r, kk * 2 + h);
-  }
-
-  f32x16 acc[MI][2];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  auto stage = [&](int st, int t) {  // st compile-time after unrolling
-    char* base = smem + st * STG + wid * 1024;
-    const int soff = t * (BK4 * 2);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) glds16(ra, base + i * 4096, voa[i], soff);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) glds16(rb, base + ASZ + i * 4096, vob[i], soff);
-  };
-  auto mfmas = [&](Frag5<MI>& f) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[j]), __builtin_bit_cast(bf16x8, f.a[i]),
-                                                            acc[i][j], 0, 0, 0);  // D[n][m]
-  };
-  Frag5<MI> F0, F1;
-
-#define NT5_STEP(S, T)                                                                \
-  {                                                                                   \
-    f5_wait(F0, acc);                                                                 \
-    f5_issue<(S) * STG>(F1, va[1], vb[1]);                                            \
-    f5_pin(F0);                                                                       \
-    mfmas(F0);                                                                        \
-    f5_wait(F1, acc);                                                                 \
-    if ((T) + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory"); \
-    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");              \
-    if ((T) + 3 < nt) stage((S), (T) + 3);                                            \
-    if ((T) + 1 < nt) f5_issue<(((S) + 1) % 3) * STG>(F0, va[0], vb[0]);              \
-    f5_pin(F1);                                                                       \
-    mfmas(F1);                                                                        \
-  }
-
-  stage(0, 0);
-  if (nt > 1) stage(1, 1);
-  if (nt > 2) stage(2, 2);
-  if (nt > 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NL) : "memory");
-  else if (nt > 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NL) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  f5_issue<0>(F0, va[0], vb[0]);
-  int t = 0;
-  for (; t + 3 <= nt; t += 3) {  // single-exit loop: stage indices stay compile-time, accumulators stay in place
-    NT5_STEP(0, t);
-    NT5_STEP(1, t + 1);
-    NT5_STEP(2, t + 2);
-  }
-  if (t < nt) {
-    NT5_STEP(0, t);
-    if (t + 1 < nt) NT5_STEP(1, t + 1);
-  }
-#undef NT5_STEP
-
-  // epilogue (all fragment reads were completed before the last barrier)
-  epilogue_bf16<FLAGS, MI>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * (32 * MI), n0 + wn * 64);
-}
-
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int nsplit, int64_t n4, int64_t stride4) {
@@ -908,25 +429,10 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
-  const size_t shm = 65536;
   if constexpr (!(FLAGS & DMI_GEMM_OUT_F32)) {
-    if (g_opt_nt5 >= 2 && nsplit == 1 && a.k_per_split == a.K) {
-      GemmArgs b = a;
-      if (g_opt_nt5 == 2) {
-        static bool attr5 = false;
-        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<FLAGS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 73728); attr5 = true; }
-        b.tiles_m = (a.M + 255) / 256;
-        gemm_nt5_kernel<FLAGS, 4><<<dim3(b.tiles_m * a.tiles_n), blk, 73728, st>>>(b);
-      } else {
-        static bool attr5 = false;
-        if (!attr5) { (void)hipFuncSetAttribute((const void*)gemm_nt5_kernel<FLAGS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152); attr5 = true; }
-        gemm_nt5_kernel<FLAGS, 2><<<dim3(a.tiles_m * a.tiles_n), blk, 49152, st>>>(b);
-      }
-      DMI_CHECK_LAUNCH("gemm_nt5");
-      return DMI_OK;
-    }
     const int tiles4 = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
-    if (g_opt_nt4 && g_opt_nt2 && g_opt_glds && nsplit == 1 && a.k_per_split == a.K && ((tiles4 >= 1536 && a.K <= 1024) || g_opt_nt4 == 2)) {  // 2 = force (tests); long-K shapes prefer the BK=64 kernel
+    // 256x128 tiles when the grid still covers >= 3 residencies; long-K shapes prefer the BK = 64 kernel.  2 = force (tests)
+    if (g_opt_nt4 && nsplit == 1 && a.k_per_split == a.K && ((tiles4 >= 1536 && a.K <= 1024) || g_opt_nt4 == 2)) {
       static bool attr4 = false;
       if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152); attr4 = true; }
       GemmArgs b = a;
@@ -935,28 +441,10 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
       DMI_CHECK_LAUNCH("gemm_nt4");
       return DMI_OK;
     }
-    const int ntiles = a.tiles_m * a.tiles_n;
-    if (g_opt_nt3 && g_opt_nt2 && g_opt_glds && nsplit == 1 && a.k_per_split == a.K && (a.K / BK) % 2 == 0 && ntiles > 512) {
-      static bool attr3 = false;
-      if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_nt3_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr3 = true; }
-      gemm_nt3_kernel<FLAGS><<<dim3(512), blk, shm, st>>>(a, ntiles);
-      DMI_CHECK_LAUNCH("gemm_nt3");
-      return DMI_OK;
-    }
   }
-  if (g_opt_nt2 && g_opt_glds) {
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_done = true; }
-    gemm_nt2_kernel<FLAGS><<<grid, blk, shm, st>>>(a);
-  } else if (g_opt_glds) {
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_done = true; }
-    gemm_nt_kernel<FLAGS, true><<<grid, blk, shm, st>>>(a);
-  } else {
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<FLAGS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); attr_done = true; }
-    gemm_nt_kernel<FLAGS, false><<<grid, blk, shm, st>>>(a);
-  }
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_done = true; }
+  gemm_nt2_kernel<FLAGS><<<grid, blk, 65536, st>>>(a);
   DMI_CHECK_LAUNCH("gemm_nt");
   return DMI_OK;
 }
@@ -969,19 +457,26 @@ static int check_nt(const void* A, int lda, const void* B, int ldb, const void* 
   return DMI_OK;
 }
 
+static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc, int M, int N, int K) {
+  a.A = A; a.B = Bt; a.C = C; a.bias = nullptr; a.residual = nullptr; a.relu_src = nullptr;
+  a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+  a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+  a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr;
+}
+
 extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc, int M, int N,
                            int K, int flags, const uint16_t* bias, const uint16_t* residual, const uint16_t* relu_src,
-                           void* stream) {
+                           const float* rowscale, void* stream) {
   int rc = check_nt(A, lda, Bt, ldb, C, ldc, M, N, K);
   if (rc) return rc;
   DMI_REQUIRE(!(flags & DMI_GEMM_BIAS) || bias, "gemm_nt: bias flag without pointer");
   DMI_REQUIRE(!(flags & DMI_GEMM_RESIDUAL) || residual, "gemm_nt: residual flag without pointer");
   DMI_REQUIRE(!(flags & DMI_GEMM_RELU_MASK) || relu_src, "gemm_nt: relu-mask flag without pointer");
+  DMI_REQUIRE(!(flags & DMI_GEMM_ROWSCALE) || rowscale, "gemm_nt: row-scale flag without pointer");
   GemmArgs a;
-  a.A = A; a.B = Bt; a.C = C; a.bias = bias; a.residual = residual; a.relu_src = relu_src;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-  a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-  a.k_per_split = K; a.slab_stride = 0; a.prio = g_opt_prio; a.dbg = g_dbg_buf;
+  fill_nt_args(a, A, lda, Bt, ldb, C, ldc, M, N, K);
+  a.bias = bias; a.residual = residual; a.relu_src = relu_src; a.rowscale = rowscale; a.dbg = g_dbg_buf;
   hipStream_t st = (hipStream_t)stream;
   switch (flags) {
     case 0: return launch_nt<0>(a, 1, st);
@@ -990,6 +485,7 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
     case DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL: return launch_nt<DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL>(a, 1, st);
     case DMI_GEMM_RELU_MASK: return launch_nt<DMI_GEMM_RELU_MASK>(a, 1, st);
     case DMI_GEMM_RESIDUAL: return launch_nt<DMI_GEMM_RESIDUAL>(a, 1, st);
+    case DMI_GEMM_ROWSCALE: return launch_nt<DMI_GEMM_ROWSCALE>(a, 1, st);
     case DMI_GEMM_OUT_F32: return launch_nt<DMI_GEMM_OUT_F32>(a, 1, st);
     default:
       dmi_set_error("gemm_nt: unsupported flag combination %d", flags);
@@ -997,9 +493,28 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
   }
 }
 
-// out_bf16[i] = sum_s slabs[s*stride + i]   (split-K epilogue for bf16 outputs; deterministic order)
+// Vocabulary projection with the softmax numerator fused into the epilogue (reference src/dalle_mtf/models.py:391-395 feeding
+// :348-359): E[m, n] = bf16(exp(A[m,:] . Bt[n,:] + bias[n] - rowshift[m])), rowsum_part[n / 64][m] = the fp32 sum of those
+// exponentials over columns [64 (n/64), +64).  The logits are never written: with rowshift[m] = the label logit (dmi_label_logit)
+// every exponent that matters is representable whatever the row maximum is (floating point keeps its relative precision over
+// 2^+-127), the row's normaliser is the sum of the partials (dmi_softmax_finish) and the softmax' per-row 1/sum factor moves
+// into the consumers of dlogits (DMI_GEMM_ROWSCALE of the input-gradient GEMM, the pre-scaled X operand of dmi_gemm_tn).
+extern "C" int dmi_gemm_nt_softmax(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, const uint16_t* bias,
+                                   const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K,
+                                   void* stream) {
+  int rc = check_nt(A, lda, Bt, ldb, E, lde, M, N, K);
+  if (rc) return rc;
+  DMI_REQUIRE(bias && rowshift && rowsum_part, "gemm_nt_softmax: null pointer");
+  GemmArgs a;
+  fill_nt_args(a, A, lda, Bt, ldb, E, lde, M, N, K);
+  a.bias = bias; a.rowshift = rowshift; a.rowsum_part = rowsum_part; a.dbg = g_dbg_buf;
+  return launch_nt<DMI_GEMM_BIAS | GEMM_SOFTMAX>(a, 1, (hipStream_t)stream);
+}
+extern "C" int64_t dmi_gemm_nt_softmax_partials(int N) { return (N + 63) / 64; }
+
+// out_bf16[i] = (sum_s slabs[s*stride + i]) * rowscale[row]   (split-K epilogue for bf16 outputs; deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __restrict__ slabs, bf16_t* __restrict__ out,
-                                                                int nsplit, int64_t n8, int64_t stride) {
+                                                                int nsplit, int64_t n8, int64_t stride, const float* __restrict__ rowscale, int N) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
     float v[8];
     const f32x4 a0 = ((const f32x4*)slabs)[2 * i], a1 = ((const f32x4*)slabs)[2 * i + 1];
@@ -1008,25 +523,28 @@ __global__ __launch_bounds__(256) void reduce_slabs_bf16_kernel(const float* __r
       const f32x4 b0 = ((const f32x4*)(slabs + s * stride))[2 * i], b1 = ((const f32x4*)(slabs + s * stride))[2 * i + 1];
       v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3]; v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
     }
+    if (rowscale) {
+      const float sc = rowscale[(i * 8) / N];   // N % 8 == 0: the 8 elements share a row
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= sc;
+    }
     ((u32x4*)out)[i] = pack8(v);
   }
 }
 
 extern "C" int64_t dmi_gemm_nt_splitk_workspace_bytes(int M, int N, int nsplit) { return (int64_t)nsplit * M * N * 4 + 256; }
 
-// C[M,N] (bf16, ldc == N) = A . Bt^T with the K range split over `nsplit` block groups (fp32 slabs in `workspace`,
-// reduced deterministically).  For long-K GEMMs whose tile count does not fill whole residencies of the chip.
+// C[M,N] (bf16, ldc == N) = (A . Bt^T) [* rowscale[m]] with the K range split over `nsplit` block groups (fp32 slabs in
+// `workspace`, reduced deterministically).  For long-K GEMMs whose tile count does not fill whole residencies of the chip.
 extern "C" int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int M, int N, int K,
-                                  int nsplit, void* workspace, void* stream) {
+                                  int nsplit, const float* rowscale, void* workspace, void* stream) {
   int rc = check_nt(A, lda, Bt, ldb, C, N, M, N, K);
   if (rc) return rc;
   DMI_REQUIRE(workspace && nsplit >= 1 && nsplit <= 16 && ((int64_t)M * N) % 8 == 0, "gemm_nt_splitk: bad arguments");
   GemmArgs a;
-  a.A = A; a.B = Bt; a.C = workspace; a.bias = nullptr; a.residual = nullptr; a.relu_src = nullptr;
-  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = N;
-  a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
+  fill_nt_args(a, A, lda, Bt, ldb, workspace, N, M, N, K);
   a.k_per_split = (int)((((K + nsplit - 1) / nsplit) + BK - 1) / BK * BK);
-  a.slab_stride = (int64_t)M * N; a.prio = g_opt_prio; a.dbg = nullptr;
+  a.slab_stride = (int64_t)M * N;
   const int ns = (K + a.k_per_split - 1) / a.k_per_split;
   hipStream_t st = (hipStream_t)stream;
   rc = launch_nt<DMI_GEMM_OUT_F32>(a, ns, st);
@@ -1034,7 +552,7 @@ extern "C" int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt
   const int64_t n8 = (int64_t)M * N / 8;
   int64_t blocks = (n8 + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  reduce_slabs_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const float*)workspace, (bf16_t*)C, ns, n8, (int64_t)M * N);
+  reduce_slabs_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>((const float*)workspace, (bf16_t*)C, ns, n8, (int64_t)M * N, rowscale, N);
   DMI_CHECK_LAUNCH("gemm_nt_splitk_reduce");
   return DMI_OK;
 }
@@ -1062,13 +580,11 @@ static int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   const int s = tn_splits(M, I, J);
   const int64_t slabs = (s > 1) ? (int64_t)s * I * J * 4 : 0;
-  const int64_t Mp = round_up64(M, 64);
-  const int64_t tr = ((int64_t)I * Mp + (int64_t)J * Mp) * 2;  // fallback: transposed operand copies
-  const int64_t cs = ((int64_t)(M + 255) / 256) * J * 4 + (int64_t)s * ((I + 127) / 128) * J * 4;  // column-sum partials (bias gradient)
+  const int64_t cs = (int64_t)s * J * 4;  // bias partials
   // unsplit shapes with a ragged last residency: row-split slabs of the tail stripe, < 512 tiles x 64 KiB (+ bias rows)
   const int64_t tiles = (int64_t)((I + 127) / 128) * ((J + 127) / 128);
   const int64_t tail = (s == 1 && tiles > 512) ? (512 * 65536 + 512 * 128 * 4 * (int64_t)((I + 127) / 128)) : 0;
-  const int64_t base = round_up64(slabs, 256) + round_up64(tr, 256) + round_up64(cs, 256) + 256;
+  const int64_t base = round_up64(slabs, 256) + round_up64(cs, 256) + 256;
   return base > tail + 256 ? base : tail + 256;
 }
 
@@ -1084,12 +600,11 @@ struct TnArgs {
   const bf16_t* Y;
   float* C;
   float* bias_part;  // [nsplit][J] column sums of Y (nullable)
+  const bf16_t* bias_w;  // nullable bf16 [M]: bias_part = sum_m bias_w[m] * Y[m, :] instead of the plain column sums
   int M, I, J, ldx, ldy;
   int tiles_i, tiles_j;
   int m_per_split;  // multiple of TN_BKM
   int64_t slab_stride;
-  int prio;
-  int bias_balanced;  // 1: every row-tile block sums the dY columns of the k-steps t == ti (mod tiles_i) into its own slot
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
 };
 
@@ -1131,6 +646,25 @@ __device__ __forceinline__ bf16x8 tr_cat(u32x2 a, u32x2 b) {
   u32x4 v = {a[0], a[1], b[0], b[1]};
   return __builtin_bit_cast(bf16x8, v);
 }
+// per-row weights of the bias-gradient MFMA (A operand rows all equal): 8 consecutive bf16 per k-substep from the stage's
+// 128-B weight strip; issued ahead of the transposed fragment reads, completed by the same lgkmcnt(0)
+struct WFrag {
+  u32x4 w[4];
+};
+__device__ __forceinline__ void w_issue(WFrag& f, unsigned addr) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\t"
+      "ds_read_b128 %1, %4 offset:32\n\t"
+      "ds_read_b128 %2, %4 offset:64\n\t"
+      "ds_read_b128 %3, %4 offset:96"
+      : "=&v"(f.w[0]), "=&v"(f.w[1]), "=&v"(f.w[2]), "=&v"(f.w[3])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void w_wait(WFrag& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]) : : "memory");
+}
+#define TN_LDS_BYTES (65536 + 512)   // two 32-KiB operand stages + two 256-B bias-weight strips
 
 // v3: LDS-DMA staging (buffer_load_dwordx4 ... lds; rows past the split / matrix end read as 0 through the
 // descriptor's num_records), two stages x (X 64x128 | Y 64x128) bf16 = 64 KiB, ONE barrier per 64-row step.
@@ -1205,12 +739,14 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
   f32x16 bacc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
-  // Bias gradient = column sums of dY, one extra all-ones MFMA per k-substep.  Done only by the ti == 0 blocks it makes
-  // those blocks 25 % longer than their neighbours, and a launch of exactly one residency then waits for them (the 512 x
-  // 2048 gradient ran 125 us with the bias vs ~95 us without).  Balanced mode spreads the k-steps of a (split, tj) column
-  // over its tiles_i row-tile blocks; each writes its own partial row, summed by the slab reduce.
-  const bool do_bias = (bias_out != nullptr) && (a.bias_balanced || ti == 0);
-  const int bias_mod = a.bias_balanced ? a.tiles_i : 1, bias_rem = a.bias_balanced ? ti : 0;
+  // Bias gradient = (weighted) column sums of dY: blocks of the first row-tile issue one extra MFMA per k-substep whose A operand
+  // is all ones (plain sums) or, with a.bias_w, the per-row weights broadcast over the 32 output rows: D[i][j] = sum_m w[m] Y[m][j].
+  // (Spreading that work over all row-tile blocks was measured: mixed, slower in the step.)
+  const bool do_bias = (bias_out != nullptr) && (ti == 0);
+  const bool use_w = do_bias && (a.bias_w != nullptr);
+  const int64_t nbw = rows > 0 ? (int64_t)rows * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(use_w ? a.bias_w + mb : a.Y), 0, (int)(use_w ? nbw : 0), 0x00020000);
+  int vow = lane * 4;   // 2 weights per lane: 64 lanes cover 128 rows, the step uses the first 64
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
@@ -1233,14 +769,19 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
       voy[i] += stepy;
     }
     if constexpr (CONV) cv_m += TN_BKM;
+    if (use_w) {   // block-uniform; every wave writes the same 256 bytes (uniform DMA count per wave)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 65536 + st * 256), 4, vow, 0, 0, 0);
+      vow += TN_BKM * 2;
+    }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
-  auto compute = [&](int st, int step) {
+  auto compute = [&](int st) {
     const unsigned base = lds0 + st * 32768;
-    if (a.prio) __builtin_amdgcn_s_setprio(1);
     TrFrag f[4];  // all four k-substeps of the stage, then k-innermost MFMA order: four back-to-back MFMAs per accumulator (source C
                   // forwarded inside the matrix pipe instead of a register-file round trip each); measured +2-4 % here, while the same
                   // order costs the NT kernels registers/occupancy and was measured neutral (128x128) or worse (256x128)
+    WFrag wf;
+    if (use_w) w_issue(wf, lds0 + 65536 + st * 256 + 16 * h);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const unsigned b2 = base + kk * 4096;
@@ -1248,6 +789,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) tr_wait(f[kk]);
+    if (use_w) w_wait(wf);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x0a, f[kk].x0b), tr_cat(f[kk].y0a, f[kk].y0b), acc[0][0], 0, 0, 0);  // D[i][j]
@@ -1264,14 +806,14 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     for (int kk = 0; kk < 4; ++kk)
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x1a, f[kk].x1b), tr_cat(f[kk].y1a, f[kk].y1b), acc[1][1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (do_bias && (step % bias_mod) == bias_rem) {  // wave (wi,wj) sums columns wj*64 + wi*32 ..  (wave-uniform branches)
+    if (do_bias) {  // wave (wi,wj) sums columns wj*64 + wi*32 ..  (wave-uniform branches)
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, tr_cat(f[kk].y0a, f[kk].y0b), bacc, 0, 0, 0);
-        else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, tr_cat(f[kk].y1a, f[kk].y1b), bacc, 0, 0, 0);
+        const bf16x8 wa = use_w ? __builtin_bit_cast(bf16x8, wf.w[kk]) : ones;
+        if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f[kk].y0a, f[kk].y0b), bacc, 0, 0, 0);
+        else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f[kk].y1a, f[kk].y1b), bacc, 0, 0, 0);
       }
     }
-    if (a.prio) __builtin_amdgcn_s_setprio(0);
   };
 
   unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, rq0 = 0;
@@ -1286,16 +828,16 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     int t = 0;
     for (; t + 2 <= nt; t += 2) {
       stage(1);
-      compute(0, t);
+      compute(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t + 2 < nt) stage(0);
-      compute(1, t + 1);
+      compute(1);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
     if (t < nt) {
-      compute(0, t);
+      compute(0);
       __syncthreads();
     }
   }
@@ -1338,9 +880,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
   const int mb = split * a.m_per_split;
   const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
   const int rows = me > mb ? me - mb : 0;
-  const int64_t bslot = a.bias_balanced ? (int64_t)split * a.tiles_i + ti : split;
   tn_tile<false>(a, nullptr, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
-          a.bias_part ? a.bias_part + bslot * a.J : nullptr);
+          a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
 }
 
 // Unsplit shapes whose tile count is not a multiple of the 512 resident blocks (the head: 4 x 397 = 1588 tiles = 3.1
@@ -1381,224 +922,66 @@ __global__ __launch_bounds__(256) void reduce_slabs_2d_kernel(const float* __res
   }
 }
 
-int dmi_transpose_padded(const uint16_t* in, uint16_t* out, int nb, int nh, int Rv, int Rp, int C,
-                         int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride, void* stream);
-
-extern "C" int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int N, void* workspace, void* stream);
-
-extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias, int M,
-                           int I, int J, void* workspace, void* stream) {
+extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias,
+                           const uint16_t* bias_weights, int M, int I, int J, void* workspace, void* stream) {
   DMI_REQUIRE(X && dY && dW && workspace, "gemm_tn: null pointer");
   DMI_REQUIRE(M > 0 && I % 8 == 0 && J % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= I && ldy >= J,
               "gemm_tn: I, J, ldx, ldy must be multiples of 8 (M=%d I=%d J=%d)", M, I, J);
   DMI_REQUIRE((((uintptr_t)X | (uintptr_t)dY | (uintptr_t)dW | (uintptr_t)workspace) & 15) == 0, "gemm_tn: 16-byte alignment required");
+  DMI_REQUIRE(!bias_weights || (dbias && ((uintptr_t)bias_weights & 3) == 0), "gemm_tn: bias_weights needs dbias and 4-byte alignment");
+  DMI_REQUIRE((int64_t)TN_BKM * (ldx > ldy ? ldx : ldy) * 2 < 0x7fffffff, "gemm_tn: leading dimension too large");
   hipStream_t st = (hipStream_t)stream;
   const int nsplit = tn_splits(M, I, J);
   float* slabs = (float*)workspace;
   const int64_t slab_bytes = (nsplit > 1) ? round_up64((int64_t)nsplit * I * J * 4, 256) : 0;
-  if (g_opt_tn_trread) {
-    TnArgs a;
-    a.X = X; a.Y = dY; a.M = M; a.I = I; a.J = J; a.ldx = ldx; a.ldy = ldy;
-    a.tiles_i = (I + 127) / 128; a.tiles_j = (J + 127) / 128;
-    a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
-    a.C = (nsplit > 1) ? slabs : dW;
-    a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-    a.prio = g_opt_prio; a.dbg = g_dbg_buf;
-    a.bias_balanced = 0;  // balanced mode measured: 512x2048 gradient 123 -> 109 us but 2048x512 116 -> 122, 512x512 53 -> 72 us and the step slower
-    // bias partials live behind the transposed-copy region of the workspace (unused in this mode)
-    float* bpart = (float*)((char*)workspace + slab_bytes);
-    a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
-    DMI_REQUIRE((int64_t)TN_BKM * (ldx > ldy ? ldx : ldy) * 2 < 0x7fffffff, "gemm_tn: leading dimension too large");
-    static bool attr_done = false;
-    const int shm = 65536;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
-    const int tiles = a.tiles_i * a.tiles_j;
-    const int nt_tile = (M + TN_BKM - 1) / TN_BKM;
-    const int tail_tiles = tiles % 512, n_whole = tiles - tail_tiles;
-    const int S = tail_tiles ? 512 / tail_tiles : 1;
-    // tiles are numbered ti-fastest: with tiles_i | n_whole the tail is the column stripe [c0, J) of dW
-    if (g_opt_tn_streamk && nsplit == 1 && tiles > 512 && S >= 2 && a.tiles_i <= GROUP_M && n_whole % a.tiles_i == 0 && J % 4 == 0) {
-      static bool attr_sk = false;
-      if (!attr_sk) { (void)hipFuncSetAttribute((const void*)gemm_tn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_sk = true; }
-      const int c0 = (n_whole / a.tiles_i) * 128, W = J - c0;
-      const int mps = (int)round_up64((M + S - 1) / S, TN_BKM);
-      float* tslab = (float*)workspace;                       // [S][I][W]
-      float* tbias = tslab + (int64_t)S * I * W;              // [S][W]
-      gemm_tn_tail_kernel<<<dim3(n_whole + tail_tiles * S), dim3(256), shm, st>>>(a, n_whole, S, mps, tslab, tbias, c0, W);
-      DMI_CHECK_LAUNCH("gemm_tn_tail");
-      reduce_slabs_2d_kernel<<<dim3(512), dim3(256), 0, st>>>(tslab, dW + c0, S, I, W, J);
-      DMI_CHECK_LAUNCH("gemm_tn_tail_reduce");
-      if (dbias) {
-        reduce_slabs_2d_kernel<<<dim3(8), dim3(256), 0, st>>>(tbias, dbias + c0, S, 1, W, J);
-        DMI_CHECK_LAUNCH("gemm_tn_tail_bias_reduce");
-      }
-    } else {
-      gemm_tn_kernel<<<dim3(tiles * nsplit), dim3(256), shm, st>>>(a);
-    }
-    DMI_CHECK_LAUNCH("gemm_tn");
-    if (dbias && nsplit > 1) {
-      reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, a.bias_balanced ? nsplit * a.tiles_i : nsplit, J / 4, J / 4);
-      DMI_CHECK_LAUNCH("gemm_tn_bias_reduce");
+  TnArgs a;
+  a.X = X; a.Y = dY; a.M = M; a.I = I; a.J = J; a.ldx = ldx; a.ldy = ldy;
+  a.tiles_i = (I + 127) / 128; a.tiles_j = (J + 127) / 128;
+  a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
+  a.C = (nsplit > 1) ? slabs : dW;
+  a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
+  a.dbg = g_dbg_buf;
+  a.bias_w = bias_weights;
+  float* bpart = (float*)((char*)workspace + slab_bytes);   // [nsplit][J] bias partials behind the slabs
+  a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
+  static bool attr_done = false;
+  const int shm = TN_LDS_BYTES;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    attr_done = true;
+  }
+  const int tiles = a.tiles_i * a.tiles_j;
+  const int tail_tiles = tiles % 512, n_whole = tiles - tail_tiles;
+  const int S = tail_tiles ? 512 / tail_tiles : 1;
+  // tiles are numbered ti-fastest: with tiles_i | n_whole the tail is the column stripe [c0, J) of dW
+  if (g_opt_tn_tail && nsplit == 1 && tiles > 512 && S >= 2 && a.tiles_i <= GROUP_M && n_whole % a.tiles_i == 0 && J % 4 == 0) {
+    const int c0 = (n_whole / a.tiles_i) * 128, W = J - c0;
+    const int mps = (int)round_up64((M + S - 1) / S, TN_BKM);
+    float* tslab = (float*)workspace;                       // [S][I][W]
+    float* tbias = tslab + (int64_t)S * I * W;              // [S][W]
+    gemm_tn_tail_kernel<<<dim3(n_whole + tail_tiles * S), dim3(256), shm, st>>>(a, n_whole, S, mps, tslab, tbias, c0, W);
+    DMI_CHECK_LAUNCH("gemm_tn_tail");
+    reduce_slabs_2d_kernel<<<dim3(512), dim3(256), 0, st>>>(tslab, dW + c0, S, I, W, J);
+    DMI_CHECK_LAUNCH("gemm_tn_tail_reduce");
+    if (dbias) {
+      reduce_slabs_2d_kernel<<<dim3(8), dim3(256), 0, st>>>(tbias, dbias + c0, S, 1, W, J);
+      DMI_CHECK_LAUNCH("gemm_tn_tail_bias_reduce");
     }
   } else {
-    // fallback: explicit transposes + split-K NT GEMM:  dW[I,J] = Xt[I,Mp] . dYt[J,Mp]^T
-    const int Mp = (int)round_up64(M, 64);
-    bf16_t* Xt = (bf16_t*)((char*)workspace + slab_bytes);
-    bf16_t* Yt = Xt + (int64_t)I * Mp;
-    int rc = dmi_transpose_padded(X, Xt, 1, 1, M, Mp, I, 0, 0, ldx, stream);  // pad rows [M, Mp) = 0
-    if (rc) return rc;
-    rc = dmi_transpose_padded(dY, Yt, 1, 1, M, Mp, J, 0, 0, ldy, stream);
-    if (rc) return rc;
-    GemmArgs g;
-    g.A = Xt; g.B = Yt; g.bias = nullptr; g.residual = nullptr; g.relu_src = nullptr;
-    g.M = I; g.N = J; g.K = Mp; g.lda = Mp; g.ldb = Mp; g.ldc = J;
-    g.tiles_m = (I + BM - 1) / BM; g.tiles_n = (J + BN - 1) / BN;
-    g.k_per_split = (int)round_up64((Mp + nsplit - 1) / nsplit, BK);
-    g.C = (nsplit > 1) ? (void*)slabs : (void*)dW;
-    g.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-    g.prio = g_opt_prio; g.dbg = nullptr;
-    const int ns = (Mp + g.k_per_split - 1) / g.k_per_split;
-    rc = launch_nt<DMI_GEMM_OUT_F32>(g, ns, st);
-    if (rc) return rc;
-    if (ns != nsplit && nsplit > 1) {
-      // fewer effective splits than planned: zero the unused slabs so the reduce stays exact
-      hipError_t e = hipMemsetAsync(slabs + (int64_t)ns * I * J, 0, (int64_t)(nsplit - ns) * I * J * 4, st);
-      DMI_REQUIRE(e == hipSuccess, "gemm_tn: memset failed");
-    }
-    if (dbias) {
-      const int64_t tr_bytes = round_up64(((int64_t)I * Mp + (int64_t)J * Mp) * 2, 256);
-      rc = dmi_colsum(dY, ldy, dbias, M, J, (char*)workspace + slab_bytes + tr_bytes, stream);
-      if (rc) return rc;
-    }
+    gemm_tn_kernel<<<dim3(tiles * nsplit), dim3(256), shm, st>>>(a);
+    DMI_CHECK_LAUNCH("gemm_tn");
   }
   if (nsplit > 1) {
+    if (dbias) {
+      reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);
+      DMI_CHECK_LAUNCH("gemm_tn_bias_reduce");
+    }
     const int64_t n4 = (int64_t)I * J / 4;
     int64_t blocks = cdiv64(n4, 256);
     if (blocks > 2048) blocks = 2048;
     reduce_slabs_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(slabs, dW, nsplit, n4, n4);
     DMI_CHECK_LAUNCH("gemm_tn_reduce");
-  }
-  return DMI_OK;
-}
-
-// ---- grouped weight gradients --------------------------------------------------------------------------------------
-// The four weight gradients of a transformer block are independent ~100 us launches of exactly one residency (512
-// blocks) each: PMC shows 1.6 of the 2 possible waves per SIMD resident on average (launch ramp + ragged finish) and a
-// slab reduce per launch.  Grouped, they are ONE launch of 4 x 512 blocks (each problem keeps its own tiling / row split /
-// slabs) whose ragged edges overlap, followed by ONE reduce launch.
-#define TN_GROUP_MAX 8
-struct TnGroup {
-  TnArgs p[TN_GROUP_MAX];
-  int first_block[TN_GROUP_MAX + 1];
-  int tiles[TN_GROUP_MAX];
-  int n;
-};
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(TnGroup g) {
-  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
-  int k = 0;
-  while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
-  const TnArgs& a = g.p[k];
-  const int local = blockIdx.x - g.first_block[k];
-  const int tiles = g.tiles[k];
-  const int P = xcd_remap(local, g.first_block[k + 1] - g.first_block[k]);   // per-XCD contiguous ranges of whole splits
-  const int split = P / tiles;
-  int ti, tj;
-  tile_of_block(P - split * tiles, a.tiles_i, a.tiles_j, ti, tj);
-  const int mb = split * a.m_per_split;
-  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
-  const int64_t bslot = a.bias_balanced ? (int64_t)split * a.tiles_i + ti : split;
-  tn_tile<false>(a, nullptr, smem_tn, ti, tj, mb, me > mb ? me - mb : 0, a.C + (int64_t)split * a.slab_stride, a.J,
-          a.bias_part ? a.bias_part + bslot * a.J : nullptr);
-}
-struct ReduceGroup {
-  const float* slabs[2 * TN_GROUP_MAX];
-  float* out[2 * TN_GROUP_MAX];
-  int nsplit[2 * TN_GROUP_MAX];
-  int64_t n4[2 * TN_GROUP_MAX];      // float4 count of one slab
-  int first_block[2 * TN_GROUP_MAX + 1];
-  int n;
-};
-__global__ __launch_bounds__(256) void reduce_slabs_grouped_kernel(ReduceGroup g) {
-  int k = 0;
-  while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
-  const int nb = g.first_block[k + 1] - g.first_block[k];
-  const f32x4* sl = (const f32x4*)g.slabs[k];
-  const int64_t n4 = g.n4[k];
-  for (int64_t i = (int64_t)(blockIdx.x - g.first_block[k]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
-    f32x4 acc = sl[i];
-    for (int s2 = 1; s2 < g.nsplit[k]; ++s2) {
-      const f32x4 v = sl[(int64_t)s2 * n4 + i];
-      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-    }
-    ((f32x4*)g.out[k])[i] = acc;
-  }
-}
-
-static int64_t tn_problem_ws(int M, int I, int J) {  // slabs + bias partials of ONE grouped problem
-  const int s = tn_splits(M, I, J);
-  return (s > 1) ? round_up64((int64_t)s * I * J * 4, 256) + round_up64((int64_t)s * ((I + 127) / 128) * J * 4, 256) : 0;
-}
-extern "C" int64_t dmi_gemm_tn_grouped_workspace_bytes(const dmi_tn_problem* probs, int n) {
-  int64_t tot = 256;
-  for (int k = 0; k < n; ++k) tot += tn_problem_ws(probs[k].M, probs[k].I, probs[k].J);
-  return tot;
-}
-extern "C" int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* workspace, void* stream) {
-  DMI_REQUIRE(probs && workspace && n > 0 && n <= TN_GROUP_MAX, "gemm_tn_grouped: need 1..%d problems", TN_GROUP_MAX);
-  DMI_REQUIRE(((uintptr_t)workspace & 15) == 0, "gemm_tn_grouped: 16-byte alignment required");
-  hipStream_t st = (hipStream_t)stream;
-  TnGroup g;
-  ReduceGroup rg;
-  g.n = n;
-  rg.n = 0;
-  int nblk = 0, rblk = 0;
-  char* wsp = (char*)workspace;
-  for (int k = 0; k < n; ++k) {
-    const dmi_tn_problem& q = probs[k];
-    DMI_REQUIRE(q.X && q.dY && q.dW, "gemm_tn_grouped: null pointer in problem %d", k);
-    DMI_REQUIRE(q.M > 0 && q.I % 8 == 0 && q.J % 8 == 0 && q.ldx % 8 == 0 && q.ldy % 8 == 0 && q.ldx >= q.I && q.ldy >= q.J,
-                "gemm_tn_grouped: I, J, ldx, ldy must be multiples of 8 (problem %d)", k);
-    DMI_REQUIRE((((uintptr_t)q.X | (uintptr_t)q.dY | (uintptr_t)q.dW) & 15) == 0, "gemm_tn_grouped: 16-byte alignment required");
-    DMI_REQUIRE((int64_t)TN_BKM * (q.ldx > q.ldy ? q.ldx : q.ldy) * 2 < 0x7fffffff, "gemm_tn_grouped: leading dimension too large");
-    const int nsplit = tn_splits(q.M, q.I, q.J);
-    TnArgs& a = g.p[k];
-    a.X = q.X; a.Y = q.dY; a.M = q.M; a.I = q.I; a.J = q.J; a.ldx = q.ldx; a.ldy = q.ldy;
-    a.tiles_i = (q.I + 127) / 128; a.tiles_j = (q.J + 127) / 128;
-    a.m_per_split = (int)round_up64((q.M + nsplit - 1) / nsplit, TN_BKM);
-    a.prio = g_opt_prio; a.dbg = nullptr;
-    a.bias_balanced = 0;
-    const int64_t ij = (int64_t)q.I * q.J;
-    if (nsplit > 1) {
-      float* slabs = (float*)wsp;
-      float* bpart = (float*)(wsp + round_up64((int64_t)nsplit * ij * 4, 256));
-      wsp += tn_problem_ws(q.M, q.I, q.J);
-      a.C = slabs; a.slab_stride = ij; a.bias_part = q.dbias ? bpart : nullptr;
-      DMI_REQUIRE(ij % 4 == 0 && q.J % 4 == 0, "gemm_tn_grouped: sizes must be multiples of 4");
-      int b = (int)cdiv64(ij / 4, 256 * 4);
-      if (b > 512) b = 512;
-      rg.slabs[rg.n] = slabs; rg.out[rg.n] = q.dW; rg.nsplit[rg.n] = nsplit; rg.n4[rg.n] = ij / 4; rg.first_block[rg.n] = rblk;
-      rblk += b; ++rg.n;
-      if (q.dbias) {
-        rg.slabs[rg.n] = bpart; rg.out[rg.n] = q.dbias; rg.nsplit[rg.n] = a.bias_balanced ? nsplit * a.tiles_i : nsplit; rg.n4[rg.n] = q.J / 4; rg.first_block[rg.n] = rblk;
-        rblk += 1; ++rg.n;
-      }
-    } else {
-      a.C = q.dW; a.slab_stride = 0; a.bias_part = q.dbias;
-    }
-    g.tiles[k] = a.tiles_i * a.tiles_j;
-    g.first_block[k] = nblk;
-    nblk += g.tiles[k] * nsplit;
-  }
-  g.first_block[n] = nblk;
-  rg.first_block[rg.n] = rblk;
-  static bool attr_done = false;
-  const int shm = 65536;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
-  gemm_tn_grouped_kernel<<<dim3(nblk), dim3(256), shm, st>>>(g);
-  DMI_CHECK_LAUNCH("gemm_tn_grouped");
-  if (rg.n > 0) {
-    reduce_slabs_grouped_kernel<<<dim3(rblk), dim3(256), 0, st>>>(rg);
-    DMI_CHECK_LAUNCH("gemm_tn_grouped_reduce");
   }
   return DMI_OK;
 }
@@ -1746,7 +1129,8 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.A = x; a.B = Wt; a.C = out; a.bias = bias; a.residual = residual; a.relu_src = relu_src;
   a.M = (int)Ml; a.N = N; a.K = ntaps * C; a.lda = (int)xbytes /* descriptor size */; a.ldb = ldw; a.ldc = ldc;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-  a.k_per_split = a.K; a.slab_stride = 0; a.prio = 0; a.dbg = nullptr;
+  a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr;
+  a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr;
   ConvGeom g;
   g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = 0; g.lh = 0;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }
@@ -1806,15 +1190,15 @@ extern "C" int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, 
   a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
   a.C = (nsplit > 1) ? slabs : dW;
   a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-  a.prio = 0; a.dbg = nullptr; a.bias_balanced = 0;
+  a.dbg = nullptr; a.bias_w = nullptr;
   float* bpart = (float*)((char*)workspace + slab_bytes);
   a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
   ConvGeom g;
   g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = lw; g.lh = lh;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_done = true; }
-  conv_wgrad_tn_kernel<<<dim3(a.tiles_i * a.tiles_j * nsplit), dim3(256), 65536, st>>>(a, g);
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)conv_wgrad_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES); attr_done = true; }
+  conv_wgrad_tn_kernel<<<dim3(a.tiles_i * a.tiles_j * nsplit), dim3(256), TN_LDS_BYTES, st>>>(a, g);
   DMI_CHECK_LAUNCH("conv_wgrad_tn");
   if (nsplit > 1) {
     if (dbias) {

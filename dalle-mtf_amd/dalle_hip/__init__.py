@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DALLE_HIP_LIB") or os.path.join(_HERE, "libdalle_hip.so")  # override: A/B of two builds
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "dalle_hip.h")
 
-GEMM_BIAS, GEMM_RELU, GEMM_RESIDUAL, GEMM_RELU_MASK, GEMM_OUT_F32 = 1, 2, 4, 8, 16
+GEMM_BIAS, GEMM_RELU, GEMM_RESIDUAL, GEMM_RELU_MASK, GEMM_OUT_F32, GEMM_ROWSCALE = 1, 2, 4, 8, 16, 32
 
 _lib = None
 
@@ -52,24 +52,27 @@ def _declare(L):
         "dmi_get_option": (I, [c_char_p]),
         "dmi_set_option": (I, [c_char_p, I]),
         "dmi_embed_fwd": (I, [P, P, P, P, L64, I, I, I, P]),
-        "dmi_embed_bwd": (I, [P, P, P, P, I, I, I, I, P]),
-        "dmi_embed_bwd_sorted": (I, [P, P, P, P, P, I, I, I, I, P]),
+        "dmi_sort_tokens_workspace_bytes": (L64, [L64]),
+        "dmi_sort_tokens": (I, [P, P, P, L64, I, P, P]),
+        "dmi_embed_bwd_workspace_bytes": (L64, [I, I, I]),
+        "dmi_embed_bwd": (I, [P, P, P, P, P, I, I, I, I, P, P]),
         "dmi_layernorm_fwd": (I, [P, P, P, P, P, P, L64, I, F, P]),
         "dmi_layernorm_bwd_workspace_bytes": (L64, [L64, I]),
         "dmi_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L64, I, P]),
-        "dmi_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, I, P, P, P, P]),
+        "dmi_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, I, P, P, P, P, P]),
         "dmi_gemm_nt_splitk_workspace_bytes": (L64, [I, I, I]),
-        "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P]),
+        "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P, P]),
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
-        "dmi_gemm_tn": (I, [P, I, P, I, P, P, I, I, I, P, P]),
-        "dmi_gemm_tn_grouped_workspace_bytes": (L64, [P, I]),
-        "dmi_gemm_tn_grouped": (I, [P, I, P, P]),
+        "dmi_gemm_tn": (I, [P, I, P, I, P, P, P, I, I, I, P, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
         "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
-        "dmi_transpose_bf16_strided": (I, [P, P, I, I, I, I, L64, L64, L64, P]),
-        "dmi_attention_fwd": (I, [P, P, P, P, I, I, I, P]),
-        "dmi_attention_bwd": (I, [P, P, P, P, P, P, P, P, P, I, I, I, P]),
+        "dmi_attention_fwd": (I, [P, P, P, I, I, I, P]),
+        "dmi_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+        "dmi_label_logit": (I, [P, I, P, I, P, P, P, P, L64, I, I, P]),
+        "dmi_gemm_nt_softmax_partials": (L64, [I]),
+        "dmi_gemm_nt_softmax": (I, [P, I, P, I, P, P, P, I, P, I, I, I, P]),
+        "dmi_softmax_finish": (I, [P, I, P, P, I, P, I, P, P, I, I, P, P, P, P, P, L64, I, I, F, P]),
         "dmi_shift_labels": (I, [P, P, I, I, I, P]),
         "dmi_cross_entropy": (I, [P, I, P, P, P, L64, I, F, P]),
         "dmi_sum_f32": (I, [P, L64, F, P, P]),
@@ -138,15 +141,24 @@ def embed_fwd(tokens, wte, wpe, x, S, d, vocab):
     _check(lib().dmi_embed_fwd(_p(tokens), _p(wte), _p(wpe), _p(x), tokens.numel(), S, d, vocab, _stream()), "embed_fwd")
 
 
-def embed_bwd(tokens, dx, dwte, dwpe, B, S, d, vocab):
-    _dev(tokens, dx, dwte, dwpe)
-    _check(lib().dmi_embed_bwd(_p(tokens), _p(dx), _p(dwte), _p(dwpe), B, S, d, vocab, _stream()), "embed_bwd")
+def sort_tokens_workspace_bytes(n):
+    return int(lib().dmi_sort_tokens_workspace_bytes(n))
 
 
-def embed_bwd_sorted(sorted_tokens, perm, dx, dwte, dwpe, B, S, d, vocab):
-    _dev(sorted_tokens, perm, dx, dwte, dwpe)
-    _check(lib().dmi_embed_bwd_sorted(_p(sorted_tokens), _p(perm), _p(dx), _p(dwte), _p(dwpe), B, S, d, vocab, _stream()),
-           "embed_bwd_sorted")
+def sort_tokens(tokens, sorted_tokens, perm, n, vocab, ws):
+    """stable sort of the token ids: sorted_tokens ascending, perm = source positions (int32 device tensors)."""
+    _dev(tokens, sorted_tokens, perm, ws)
+    _check(lib().dmi_sort_tokens(_p(tokens), _p(sorted_tokens), _p(perm), n, vocab, _p(ws), _stream()), "sort_tokens")
+
+
+def embed_bwd_workspace_bytes(B, S, d):
+    return int(lib().dmi_embed_bwd_workspace_bytes(B, S, d))
+
+
+def embed_bwd(sorted_tokens, perm, dx, dwte, dwpe, B, S, d, vocab, ws):
+    _dev(sorted_tokens, perm, dx, dwte, dwpe, ws)
+    _check(lib().dmi_embed_bwd(_p(sorted_tokens), _p(perm), _p(dx), _p(dwte), _p(dwpe), B, S, d, vocab, _p(ws), _stream()),
+           "embed_bwd")
 
 
 def layernorm_fwd(x, g, b, y, mean, rstd, rows, d, eps=1e-5):
@@ -164,28 +176,29 @@ def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, ws, rows, d):
                                    _p(ws), rows, d, _stream()), "layernorm_bwd")
 
 
-def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None, relu_src=None):
+def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None, relu_src=None, rowscale=None):
     _dev(A, Bt, C)
     _check(lib().dmi_gemm_nt(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _p(residual),
-                             _p(relu_src), _stream()), "gemm_nt")
+                             _p(relu_src), _p(rowscale), _stream()), "gemm_nt")
 
 
 def gemm_nt_splitk_workspace_bytes(M, N, nsplit):
     return lib().dmi_gemm_nt_splitk_workspace_bytes(M, N, nsplit)
 
 
-def gemm_nt_splitk(A, lda, Bt, ldb, C, M, N, K, nsplit, ws):
+def gemm_nt_splitk(A, lda, Bt, ldb, C, M, N, K, nsplit, ws, rowscale=None):
     _dev(A, Bt, C, ws)
-    _check(lib().dmi_gemm_nt_splitk(_p(A), lda, _p(Bt), ldb, _p(C), M, N, K, nsplit, _p(ws), _stream()), "gemm_nt_splitk")
+    _check(lib().dmi_gemm_nt_splitk(_p(A), lda, _p(Bt), ldb, _p(C), M, N, K, nsplit, _p(rowscale), _p(ws), _stream()),
+           "gemm_nt_splitk")
 
 
 def gemm_tn_workspace_bytes(M, I, J):
     return lib().dmi_gemm_tn_workspace_bytes(M, I, J)
 
 
-def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws, dbias=None):
-    _dev(X, dY, dW, ws, dbias)
-    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), M, I, J, _p(ws), _stream()), "gemm_tn")
+def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws, dbias=None, bias_weights=None):
+    _dev(X, dY, dW, ws, dbias, bias_weights)
+    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), _p(bias_weights), M, I, J, _p(ws), _stream()), "gemm_tn")
 
 
 def colsum_workspace_bytes(M, N):
@@ -202,32 +215,6 @@ def transpose(inp, out, batch, R, C):
     _check(lib().dmi_transpose_bf16(_p(inp), _p(out), batch, R, C, _stream()), "transpose")
 
 
-class TnProblem(ctypes.Structure):
-    """dmi_tn_problem (include/dalle_hip.h)."""
-    _fields_ = [("X", c_void_p), ("ldx", c_int), ("dY", c_void_p), ("ldy", c_int), ("dW", c_void_p), ("dbias", c_void_p),
-                ("M", c_int), ("I", c_int), ("J", c_int)]
-
-
-def tn_problems(items):
-    """items: iterable of (X, ldx, dY, ldy, dW, M, I, J, dbias-or-None) device tensors -> ctypes array (host side)."""
-    items = list(items)
-    arr = (TnProblem * len(items))()
-    for k, (X, ldx, dY, ldy, dW, M, I_, J, dbias) in enumerate(items):
-        _dev(X, dY, dW, dbias)
-        arr[k] = TnProblem(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias) or None, M, I_, J)
-    return arr
-
-
-def gemm_tn_grouped_workspace_bytes(probs):
-    return int(lib().dmi_gemm_tn_grouped_workspace_bytes(ctypes.byref(probs), len(probs)))
-
-
-def gemm_tn_grouped(probs, ws):
-    """All weight gradients of `probs` (tn_problems(...)) in one launch + one reduce launch; bit-identical to gemm_tn."""
-    _dev(ws)
-    _check(lib().dmi_gemm_tn_grouped(ctypes.byref(probs), len(probs), _p(ws), _stream()), "gemm_tn_grouped")
-
-
 def set_debug_buffer(t):
     """tools only: u64 device tensor [blocks, 5] receiving per-block phase timestamps of the 256x128 NT kernel (None: off)."""
     fn = lib().dmi_set_debug_buffer
@@ -241,21 +228,14 @@ def transpose_batch(in_base, out_base, table, n, total_tiles):
     _check(lib().dmi_transpose_bf16_batch(_p(in_base), _p(out_base), _p(table), n, total_tiles, _stream()), "transpose_batch")
 
 
-def transpose_strided(inp_ptr, out, nb, nh, R, C, sb, sh, sr):
-    """inp_ptr: raw device address (int) of element (0,0,0,0)."""
-    _dev(out)
-    _check(lib().dmi_transpose_bf16_strided(inp_ptr, _p(out), nb, nh, R, C, sb, sh, sr, _stream()), "transpose_strided")
-
-
-def attention_fwd(qkv, vt, o, lse, B, H, S):
+def attention_fwd(qkv, o, lse, B, H, S):
     _dev(qkv, o, lse)
-    _check(lib().dmi_attention_fwd(_p(qkv), _p(vt), _p(o), _p(lse), B, H, S, _stream()), "attention_fwd")
+    _check(lib().dmi_attention_fwd(_p(qkv), _p(o), _p(lse), B, H, S, _stream()), "attention_fwd")
 
 
-def attention_bwd(qkv, qt, kt, o, d_o, dot, lse, delta, dqkv, B, H, S):
-    _dev(qkv, o, d_o, lse, delta, dqkv)
-    _check(lib().dmi_attention_bwd(_p(qkv), _p(qt), _p(kt), _p(o), _p(d_o), _p(dot), _p(lse), _p(delta), _p(dqkv),
-                                   B, H, S, _stream()), "attention_bwd")
+def attention_bwd(qkv, o, d_o, lse, scratch, dqkv, B, H, S):
+    _dev(qkv, o, d_o, lse, scratch, dqkv)
+    _check(lib().dmi_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(scratch), _p(dqkv), B, H, S, _stream()), "attention_bwd")
 
 
 def shift_labels(tokens, labels, B, S, eos):
@@ -266,6 +246,29 @@ def shift_labels(tokens, labels, B, S, eos):
 def cross_entropy(z, ldz, labels, loss_rows, lse, M, V, dz_scale):
     _dev(z, labels, loss_rows)
     _check(lib().dmi_cross_entropy(_p(z), ldz, _p(labels), _p(loss_rows), _p(lse), M, V, dz_scale, _stream()), "cross_entropy")
+
+
+def label_logit(X, ldx, Wt, ldw, bias, labels, zl, flag, M, K, V):
+    _dev(X, Wt, bias, labels, zl, flag)
+    _check(lib().dmi_label_logit(_p(X), ldx, _p(Wt), ldw, _p(bias), _p(labels), _p(zl), _p(flag), M, K, V, _stream()), "label_logit")
+
+
+def gemm_nt_softmax_partials(N):
+    return int(lib().dmi_gemm_nt_softmax_partials(N))
+
+
+def gemm_nt_softmax(X, ldx, Wt, ldw, bias, rowshift, E, lde, rowsum_part, M, N, K):
+    _dev(X, Wt, bias, rowshift, E, rowsum_part)
+    _check(lib().dmi_gemm_nt_softmax(_p(X), ldx, _p(Wt), ldw, _p(bias), _p(rowshift), _p(E), lde, _p(rowsum_part), M, N, K,
+                                     _stream()), "gemm_nt_softmax")
+
+
+def softmax_finish(rowsum_part, nparts, labels, X, ldx, Wt, ldw, bias, E, lde, N, loss_rows, rowscale, rowscale_bf16, Xs, flag,
+                   M, K, V, dz_scale):
+    _dev(rowsum_part, labels, X, Wt, bias, E, loss_rows, flag)
+    _check(lib().dmi_softmax_finish(_p(rowsum_part), nparts, _p(labels), _p(X), ldx, _p(Wt), ldw, _p(bias), _p(E), lde, N,
+                                    _p(loss_rows), _p(rowscale), _p(rowscale_bf16), _p(Xs), _p(flag), M, K, V, float(dz_scale),
+                                    _stream()), "softmax_finish")
 
 
 def sum_f32(x, n, scale, out):

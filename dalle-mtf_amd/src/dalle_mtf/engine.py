@@ -123,7 +123,6 @@ class DalleEngine:
         self.global_step = 0
         self._alloc_activations()
         self._pending = []  # async all-reduce handles
-        self._ev = {}
 
     # ------------------------------------------------------------------ parameter access
     def view(self, buf, name):
@@ -231,10 +230,25 @@ class DalleEngine:
         self.stats = [[torch.empty(M, **f32) for _ in range(4)] for _ in range(L)]  # mean1, rstd1, mean2, rstd2
         self.xnf = torch.empty(M, d, **b16)
         self.statf = [torch.empty(M, **f32) for _ in range(2)]
-        self.z = torch.empty(M, Vp, **b16)
+        self.z = torch.empty(M, Vp, **b16)      # eval: logits; train: E = exp(logit - label logit), patched into unnormalised dlogits
         self.loss_rows = torch.empty(M, **f32)
         self.loss = torch.zeros(1, **f32)
         self.gnorm_sq = torch.zeros(1, **f32)
+        # fused softmax head (training path, include/dalle_hip.h K7/K8 (b))
+        self.nparts = dh.gemm_nt_softmax_partials(Vp)
+        self.zl = torch.empty(M, **f32)                      # label logit = exponent shift
+        self.rowsum_part = torch.empty(self.nparts, M, **f32)
+        self.rowscale = torch.empty(M, **f32)                # dz_scale / sum_v exp(.)
+        self.rowscale_bf = torch.empty(_round_up(M, 128) + 128, **b16)
+        self.xs = torch.empty(M, d, **b16)                   # rowscale * LN_f(x): left operand of the head weight gradient
+        self.head_flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # token-id order for the embedding scatter-add: sorted on a side stream while the forward runs
+        self.tok_sorted = torch.empty(M, dtype=torch.int32, device=self.dev)
+        self.tok_perm = torch.empty(M, dtype=torch.int32, device=self.dev)
+        self.sort_ws = torch.empty(dh.sort_tokens_workspace_bytes(M), dtype=torch.uint8, device=self.dev)
+        self.embed_ws = torch.empty(dh.embed_bwd_workspace_bytes(B, S, d), dtype=torch.uint8, device=self.dev)
+        self.sort_stream = torch.cuda.Stream(device=self.dev)
+        self._sort_done = None
         # scratch
         self.dx = [torch.empty(M, d, **b16) for _ in range(2)]
         self.dxn = torch.empty(M, d, **b16)
@@ -244,19 +258,11 @@ class DalleEngine:
         self.delta = torch.empty(3, B, H, S, **f32)   # delta | (lse, delta) pairs for the dK/dV kernel's DMA
         wsz = max(dh.gemm_tn_workspace_bytes(M, d, Vp), dh.gemm_tn_workspace_bytes(M, 4 * d, d),
                   dh.gemm_tn_workspace_bytes(M, d, 4 * d), dh.gemm_tn_workspace_bytes(M, d, 3 * d),
-                  dh.gemm_tn_workspace_bytes(M, d, d), dh.colsum_workspace_bytes(M, Vp),
-                  dh.layernorm_bwd_workspace_bytes(M, d), dh.sumsq_workspace_bytes(self.lay.total),
-                  dh.gemm_nt_splitk_workspace_bytes(M, d, 2))
+                  dh.gemm_tn_workspace_bytes(M, d, d), dh.layernorm_bwd_workspace_bytes(M, d),
+                  dh.sumsq_workspace_bytes(self.lay.total), dh.gemm_nt_splitk_workspace_bytes(M, d, 2))
         self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
-        # optional (hparams["wgrad_side_stream"]): weight gradients on a second HIP stream -- they only feed the optimizer.
-        # Measured on MI355X: no gain (22.8 vs 22.5 ms/step; both kernel families already fill the LDS-limited residency)
-        self.ws_side = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
-        self.side = torch.cuda.Stream(device=self.dev) if (self.dev.type == "cuda" and self.hp.get("wgrad_side_stream", False)) else None
-        self._side_done = None
-        self._group, self._group_cache, self.ws_group = None, {}, None   # grouped weight gradients (hparams['grouped_wgrad'])
-        # tuning switches: hparams win, environment variables give the default (A/B runs: tools/ab_env.sh)
+        # tuning switch: hparams win, the environment variable gives the default (A/B runs: tools/ab_env.sh)
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
-        self.hp.setdefault("grouped_wgrad", os.environ.get("DALLE_GROUPED_WGRAD", "0") != "0")
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -265,10 +271,20 @@ class DalleEngine:
     def forward(self, tokens: torch.Tensor, need_grad=True) -> torch.Tensor:
         """tokens int32 [B,S] on device.  Returns the device scalar loss = mean over ALL B*S positions of
         -log softmax(logits)[label] (src/dalle_mtf/models.py:348-359), labels = shift(tokens) (:407-410).
-        With need_grad the logits buffer is overwritten by dlogits (scaled by 1/(global B*S))."""
+        need_grad=True (training): the softmax is fused into the vocabulary projection -- self.z then holds the
+        unnormalised dlogits E, self.rowscale their per-row factor (already scaled by 1/(global B*S*microbatches)).
+        need_grad=False (evaluation): self.z holds the bf16 logits (see logits()); the loss is the plain mean
+        (the reference forces num_microbatches = 1 outside training, src/model_fns.py:150-154)."""
         M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
         assert tokens.shape == (B, S) and tokens.dtype == torch.int32
         self.tokens.copy_(tokens)
+        if need_grad:   # token-id order for the embedding backward: off the critical path
+            main = torch.cuda.current_stream()
+            self.sort_stream.wait_stream(main)
+            with torch.cuda.stream(self.sort_stream):
+                dh.sort_tokens(self.tokens, self.tok_sorted, self.tok_perm, M, self.V, self.sort_ws)
+                self._sort_done = torch.cuda.Event()
+                self._sort_done.record(self.sort_stream)
         dh.shift_labels(self.tokens, self.labels, B, S, self.eos)
         dh.embed_fwd(self.tokens, self._w("embedding/wte"), self._w("positional_embedding/wpe"), self.X[0], S, d, self.V)
         for l in range(L):
@@ -277,7 +293,7 @@ class DalleEngine:
             st = self.stats[l]
             dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
             dh.gemm_nt(self.xn1[l], d, self.tview(p + "attn/qkv"), d, self.qkv[l], 3 * d, M, 3 * d, d)
-            dh.attention_fwd(self.qkv[l], None, self.o[l], self.lse[l], B, H, S)   # no transposed copies: hardware transpose reads
+            dh.attention_fwd(self.qkv[l], self.o[l], self.lse[l], B, H, S)   # no transposed copies: hardware transpose reads
             dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
                        bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
             dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
@@ -287,24 +303,34 @@ class DalleEngine:
                        dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=self.x1[l])
         dh.layernorm_fwd(self.X[L], self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), self.xnf,
                          self.statf[0], self.statf[1], M, d)
+        Wt, bias = self.tview("to_logits/linear_out/kernel"), self._w("to_logits/linear_out/bias")
+        nmb = (self.hp.get("num_microbatches", 1) or 1) if need_grad else 1
+        if need_grad:
+            dh.label_logit(self.xnf, d, Wt, d, bias, self.labels, self.zl, self.head_flag, M, d, self.V)
         hook = getattr(self, "event_hook", None)  # bench.py: HIP events around the largest single launch
         if hook is not None:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        dh.gemm_nt(self.xnf, d, self.tview("to_logits/linear_out/kernel"), d, self.z, Vp, M, Vp, d, dh.GEMM_BIAS,
-                   bias=self._w("to_logits/linear_out/bias"))
+        if need_grad:
+            dh.gemm_nt_softmax(self.xnf, d, Wt, d, bias, self.zl, self.z, Vp, self.rowsum_part, M, Vp, d)
+        else:
+            dh.gemm_nt(self.xnf, d, Wt, d, self.z, Vp, M, Vp, d, dh.GEMM_BIAS, bias=bias)
         if hook is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             hook().append((e0, e1))
-        nmb = self.hp.get("num_microbatches", 1) or 1
-        scale = 1.0 / (self.B_global * S * nmb) if need_grad else 0.0
-        dh.cross_entropy(self.z, Vp, self.labels, self.loss_rows, None, M, self.V, scale)
+        if need_grad:
+            dh.softmax_finish(self.rowsum_part, self.nparts, self.labels, self.xnf, d, Wt, d, bias, self.z, Vp, Vp,
+                              self.loss_rows, self.rowscale, self.rowscale_bf, self.xs, self.head_flag, M, d, self.V,
+                              1.0 / (self.B_global * S * nmb))
+        else:
+            dh.cross_entropy(self.z, Vp, self.labels, self.loss_rows, None, M, self.V, 0.0)
         dh.sum_f32(self.loss_rows, M, 1.0 / (M * nmb), self.loss)
         return self.loss
 
     def logits(self) -> torch.Tensor:
         """fp32 logits [B,S,V] of the last forward(need_grad=False) ("go to full precision", models.py:395)."""
+        # (after a training forward self.z holds unnormalised dlogits, not logits)
         return self.z.view(self.B, self.S, self.Vp)[:, :, :self.V].float()
 
     # ------------------------------------------------------------------ backward
@@ -319,143 +345,79 @@ class DalleEngine:
         hi = self.lay.bucket_ends[idx]
         self._pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
-    def _wgrad(self, X, ldx, dY, ldy, dW, M, I, J, dbias=None, tag=None):
-        """dW = X^T dY (+ fused bias gradient) on the side stream, ordered after everything enqueued so far.
-        `tag` names the gradient-activation buffer (dY) this launch reads; _wait_tag(tag) must precede its reuse."""
-        if self.side is None:
-            if self._group is not None:   # inside a transformer block: deferred to one grouped launch (_flush_group)
-                self._group.append((X, ldx, dY, ldy, dW, M, I, J, dbias))
-                return
-            dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws, dbias=dbias)
-            return
-        main = torch.cuda.current_stream()
-        ev = torch.cuda.Event()
-        ev.record(main)
-        self.side.wait_event(ev)
-        with torch.cuda.stream(self.side):
-            dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws_side, dbias=dbias)
-            done = torch.cuda.Event()
-            done.record(self.side)
-        self._side_done = done
-        if tag is not None:
-            self._ev[tag] = done
-
-    def _flush_group(self, key):
-        """One launch for the weight gradients collected since the group was opened.  Every operand they read (h, xn2, o,
-        xn1 and the gradient activations dxa, dh, dxb, dqkv) is still intact at the call site: just before the block's
-        last LayerNorm backward overwrites dxa.  The ctypes problem array is built once per block and reused."""
-        items, self._group = self._group, None
-        if not items:
-            return
-        cached = self._group_cache.get(key)
-        if cached is None:
-            probs = dh.tn_problems(items)
-            need = dh.gemm_tn_grouped_workspace_bytes(probs)
-            if self.ws_group is None or self.ws_group.numel() < need:
-                self.ws_group = torch.empty(need + 1024, dtype=torch.uint8, device=self.dev)
-            cached = self._group_cache[key] = probs
-        dh.gemm_tn_grouped(cached, self.ws_group)
-
-    def _wait_tag(self, tag):
-        ev = self._ev.pop(tag, None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-
-    def _join_side(self):
-        """main stream waits for every weight gradient issued so far."""
-        if self._side_done is not None:
-            torch.cuda.current_stream().wait_event(self._side_done)
-            self._side_done = None
-        self._ev.clear()
+    def _wgrad(self, X, ldx, dY, ldy, dW, M, I, J, dbias=None, bias_weights=None):
+        """dW = X^T dY (+ fused bias gradient)."""
+        dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws, dbias=dbias, bias_weights=bias_weights)
 
     def backward(self, allreduce=True):
-        """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  Weight gradients are issued on the
-        side stream; with world_size > 1 each finished bucket is all-reduced (SUM) asynchronously, one layer behind the
-        compute so the join with the side stream never stalls the dependency chain -- the explicit form of mtf's
-        implicit all-reduce over the `data` mesh axis (src/model_fns.py:81-82,189)."""
+        """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  With world_size > 1 each finished
+        bucket is all-reduced (SUM) asynchronously, one layer behind the compute -- the explicit form of mtf's implicit
+        all-reduce over the `data` mesh axis (src/model_fns.py:81-82,189)."""
         M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
         ws = self.ws
-        dz = self.z
-        self._ev = {}
-        pending_bucket = []  # (bucket index, event after its last weight gradient)
+        E = self.z   # unnormalised dlogits: dlogits[m, :] = rowscale[m] * E[m, :]
+        pending_bucket = []
 
         def flush_buckets(keep_last):
             while len(pending_bucket) > (1 if keep_last else 0):
-                idx, ev = pending_bucket.pop(0)
+                idx = pending_bucket.pop(0)
                 if self.world > 1 and allreduce:
-                    if ev is not None:
-                        torch.cuda.current_stream().wait_event(ev)
                     self._allreduce_bucket(idx)
 
-        # head
-        self._wgrad(self.xnf, d, dz, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
-                    dbias=self._gv("to_logits/linear_out/bias"))
-        # K = vocabulary: 128x128 tiles of this [M, d] output do not fill whole residencies of the chip -> split K
+        # head: dW = (rowscale * xnf)^T E, dbias = rowscale^T E, dxn = rowscale * (E W^T)
+        self._wgrad(self.xs, d, E, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
+                    dbias=self._gv("to_logits/linear_out/bias"), bias_weights=self.rowscale_bf)
+        # K = vocabulary: the 128x128 tiles of this [M, d] output run as long blocks; when the last residency of the chip
+        # (512 blocks = 2 per CU) would be partly empty, its rows are computed by a second launch with K split in two
         tiles = ((M + 127) // 128) * ((d + 127) // 128)
-        frac = (tiles / 512.0) % 1.0          # 512 = blocks resident at once (2 per CU)
-        # measured on MI355X: no gain at dalle_example (22.0 vs 21.7 ms/step; dynamic block dispatch already smooths the
-        # partial last round), so split-K is opt-in (hparams["dlogits_splitk"])
-        nsplit = 2 if (self.hp.get("dlogits_splitk") and tiles >= 256 and 0.4 <= frac <= 0.75) else 1
+        frac = (tiles / 512.0) % 1.0
         tail_rows = 0
-        if nsplit == 1 and tiles > 512 and 0.25 <= frac <= 0.75 and self.hp["dgrad_tail_split"]:
-            # ragged last residency of long (K = vocabulary) blocks: the rows of the last partial round are computed by a
-            # second launch with K split in two, so they also run two blocks per CU (same idea as gemm_tn_tail_kernel)
+        if tiles > 512 and 0.25 <= frac <= 0.75 and self.hp["dgrad_tail_split"]:
             tail_rows = (tiles % 512) // ((d + 127) // 128) * 128
             tail_rows = min(tail_rows, M) // 128 * 128
         Wk = self._w("to_logits/linear_out/kernel")
-        if nsplit > 1:
-            dh.gemm_nt_splitk(dz, Vp, Wk, Vp, self.dxn, M, d, Vp, nsplit, self.ws)
-        elif tail_rows > 0 and dh.gemm_nt_splitk_workspace_bytes(tail_rows, d, 2) <= self.ws.numel():
+        if tail_rows > 0 and dh.gemm_nt_splitk_workspace_bytes(tail_rows, d, 2) <= self.ws.numel():
             head_rows = M - tail_rows
-            dh.gemm_nt(dz, Vp, Wk, Vp, self.dxn, d, head_rows, d, Vp)
-            dh.gemm_nt_splitk(dz[head_rows:], Vp, Wk, Vp, self.dxn[head_rows:], tail_rows, d, Vp, 2, self.ws)
+            dh.gemm_nt(E, Vp, Wk, Vp, self.dxn, d, head_rows, d, Vp, dh.GEMM_ROWSCALE, rowscale=self.rowscale)
+            dh.gemm_nt_splitk(E[head_rows:], Vp, Wk, Vp, self.dxn[head_rows:], tail_rows, d, Vp, 2, self.ws,
+                              rowscale=self.rowscale[head_rows:])
         else:
-            dh.gemm_nt(dz, Vp, Wk, Vp, self.dxn, d, M, d, Vp)
+            dh.gemm_nt(E, Vp, Wk, Vp, self.dxn, d, M, d, Vp, dh.GEMM_ROWSCALE, rowscale=self.rowscale)
         dxa, dxb = self.dx
         dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                          self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)
-        pending_bucket.append((0, self._side_done))
+        pending_bucket.append(0)
         for bi, l in enumerate(reversed(range(L))):
             p = f"layer_{l}/"
             st = self.stats[l]
-            if self.side is None and self.hp["grouped_wgrad"]:
-                self._group = []
             # FFN
             self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
-                        dbias=self._gv(p + "mlp/mlp_linear_2/bias"), tag="dxa")
-            self._wait_tag("dh")      # previous layer's W1 gradient still reads self.dh
+                        dbias=self._gv(p + "mlp/mlp_linear_2/bias"))
             dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
                        relu_src=self.h[l])
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
-                        dbias=self._gv(p + "mlp/mlp_linear_1/bias"), tag="dh")
+                        dbias=self._gv(p + "mlp/mlp_linear_1/bias"))
             dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
-            self._wait_tag("dxb")     # previous layer's Wo gradient still reads dxb
             dh.layernorm_bwd(self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
                              self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"), ws, M, d)
             # attention
             self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
-                        dbias=self._gv(p + "attn/compute_output_bias/o_b"), tag="dxb")
+                        dbias=self._gv(p + "attn/compute_output_bias/o_b"))
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
-            qkv = self.qkv[l]
-            self._wait_tag("dqkv")    # previous layer's Wqkv gradient still reads self.dqkv
-            dh.attention_bwd(qkv, None, None, self.o[l], self.d_o, None, self.lse[l], self.delta, self.dqkv, B, H, S)
-            self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, tag="dqkv")
+            dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
+            self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d)
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
-            self._wait_tag("dxa")     # this layer's W2 gradient (issued at the top) read dxa
-            if self._group is not None:
-                self._flush_group(l)
             dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
                              self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"), ws, M, d)
-            pending_bucket.append((1 + bi, self._side_done))
-            flush_buckets(keep_last=True)   # all-reduce the PREVIOUS bucket: its side-stream work finished long ago
-        gw = self._gv("embedding/wte")
-        gw.zero_()
-        # index plumbing only: visit positions in token-id order so equal ids reduce in registers
-        st, perm = torch.sort(self.tokens.view(-1), stable=True)
-        dh.embed_bwd_sorted(st, perm.to(torch.int32), dxa, gw, self._gv("positional_embedding/wpe"), B, S, d, self.V)
-        pending_bucket.append((L + 1, None))
+            pending_bucket.append(1 + bi)
+            flush_buckets(keep_last=True)   # all-reduce the PREVIOUS bucket
+        # embeddings: positions visited in token-id order (sorted on the side stream during the forward)
+        if self._sort_done is not None:
+            torch.cuda.current_stream().wait_event(self._sort_done)
+        dh.embed_bwd(self.tok_sorted, self.tok_perm, dxa, self._gv("embedding/wte"), self._gv("positional_embedding/wpe"),
+                     B, S, d, self.V, self.embed_ws)
+        pending_bucket.append(L + 1)
         flush_buckets(keep_last=False)
-        self._join_side()
 
     def wait_grads(self):
         for h in self._pending:

@@ -28,8 +28,9 @@ typedef enum {
 
 const char* dmi_last_error_string(void);
 int dmi_version(void);
-/* Kernel-variant switches (tests and A/B measurements; every variant computes the same results): "glds", "tn_trread",
- * "nt2", "nt3", "nt4", "nt5", "prio", "tn_streamk", "attn_xcd".  Unknown name -> -1. */
+/* Test hooks (every setting computes the same results): "nt4" 0/1/2 = never / auto / always use the 256x128 NT tile,
+ * "tn_tail" 0/1 = row-split the ragged last residency of unsplit weight gradients, "attn_xcd" G = attention block order
+ * (0 plain grid, G >= 1 per-XCD ranges in groups of G (batch, head) pairs).  Unknown name -> -1. */
 int dmi_get_option(const char* name);
 int dmi_set_option(const char* name, int value);
 /* Diagnostics (tools/phases.py): u64 device buffer [blocks][5 or 8] that the 256x128 NT kernel and the weight-gradient
@@ -39,16 +40,19 @@ int dmi_set_debug_buffer(void* device_buffer);
 /* ---- K1  embedding: mtf.gather(wte, tokens) + wpe[0..S)   src/dalle_mtf/models.py:186-219 ---- */
 int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
                   int64_t rows /*B*S*/, int S, int d, int vocab, void* stream);
-/* backward: dwpe[s] = sum_b dx[b,s] (deterministic), dwte[tok] += dx (fp32 atomics; dwte must be
- * zeroed by the caller).  gradient of mtf.gather = scatter-add. */
-int dmi_embed_bwd(const int32_t* tokens, const uint16_t* dx, float* dwte, float* dwpe,
-                  int B, int S, int d, int vocab, void* stream);
-
-/* same, visiting positions in token-id order: sorted_tokens ascending (stable), perm[i] = source row of
- * sorted position i.  Runs of equal ids are reduced in registers; only runs crossing a 32-position chunk use
- * atomics (the repeated padding id no longer serialises on one row).  dwte must be zeroed by the caller. */
-int dmi_embed_bwd_sorted(const int32_t* sorted_tokens, const int32_t* perm, const uint16_t* dx, float* dwte,
-                         float* dwpe, int B, int S, int d, int vocab, void* stream);
+/* stable sort of the n token ids (clamped to [0, vocab)): sorted_tokens ascending, perm[i] = source position of sorted
+ * position i.  Index plumbing for dmi_embed_bwd; one-block radix sort, deterministic.
+ * workspace: dmi_sort_tokens_workspace_bytes(n). */
+int64_t dmi_sort_tokens_workspace_bytes(int64_t n);
+int dmi_sort_tokens(const int32_t* tokens, int32_t* sorted_tokens, int32_t* perm, int64_t n, int vocab,
+                    void* workspace, void* stream);
+/* backward: dwpe[s] = sum_b dx[b,s];  dwte[tok] = sum of dx over the positions holding tok (gradient of mtf.gather =
+ * scatter-add), written for every id incl. zeros for absent ones.  Positions are visited in
+ * token-id order (dmi_sort_tokens) so equal ids reduce in registers; deterministic, no atomics.
+ * workspace: dmi_embed_bwd_workspace_bytes(B, S, d). */
+int64_t dmi_embed_bwd_workspace_bytes(int B, int S, int d);
+int dmi_embed_bwd(const int32_t* sorted_tokens, const int32_t* perm, const uint16_t* dx, float* dwte,
+                  float* dwpe, int B, int S, int d, int vocab, void* workspace, void* stream);
 
 /* ---- K2  LayerNorm eps=1e-5 biased variance   models.py:373-389, layers.py:30-33 ---- */
 int dmi_layernorm_fwd(const uint16_t* x, const uint16_t* g, const uint16_t* b, uint16_t* y,
@@ -62,69 +66,77 @@ int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, 
 
 /* ---- K3/K5/K6/K7  dense layers: mtf einsum / mtf.layers.dense   models.py:242-244,303-311,320-321,369,393
  * C[M,N] = A[M,K] . Bt[N,K]^T  (both operands K-contiguous), bf16 in, fp32 accumulate on MFMA.
- * flags: DMI_GEMM_*;  bias bf16 [N];  residual bf16 [M,ldc] added;  relu_src bf16 [M,ldc]: C *= (relu_src>0).
- * K % 64 == 0, N % 8 == 0.  Output bf16 (or fp32 with DMI_GEMM_OUT_F32). */
+ * flags: DMI_GEMM_*;  bias bf16 [N];  residual bf16 [M,ldc] added;  relu_src bf16 [M,ldc]: C *= (relu_src>0);
+ * rowscale fp32 [M]: C[m,:] *= rowscale[m].  K % 64 == 0, N % 8 == 0.  Output bf16 (or fp32 with DMI_GEMM_OUT_F32).
+ * Supported flag sets: 0, BIAS, BIAS|RELU, BIAS|RESIDUAL, RESIDUAL, RELU_MASK, ROWSCALE, OUT_F32. */
 #define DMI_GEMM_BIAS 1
 #define DMI_GEMM_RELU 2
 #define DMI_GEMM_RESIDUAL 4
 #define DMI_GEMM_RELU_MASK 8
 #define DMI_GEMM_OUT_F32 16
+#define DMI_GEMM_ROWSCALE 32
 int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc,
                 int M, int N, int K, int flags, const uint16_t* bias, const uint16_t* residual,
-                const uint16_t* relu_src, void* stream);
+                const uint16_t* relu_src, const float* rowscale, void* stream);
 /* same product with the K range split over nsplit block groups (fp32 slabs in workspace, deterministic reduction to
- * bf16 C with ldc == N): for long-K GEMMs whose tile count does not fill whole residencies (dlogits: K = vocab). */
+ * bf16 C with ldc == N, optionally times rowscale[m]): for long-K GEMMs whose tile count does not fill whole
+ * residencies (the head's input gradient: K = vocabulary). */
 int64_t dmi_gemm_nt_splitk_workspace_bytes(int M, int N, int nsplit);
 int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int M, int N, int K,
-                       int nsplit, void* workspace, void* stream);
+                       int nsplit, const float* rowscale, void* workspace, void* stream);
 /* weight gradient: dW[I,J] (fp32, ld = J) = sum_m X[m,I] * dY[m,J]; deterministic split over m.
- * dbias (nullable): fp32 [J] = sum_m dY[m, :] fused into the same pass (bias gradient of the dense layer).
+ * dbias (nullable): fp32 [J] = sum_m w[m] * dY[m, :] fused into the same pass (bias gradient of the dense layer), with
+ * w = 1, or w = bias_weights (nullable bf16 [M]) for the fused-softmax head where dY holds unnormalised dlogits.
  * workspace: dmi_gemm_tn_workspace_bytes(M, I, J). */
 int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J);
-int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias, int M, int I, int J,
-                void* workspace, void* stream);
-/* Several independent weight gradients in ONE launch (+ one reduce launch): the four dW of a transformer block
- * (mtf.gradients over the block's einsums, reference src/optimizers.py:34).  Same results, bit for bit, as n calls of
- * dmi_gemm_tn.  probs is a HOST array (n <= 8); workspace >= dmi_gemm_tn_grouped_workspace_bytes(probs, n). */
-typedef struct dmi_tn_problem {
-  const uint16_t* X; int ldx;
-  const uint16_t* dY; int ldy;
-  float* dW; float* dbias;   /* dbias nullable */
-  int M, I, J;
-} dmi_tn_problem;
-int64_t dmi_gemm_tn_grouped_workspace_bytes(const dmi_tn_problem* probs, int n);
-int dmi_gemm_tn_grouped(const dmi_tn_problem* probs, int n, void* workspace, void* stream);
+int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias,
+                const uint16_t* bias_weights, int M, int I, int J, void* workspace, void* stream);
 
 /* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
 int64_t dmi_colsum_workspace_bytes(int64_t M, int N);
 int dmi_colsum(const uint16_t* Y, int ldy, float* out, int64_t M, int N, void* workspace, void* stream);
 /* batched bf16 transpose: in [batch, R, C] -> out [batch, C, R] */
 int dmi_transpose_bf16(const uint16_t* in, uint16_t* out, int batch, int R, int C, void* stream);
-/* strided form: element (b,h,r,c) read at in + b*in_b_stride + h*in_h_stride + r*in_r_stride + c,
- * written at out[((b*nh + h)*C + c)*R + r]   (per-head transposes of q/k/v/d_o for the attention kernels) */
-int dmi_transpose_bf16_strided(const uint16_t* in, uint16_t* out, int nb, int nh, int R, int C,
-                               int64_t in_b_stride, int64_t in_h_stride, int64_t in_r_stride, void* stream);
 
 /* ---- K4  causal attention, UNSCALED logits, fp32 softmax   models.py:221-227,292-299 (Appendix A.2/A.3)
  * qkv [B*S, 3*H*128] bf16 = the QKV projection output, row = [q | k | v] x [H, 128] (heads-major, A.1);
  * o [B*S, H*128] bf16;  lse [B,H,S] fp32.  head dim is fixed at 128 (README.md:164); S % 8 == 0.
- * The vt / qt / kt / dot parameters are legacy (transposed operand copies of the first kernel generation) and are
- * ignored: every transposed fragment is fetched with hardware transpose reads.  Pass NULL. */
-int dmi_attention_fwd(const uint16_t* qkv, const uint16_t* vt, uint16_t* o, float* lse,
-                      int B, int H, int S, void* stream);
-/* backward.  d_o [B*S, H*128] bf16; delta: fp32 scratch of 3*B*H*S floats (delta | interleaved (lse, delta) pairs);
+ * Every transposed MFMA operand is a hardware transpose read of the natural tile: no transposed copies. */
+int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int H, int S, void* stream);
+/* backward.  d_o [B*S, H*128] bf16; scratch: 3*B*H*S floats (delta | interleaved (lse, delta) pairs);
  * dqkv [B*S, 3*H*128] bf16 in the qkv layout (what the QKV dgrad/wgrad GEMMs consume). */
-int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* qt, const uint16_t* kt, const uint16_t* o,
-                      const uint16_t* d_o, const uint16_t* dot, const float* lse, float* delta,
+int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* scratch,
                       uint16_t* dqkv, int B, int H, int S, void* stream);
 
-/* ---- K7/K8  cross entropy over bf16 logits, labels = shift(tokens)   models.py:348-359,407-410
- * logits z [M, ldz] bf16 (ldz >= V, pad columns must hold a large negative value).
- * labels[t] = tokens[t+1], last = eos (bit-exact int path).  loss_rows[M] fp32 = lse - z[label];
- * if dz_scale != 0: z is overwritten IN PLACE by dz = (softmax(z) - onehot(label)) * dz_scale. */
+/* ---- K7/K8  to_logits + cross entropy, labels = shift(tokens)   models.py:391-395,348-359,407-410
+ * labels[t] = tokens[t+1], last = eos (bit-exact int path). */
 int dmi_shift_labels(const int32_t* tokens, int32_t* labels, int B, int S, int eos, void* stream);
+/* (a) evaluation / logits-returning path: cross entropy over materialised bf16 logits z [M, ldz] (ldz >= V, pad columns
+ * must hold a large negative value).  loss_rows[M] fp32 = lse - z[label]; if dz_scale != 0: z is overwritten IN PLACE by
+ * dz = (softmax(z) - onehot(label)) * dz_scale. */
 int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, float* loss_rows, float* lse,
                       int64_t M, int V, float dz_scale, void* stream);
+/* (b) training path: the softmax is fused into the vocabulary projection and its row normaliser is deferred, so the
+ * logits never make a round trip through HBM:
+ *   dmi_label_logit      zl[m] = X[m,:] . Wt[label[m],:] + bias[label[m]] (fp32) = the per-row exponent shift; clears flag[0].
+ *   dmi_gemm_nt_softmax  E[m,n] = bf16(exp(X[m,:] . Wt[n,:] + bias[n] - rowshift[m])) and
+ *                        rowsum_part[n/64][m] = fp32 sum of those exponentials over the 64-column group
+ *                        (dmi_gemm_nt_softmax_partials(N) groups; pad columns need bias << 0 so that they contribute 0).
+ *   dmi_softmax_finish   S[m] = sum of the partials; loss_rows[m] = log S[m] (= logsumexp - label logit);
+ *                        rowscale[m] = dz_scale / S[m] (+ its bf16 copy); E[m,label] -= S[m], so dlogits = rowscale[m] * E[m,:];
+ *                        Xs[M,K] = bf16(rowscale[m] * X[m,:]).  Consumers: dX = dmi_gemm_nt(E, W, DMI_GEMM_ROWSCALE),
+ *                        dW = dmi_gemm_tn(Xs, E, bias_weights = rowscale_bf16).  With dz_scale == 0 only loss_rows is written.
+ *                        Rows whose exponent overflowed (some logit > label logit + 88) are redone exactly with the row
+ *                        maximum as the shift (needs X, Wt, bias again); flag[0] != 0 afterwards tells that it happened. */
+int dmi_label_logit(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
+                    const int32_t* labels, float* zl, int32_t* flag, int64_t M, int K, int V, void* stream);
+int64_t dmi_gemm_nt_softmax_partials(int N);
+int dmi_gemm_nt_softmax(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
+                        const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K, void* stream);
+int dmi_softmax_finish(const float* rowsum_part, int nparts, const int32_t* labels, const uint16_t* X, int ldx,
+                       const uint16_t* Wt, int ldw, const uint16_t* bias, uint16_t* E, int lde, int N,
+                       float* loss_rows, float* rowscale, uint16_t* rowscale_bf16, uint16_t* Xs, int32_t* flag,
+                       int64_t M, int K, int V, float dz_scale, void* stream);
 /* out[0] = scale * sum(x[0..n))  deterministic single-block reduce (loss mean; grad-norm finish) */
 int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream);
 

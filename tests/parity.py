@@ -1,9 +1,18 @@
-"""On-device self-check used by __graft_entry__.smoke() and tests/: one tiny DALL-E train step through the
-HIP engine vs the CPU oracle on identical weights and tokens.  The oracle is imported HERE (checker only)."""
+"""On-device parity harness used by tests/ and __graft_entry__.smoke(): DALL-E train steps through the HIP engine vs the
+CPU oracle on identical weights and tokens.  TEST INFRASTRUCTURE: the oracle is imported HERE (checker only); nothing in
+the product package imports this file."""
+import json
 import math
+import os
+import sys
 
 import numpy as np
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "dalle-mtf_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def rel_l2(a, b):
@@ -12,14 +21,24 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
+def save_report(name, obj):
+    """best effort: parity tables land under gpurun_out/ (copied to profiles/ by the author)."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, name), "w") as f:
+            json.dump(obj, f, indent=1, default=lambda o: float(o) if isinstance(o, (np.floating,)) else str(o))
+    except OSError:
+        pass
+
+
 def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=64, T=16, P=112, B=2, seed=0,
-                 steps=2, verbose=True, hp=None):
+                 steps=2, verbose=True, hp=None, perturb=0.05, bf16_oracle=True, per_tensor=False):
     from oracle import dalle_oracle as do
-    from .dalle_mtf.engine import DalleEngine
+    from src.dalle_mtf.engine import DalleEngine
     cfg = do.DalleConfig(n_embd, text_vocab, image_vocab, T, P, n_layers, n_heads)
     hp = dict(hp or dict(lr=1e-3, train_steps=1000, warmup_steps=2, gradient_clipping=1.0))
-    P0 = do.init_params(cfg, seed=1234 + seed, perturb=0.05)
-    rng = np.random.default_rng(seed)
+    P0 = do.init_params(cfg, seed=1234 + seed, perturb=perturb)
     text = do.synthetic_captions(B, T, text_vocab, seed=seed + 1)
     img = do.synthetic_image_tokens(B, P, image_vocab, seed=seed + 2)
     tokens = do.assemble_tokens(text, img, text_vocab)
@@ -30,16 +49,21 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
     Po = {k: v.copy() for k, v in P0.items()}
     m = {k: np.zeros_like(v) for k, v in P0.items()}
     v = {k: np.zeros_like(v) for k, v in P0.items()}
-    report = {"steps": []}
+    report = {"config": dict(n_embd=n_embd, n_heads=n_heads, n_layers=n_layers, V=cfg.total_tokens, S=T + P, B=B), "steps": []}
     for step in range(steps):
         loss_o32, g32 = do.loss_and_grads(Po, tokens, cfg, bf16=False)
-        loss_o16, g16 = do.loss_and_grads(Po, tokens, cfg, bf16=True)
         loss_h = float(eng.forward(tok_d, need_grad=True).item())
         eng.backward()
         eng.wait_grads()
         gh = eng.export_reference(eng.g)
-        worst = max(((rel_l2(gh[k], g16[k]), k) for k in g16), key=lambda t: t[0])
-        worst32 = max(((rel_l2(gh[k], g32[k]), k) for k in g32), key=lambda t: t[0])
+        table32 = {k: rel_l2(gh[k], g32[k]) for k in g32}
+        worst32 = max(((e, k) for k, e in table32.items()), key=lambda t: t[0])
+        rec = dict(step=step, loss_hip=loss_h, loss_oracle_fp32=loss_o32, worst_grad_rel_l2_vs_fp32_oracle=worst32,
+                   head_fixup_flag=int(eng.head_flag.item()))
+        if bf16_oracle:
+            loss_o16, g16 = do.loss_and_grads(Po, tokens, cfg, bf16=True)
+            rec["loss_oracle_bf16"] = loss_o16
+            rec["worst_grad_rel_l2_vs_bf16_oracle"] = max(((rel_l2(gh[k], g16[k]), k) for k in g16), key=lambda t: t[0])
         gn_h = math.sqrt(sum(float((gh[k].astype(np.float64) ** 2).sum()) for k in gh))
         gn_o = math.sqrt(sum(float((g32[k].astype(np.float64) ** 2).sum()) for k in g32))
         eng.global_step = step + 1  # past step 0 (lr(0) = 0 under warm-up)
@@ -49,26 +73,31 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
         do.adam_step(Po, gc, m, v, do.learning_rate(step + 1, hp["lr"], hp["train_steps"], hp.get("warmup_steps", 3000)))
         ph = eng.export_reference(eng.p)
         pw = max(((float(np.abs(ph[k] - Po[k]).max()), k) for k in Po), key=lambda t: t[0])
-        rec = dict(step=step, loss_hip=loss_h, loss_oracle_fp32=loss_o32, loss_oracle_bf16=loss_o16,
-                   worst_grad_rel_l2_vs_bf16_oracle=worst, worst_grad_rel_l2_vs_fp32_oracle=worst32,
-                   grad_norm_hip=gn_h, grad_norm_oracle=gn_o, lr=lr, worst_param_abs_diff=pw)
+        rec.update(grad_norm_hip=gn_h, grad_norm_oracle=gn_o, lr=lr, worst_param_abs_diff=pw)
+        if per_tensor:
+            rec["grad_rel_l2"] = table32
         report["steps"].append(rec)
         if verbose:
-            print(rec, flush=True)
+            print({k: v for k, v in rec.items() if k != "grad_rel_l2"}, flush=True)
+            if per_tensor:
+                for k, e in sorted(table32.items(), key=lambda t: -t[1])[:12]:
+                    print(f"    rel-L2 {e:.4f}  {k}", flush=True)
+    del eng
+    torch.cuda.empty_cache()
     return report
 
 
-def check_report(report, loss_rtol=1e-2, grad_tol=6e-2, gn_rtol=3e-2):
-    """bf16 compute vs the fp32 oracle: loss within 1e-2 relative; every gradient tensor within
-    6e-2 relative L2 on the first step (identical weights) and 1e-1 afterwards (weights have drifted by the
-    sign-like first Adam updates); global grad-norm within 3e-2.
+def check_report(report, loss_rtol=2e-3, grad_tol=5e-2, grad_tol_later=0.1, gn_rtol=1e-2):
+    """bf16 compute vs the fp32 oracle: relative loss error, every gradient tensor's relative L2 error on
+    the first step (identical weights) and afterwards (weights have drifted by the sign-like first Adam updates), global
+    grad-norm.  Bounds = measured on MI355X + 25 % (profiles/r02_parity_*.json hold the measured tables).
     Parameters: Adam WITHOUT bias correction moves a weight by lr*0.1g/(sqrt(0.001)|g|+eps) ~= 3.16*lr on its first
     step whatever |g| is, so a noise-level gradient whose sign differs costs 2*3.16*lr: bound 6.5*lr per element
     (exactness of the update rule itself on identical gradients is pinned by test_sumsq_adam_cast)."""
     for r in report["steps"]:
         first = r["step"] == 0
         assert abs(r["loss_hip"] - r["loss_oracle_fp32"]) <= loss_rtol * abs(r["loss_oracle_fp32"]), r
-        assert r["worst_grad_rel_l2_vs_fp32_oracle"][0] <= (grad_tol if first else 0.1), r
+        assert r["worst_grad_rel_l2_vs_fp32_oracle"][0] <= (grad_tol if first else grad_tol_later), r
         assert abs(r["grad_norm_hip"] - r["grad_norm_oracle"]) <= gn_rtol * r["grad_norm_oracle"], r
         assert r["worst_param_abs_diff"][0] <= 6.5 * r["lr"] * (1 if first else 2) + 1e-6, r
 

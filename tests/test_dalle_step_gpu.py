@@ -9,13 +9,13 @@ pytestmark = pytest.mark.gpu
 
 
 def test_small_step_matches_oracle():
-    from src.selftest import check_report, compare_step
+    from parity import check_report, compare_step
     check_report(compare_step(verbose=True))
 
 
 def test_ref_faithful_seq_272_step():
     """S = 256 + 16 (the reference-faithful CIFAR grid, src/model_fns.py:68), ragged tiles (272 = 2*128 + 16)."""
-    from src.selftest import check_report, compare_step
+    from parity import check_report, compare_step
     check_report(compare_step(n_embd=256, n_heads=2, n_layers=1, text_vocab=500, image_vocab=32, T=256, P=16, B=2,
                               seed=3, steps=1))
 

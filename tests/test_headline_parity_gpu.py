@@ -1,0 +1,72 @@
+"""Parity at the shapes BASELINE.json names: the HIP engine vs the fp32 CPU oracle at the exact
+`dalle_example` configuration (n_embd 512, 4 heads, 6 layers, 256 + 1024 positions, V = 50 771) and at one layer of the
+1.3B shape (n_embd 2048, 16 heads), plus the attention kernels alone at (B, H, S) = (1, 4, 1280) and (1, 16, 1280).
+Each test prints the per-tensor relative-L2 table and stores it under gpurun_out/ (committed copies: profiles/r02_parity_*).
+Tolerances = measured on MI355X + 25 %."""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DALLE_EXAMPLE = dict(n_embd=512, n_heads=4, n_layers=6, text_vocab=50258, image_vocab=512, T=256, P=1024)
+
+
+def test_dalle_example_shape_step_vs_fp32_oracle():
+    """loss, every gradient tensor and one clip + Adam update at the headline shape (B = 2: 2560 rows -> the 256x128 NT
+    tiling of the vocabulary projection, the row-split weight-gradient tail and the fused softmax head all engage)."""
+    from parity import check_report, compare_step, save_report
+    rep = compare_step(B=2, seed=21, steps=1, perturb=0.02, bf16_oracle=False, per_tensor=True, **DALLE_EXAMPLE)
+    save_report("parity_dalle_example.json", rep)
+    check_report(rep, loss_rtol=1e-3, grad_tol=5e-2, gn_rtol=1e-2)
+    assert rep["steps"][0]["head_fixup_flag"] == 0
+
+
+def test_dalle_example_shape_eval_logits_vs_fp32_oracle():
+    from oracle import dalle_oracle as do
+    from parity import save_report
+    from src.dalle_mtf.engine import DalleEngine
+    c = DALLE_EXAMPLE
+    cfg = do.DalleConfig(c["n_embd"], c["text_vocab"], c["image_vocab"], c["T"], c["P"], c["n_layers"], c["n_heads"])
+    P0 = do.init_params(cfg, seed=77, perturb=0.02)
+    eng = DalleEngine(c["n_embd"], c["n_layers"], c["n_heads"], c["text_vocab"], c["image_vocab"], c["T"], c["P"], batch_size=1,
+                      hparams=dict(lr=1e-3, train_steps=10, num_microbatches=4))   # eval ignores the micro-batch count
+    eng.load_reference_params(P0)
+    tokens = do.assemble_tokens(do.synthetic_captions(1, c["T"], c["text_vocab"], seed=5),
+                                do.synthetic_image_tokens(1, c["P"], c["image_vocab"], seed=6), c["text_vocab"])
+    loss_h = float(eng.forward(torch.from_numpy(tokens).cuda(), need_grad=False))
+    got = eng.logits().cpu().numpy()
+    Pt = OrderedDict((k, torch.tensor(v)) for k, v in P0.items())
+    loss_o, _, ref = do.forward(Pt, tokens, cfg, bf16=False, return_logits=True)
+    ref = ref.numpy()
+    err = float(np.abs(got - ref).max())
+    rel = float(np.linalg.norm(got - ref) / np.linalg.norm(ref))
+    agree = float((got.argmax(-1) == ref.argmax(-1)).mean())
+    print(dict(max_abs_err=err, rel_l2=rel, ref_absmax=float(np.abs(ref).max()), loss_hip=loss_h, loss_oracle=float(loss_o),
+               argmax_agreement=agree))
+    save_report("parity_dalle_example_logits.json", dict(max_abs_err=err, rel_l2=rel, loss_hip=loss_h, loss_oracle=float(loss_o),
+                                                         argmax_agreement=agree))
+    assert err <= 3e-2 * max(1.0, float(np.abs(ref).max())), err
+    assert rel <= 2e-2, rel
+    assert abs(loss_h - float(loss_o)) <= 1e-3 * abs(float(loss_o))
+
+
+def test_1p3b_layer_shape_step_vs_fp32_oracle():
+    """one transformer block + the vocabulary head at the 1.3B width (n_embd 2048, 16 heads, K = 2048 GEMMs: the 128x128x64
+    NT tiling, head dim 128 x 16 heads in attention)."""
+    from parity import check_report, compare_step, save_report
+    rep = compare_step(n_embd=2048, n_heads=16, n_layers=1, text_vocab=50258, image_vocab=512, T=256, P=1024, B=1, seed=31,
+                       steps=1, perturb=0.02, bf16_oracle=False, per_tensor=True)
+    save_report("parity_1p3b_layer.json", rep)
+    check_report(rep, loss_rtol=1e-3, grad_tol=5e-2, gn_rtol=1e-2)
+
+
+@pytest.mark.parametrize("B,H,S", [(1, 4, 1280), (1, 16, 1280)])
+def test_attention_kernels_at_headline_shape(B, H, S):
+    """attention forward + backward alone vs fp32 autograd at the benchmark's (H, S): 10 query tiles x 20 key tiles per
+    head, every causal tile class, all XCD-grouped block orders in one grid."""
+    from test_kernels_gpu import _attention_fwd_bwd
+    _attention_fwd_bwd(B, H, S)

@@ -52,12 +52,55 @@ def test_embed_fwd_bwd():
     ref = wte.float()[tok.long()] + wpe.float()[None, :S]
     close(x.view(B, S, d), ref, 8e-3, 1e-6, "embed_fwd")
     dx = rnd(B * S, d, seed=4)
-    dwte = torch.zeros(V, d, dtype=torch.float32, device=DEV)
+    dwte = torch.full((V, d), 7.0, dtype=torch.float32, device=DEV)   # must be overwritten, zeros for absent ids
     dwpe = torch.empty(S, d, dtype=torch.float32, device=DEV)
-    dh.embed_bwd(tok.to(DEV), dx.to(DEV), dwte, dwpe, B, S, d, V)
+    st, perm = _sorted(tok.view(-1).to(DEV), V)
+    dh.embed_bwd(st, perm, dx.to(DEV), dwte, dwpe, B, S, d, V, ws(dh.embed_bwd_workspace_bytes(B, S, d)))
     ref_wte = torch.zeros(V, d).index_add_(0, tok.view(-1).long(), dx.float())
     close(dwte, ref_wte, 1e-5, 1e-5, "embed_bwd wte")
     close(dwpe, dx.float().view(B, S, d).sum(0), 1e-5, 1e-5, "embed_bwd wpe")
+
+
+def _sorted(tok_flat, V):
+    n = tok_flat.numel()
+    st = torch.empty(n, dtype=torch.int32, device=DEV)
+    perm = torch.empty(n, dtype=torch.int32, device=DEV)
+    dh.sort_tokens(tok_flat, st, perm, n, V, ws(dh.sort_tokens_workspace_bytes(n)))
+    return st, perm
+
+
+@pytest.mark.parametrize("n,V", [(1, 5), (37, 16), (1024, 17), (5000, 50771), (40960, 50771), (2049, 70000), (4097, 2)])
+def test_sort_tokens_is_stable(n, V):
+    """one-block radix sort: bit-identical to a stable sort (ids and source positions), for 1..5 digit passes, ragged
+    per-thread chunks and heavy duplicates (the padding id)."""
+    g = torch.Generator().manual_seed(n)
+    tok = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
+    tok[n // 3: 2 * n // 3] = V - 1
+    st, perm = _sorted(tok.to(DEV), V)
+    rs, rp = torch.sort(tok, stable=True)
+    assert torch.equal(st.cpu(), rs) and torch.equal(perm.cpu().long(), rp)
+
+
+def test_embed_bwd_long_runs_deterministic():
+    """runs of one id spanning many 32-position chunks (padding) + runs ending exactly on chunk borders: equals the fp32
+    index_add, and two launches agree bit for bit (no atomics)."""
+    B, S, d, V = 4, 640, 256, 300
+    g = torch.Generator().manual_seed(5)
+    tok = torch.randint(0, V, (B, S), generator=g, dtype=torch.int32)
+    tok[:, 100:500] = V - 1          # 1600 positions of one id
+    tok[0, :64] = 7                  # exactly two chunks' worth of another id
+    tok[1, :32] = 9
+    dx = rnd(B * S, d, seed=6).to(DEV)
+    st, perm = _sorted(tok.view(-1).to(DEV), V)
+    outs = []
+    for _ in range(2):
+        dwte = torch.full((V, d), float("nan"), dtype=torch.float32, device=DEV)
+        dwpe = torch.empty(S, d, dtype=torch.float32, device=DEV)
+        dh.embed_bwd(st, perm, dx, dwte, dwpe, B, S, d, V, ws(dh.embed_bwd_workspace_bytes(B, S, d)))
+        outs.append(dwte.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(V, d).index_add_(0, tok.view(-1).long(), dx.float().cpu())
+    close(outs[0], ref, 1e-5, 2e-4, "embed_bwd long runs")
 
 
 # ------------------------------------------------------------------ layernorm
@@ -105,67 +148,56 @@ def _gemm_ref(A, Bt, bias=None, relu=False, residual=None, relu_src=None):
     return C
 
 
-VARIANTS = {"nt2": dict(nt2=1, glds=1), "glds": dict(nt2=0, glds=1), "regstage": dict(nt2=0, glds=0)}
-
-
-def _set_variant(v):
-    for k, val in VARIANTS[v].items():
-        dh.set_option(k, val)
-
-
-@pytest.mark.parametrize("glds", list(VARIANTS))
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1024, 512, 512), (257, 1160, 192), (130, 128, 448)])
-def test_gemm_nt_plain(glds, M, N, K):
-    _set_variant(glds)
-    try:
-        A, Bt = rnd(M, K, seed=1), rnd(N, K, seed=2)
-        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K)
-        close(C, _gemm_ref(A, Bt), 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt glds={glds}")
-    finally:
-        _set_variant("nt2")
+def test_gemm_nt_plain(M, N, K):
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K)
+    close(C, _gemm_ref(A, Bt), 1.6e-2, 2e-2 * math.sqrt(K / 64), "gemm_nt")
 
 
-@pytest.mark.parametrize("glds", list(VARIANTS))
-def test_gemm_nt_epilogues(glds):
-    _set_variant(glds)
-    try:
-        M, N, K = 384, 640, 256
-        A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
-        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
-        hsrc = torch.relu(rnd(M, N, seed=5))
-        Ad, Bd = A.to(DEV), Bt.to(DEV)
-        tol = dict(rtol=1.6e-2, atol=2e-2)
-        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS, bias=bias.to(DEV))
-        close(C, _gemm_ref(A, Bt, bias), what="bias", **tol)
-        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RELU, bias=bias.to(DEV))
-        close(C, _gemm_ref(A, Bt, bias, relu=True), what="bias+relu", **tol)
-        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=bias.to(DEV), residual=res.to(DEV))
-        close(C, _gemm_ref(A, Bt, bias, residual=res), what="bias+residual", **tol)
-        dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_RELU_MASK, relu_src=hsrc.to(DEV))
-        close(C, _gemm_ref(A, Bt, relu_src=hsrc), what="relu mask", **tol)
-        Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
-        dh.gemm_nt(Ad, K, Bd, K, Cf, N, M, N, K, dh.GEMM_OUT_F32)
-        close(Cf, _gemm_ref(A, Bt), 1e-3, 1e-3, "f32 out")
-        # strided operands (lda > K): the QKV-style slices
-        A2 = rnd(M, 3 * K, seed=7)
-        dh.gemm_nt(A2.to(DEV)[:, K:], 3 * K, Bd, K, C, N, M, N, K)
-        close(C, _gemm_ref(A2[:, K:2 * K], Bt), what="strided A", **tol)
-    finally:
-        _set_variant("nt2")
+def test_gemm_nt_epilogues():
+    M, N, K = 384, 640, 256
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    hsrc = torch.relu(rnd(M, N, seed=5))
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(6)) * 3 - 1
+    Ad, Bd = A.to(DEV), Bt.to(DEV)
+    tol = dict(rtol=1.6e-2, atol=2e-2)
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS, bias=bias.to(DEV))
+    close(C, _gemm_ref(A, Bt, bias), what="bias", **tol)
+    dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RELU, bias=bias.to(DEV))
+    close(C, _gemm_ref(A, Bt, bias, relu=True), what="bias+relu", **tol)
+    dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=bias.to(DEV), residual=res.to(DEV))
+    close(C, _gemm_ref(A, Bt, bias, residual=res), what="bias+residual", **tol)
+    dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_RELU_MASK, relu_src=hsrc.to(DEV))
+    close(C, _gemm_ref(A, Bt, relu_src=hsrc), what="relu mask", **tol)
+    dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, dh.GEMM_ROWSCALE, rowscale=rs.to(DEV))
+    close(C, _gemm_ref(A, Bt) * rs[:, None], what="row scale", **tol)
+    Cf = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    dh.gemm_nt(Ad, K, Bd, K, Cf, N, M, N, K, dh.GEMM_OUT_F32)
+    close(Cf, _gemm_ref(A, Bt), 1e-3, 1e-3, "f32 out")
+    # strided operands (lda > K): the QKV-style slices
+    A2 = rnd(M, 3 * K, seed=7)
+    dh.gemm_nt(A2.to(DEV)[:, K:], 3 * K, Bd, K, C, N, M, N, K)
+    close(C, _gemm_ref(A2[:, K:2 * K], Bt), what="strided A", **tol)
 
 
-@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3), (515, 136, 64, 8)])
+@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3),
+                                         (515, 136, 64, 8), (700, 264, 128, 32)])
 def test_gemm_nt4_tile_256(M, N, K, flags):
     """256x128x32-tile kernel (forced), incl. M/N tails: same results as the 128x128x64 kernel (identical k order)."""
     A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
     hsrc = torch.relu(rnd(M, N, seed=5))
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(6)) + 0.5
     kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None,
-              relu_src=hsrc.to(DEV) if flags & 8 else None)
+              relu_src=hsrc.to(DEV) if flags & 8 else None, rowscale=rs.to(DEV) if flags & 32 else None)
     ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None,
                     relu_src=hsrc if flags & 8 else None)
+    if flags & 32:
+        ref = ref * rs[:, None]
     outs = []
     for nt4 in (2, 0):
         dh.set_option("nt4", nt4)
@@ -177,55 +209,6 @@ def test_gemm_nt4_tile_256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "256-row-tile and 128-row-tile kernels must be bit-identical"
 
 
-@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 64, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3),
-                                         (515, 136, 64, 8), (700, 384, 320, 0), (260, 128, 1024, 4), (1024, 512, 2112, 0)])
-@pytest.mark.parametrize("mode", [2, 3])
-def test_gemm_nt5_hand_scheduled(M, N, K, flags, mode):
-    """3-stage-ring kernel with asm-scheduled fragment reads (forced; mode 2 = 256x128 tiles, 3 = 128x128), K-step counts
-    2..66 (all residues mod 3), M/N tails and every epilogue: bit-identical to the 128x128x64 kernel (same k order)."""
-    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
-    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
-    hsrc = torch.relu(rnd(M, N, seed=5))
-    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None,
-              relu_src=hsrc.to(DEV) if flags & 8 else None)
-    ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None,
-                    relu_src=hsrc if flags & 8 else None)
-    outs = []
-    saved = dh.get_option("nt5")
-    dh.set_option("nt4", 0)
-    try:
-        for nt5 in (mode, 0):
-            dh.set_option("nt5", nt5)
-            C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-            dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
-            close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt5={nt5}")
-            outs.append(C.cpu())
-    finally:
-        dh.set_option("nt5", saved)
-        dh.set_option("nt4", 1)
-    assert torch.equal(outs[0], outs[1]), "hand-scheduled and compiler-scheduled kernels must be bit-identical"
-
-
-@pytest.mark.parametrize("M,N,K,flags", [(4000, 2568, 128, 0), (8192, 1280, 256, 5), (3000, 3000 // 8 * 8, 384, 3)])
-def test_gemm_nt_persistent(M, N, K, flags):
-    """> 512 tiles and an even number of K-steps: the persistent kernel (nt3) path, incl. M/N tails; must agree with nt2."""
-    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
-    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
-    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None)
-    ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None)
-    outs = []
-    dh.set_option("nt4", 0)
-    for nt3 in (1, 0):
-        dh.set_option("nt3", nt3)
-        C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-        dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
-        close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt3={nt3}")
-        outs.append(C.cpu())
-    dh.set_option("nt3", 0)
-    dh.set_option("nt4", 1)
-    assert torch.equal(outs[0], outs[1]), "persistent and per-tile kernels must be bit-identical"
-
-
 @pytest.mark.parametrize("M,N,K,ns", [(300, 256, 1024, 2), (1024, 512, 4096, 2), (130, 128, 448, 3)])
 def test_gemm_nt_splitk(M, N, K, ns):
     A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
@@ -233,15 +216,17 @@ def test_gemm_nt_splitk(M, N, K, ns):
     w = ws(dh.gemm_nt_splitk_workspace_bytes(M, N, ns))
     dh.gemm_nt_splitk(A.to(DEV), K, Bt.to(DEV), K, C, M, N, K, ns, w)
     close(C, _gemm_ref(A, Bt), 1.6e-2, 2e-2 * math.sqrt(K / 64) * 0.1, "gemm_nt_splitk")
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(3)) * 2 - 0.5
+    dh.gemm_nt_splitk(A.to(DEV), K, Bt.to(DEV), K, C, M, N, K, ns, w, rowscale=rs.to(DEV))
+    close(C, _gemm_ref(A, Bt) * rs[:, None], 1.6e-2, 2e-2 * math.sqrt(K / 64) * 0.1, "gemm_nt_splitk row scale")
 
 
-@pytest.mark.parametrize("trread", [1, 0])
+@pytest.mark.parametrize("tail", [1, 0])
 @pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200),
                                    (48, 128, 128), (100, 64, 72), (10000, 512, 512),
-                                   (200, 1024, 8320), (330, 640, 13320)])   # 520 / 525 tiles: the stream-K launch
-def test_gemm_tn(trread, M, I, J):
-    """trread 1: hardware-transpose-read kernel; 0: explicit transposes + NT fallback."""
-    dh.set_option("tn_trread", trread)
+                                   (200, 1024, 8320), (330, 640, 13320)])   # 520 / 525 tiles: the row-split tail launch
+def test_gemm_tn(tail, M, I, J):
+    dh.set_option("tn_tail", tail)
     try:
         X, dY = rnd(M, I, seed=1), rnd(M, J, seed=2)
         dW = torch.full((I, J), 7.0, dtype=torch.float32, device=DEV)
@@ -249,38 +234,107 @@ def test_gemm_tn(trread, M, I, J):
         db = torch.full((J,), 3.0, dtype=torch.float32, device=DEV)
         dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW, M, I, J, w, dbias=db)
         ref = X.float().t() @ dY.float()
-        close(dW, ref, 2e-3, 2e-3 * math.sqrt(M), f"gemm_tn trread={trread}")
-        close(db, dY.float().sum(0), 1e-4, 1e-3 * math.sqrt(M), f"gemm_tn fused bias grad trread={trread}")
+        close(dW, ref, 2e-3, 2e-3 * math.sqrt(M), f"gemm_tn tail={tail}")
+        close(db, dY.float().sum(0), 1e-4, 1e-3 * math.sqrt(M), f"gemm_tn fused bias grad tail={tail}")
         dW2 = torch.zeros_like(dW)
         dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW2, M, I, J, w)          # without the bias output
         assert torch.equal(dW2, dW), "gemm_tn must be deterministic and independent of the bias option"
+        # weighted column sums (the fused-softmax head's bias gradient): dbias = w^T dY, w bf16 [M]
+        wv = rnd(M, seed=3)
+        db2 = torch.full((J,), 3.0, dtype=torch.float32, device=DEV)
+        dW3 = torch.zeros_like(dW)
+        dh.gemm_tn(X.to(DEV), I, dY.to(DEV), J, dW3, M, I, J, w, dbias=db2, bias_weights=wv.to(DEV))
+        assert torch.equal(dW3, dW)
+        close(db2, wv.float() @ dY.float(), 1e-4, 1e-3 * math.sqrt(M), f"gemm_tn weighted bias grad tail={tail}")
     finally:
-        dh.set_option("tn_trread", 1)
+        dh.set_option("tn_tail", 1)
 
 
-def test_gemm_tn_grouped_is_bit_identical():
-    """four weight gradients of different shapes (split / unsplit, with and without bias) in one grouped launch ==
-    four dmi_gemm_tn calls, bit for bit; repeated launches reuse the same host problem array."""
-    M = 2000
-    shapes = [(256, 768, True), (256, 256, True), (1024, 256, False), (256, 1024, True), (64, 72, False)]
-    items, refs = [], []
-    for k, (I, J, wb) in enumerate(shapes):
-        X, dY = rnd(M, I, seed=10 + k).to(DEV), rnd(M, J, seed=20 + k).to(DEV)
-        dW = torch.full((I, J), 5.0, dtype=torch.float32, device=DEV)
-        db = torch.full((J,), 2.0, dtype=torch.float32, device=DEV) if wb else None
-        items.append((X, I, dY, J, dW, M, I, J, db))
-        rW, rb = torch.zeros_like(dW), (torch.zeros_like(db) if wb else None)
-        dh.gemm_tn(X, I, dY, J, rW, M, I, J, ws(dh.gemm_tn_workspace_bytes(M, I, J)), dbias=rb)
-        refs.append((rW, rb))
-    probs = dh.tn_problems(items)
-    w = ws(dh.gemm_tn_grouped_workspace_bytes(probs))
-    for _ in range(2):
-        dh.gemm_tn_grouped(probs, w)
-        for (X, I, dY, J, dW, M_, I_, J_, db), (rW, rb) in zip(items, refs):
-            assert torch.equal(dW, rW), (I, J)
-            if db is not None:
-                assert torch.equal(db, rb), (I, J)
-            close(dW, X.float().t() @ dY.float(), 2e-3, 2e-3 * math.sqrt(M), "grouped tn")
+# ------------------------------------------------------------------ fused softmax head
+
+def _head_case(M, K, V, seed, big=None):
+    g = torch.Generator().manual_seed(seed)
+    Vp = (V + 127) // 128 * 128
+    X = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    Wt = torch.zeros(Vp, K)
+    Wt[:V] = torch.randn(V, K, generator=g) * (2.0 / math.sqrt(K))
+    Wt = Wt.to(torch.bfloat16)
+    bias = torch.full((Vp,), -30000.0)
+    bias[:V] = torch.randn(V, generator=g) * 0.5
+    bias = bias.to(torch.bfloat16)
+    labels = torch.randint(0, V, (M,), generator=g, dtype=torch.int32)
+    if big is not None:   # rows whose label logit is > 88 below the row maximum: the exponent overflows -> exact fix-up path
+        for r in big:
+            v_hi = (int(labels[r]) + 1) % V
+            Wt[v_hi] = (X[r].float() * (200.0 / float(X[r].float().pow(2).sum()))).to(torch.bfloat16)
+            Wt[int(labels[r])] = (-X[r].float() * (100.0 / float(X[r].float().pow(2).sum()))).to(torch.bfloat16)
+    return X, Wt, bias, labels, Vp
+
+
+def _run_head(X, Wt, bias, labels, V, Vp, dz_scale):
+    M, K = X.shape
+    Xd, Wd, bd, ld = X.to(DEV), Wt.to(DEV), bias.to(DEV), labels.to(DEV)
+    zl = torch.empty(M, dtype=torch.float32, device=DEV)
+    flag = torch.full((1,), 5, dtype=torch.int32, device=DEV)
+    dh.label_logit(Xd, K, Wd, K, bd, ld, zl, flag, M, K, V)
+    nparts = dh.gemm_nt_softmax_partials(Vp)
+    part = torch.full((nparts, M), float("nan"), dtype=torch.float32, device=DEV)
+    E = torch.zeros(M, Vp, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt_softmax(Xd, K, Wd, K, bd, zl, E, Vp, part, M, Vp, K)
+    loss = torch.empty(M, dtype=torch.float32, device=DEV)
+    rsc = torch.empty(M, dtype=torch.float32, device=DEV)
+    rsb = torch.empty(M, dtype=torch.bfloat16, device=DEV)
+    Xs = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    dh.softmax_finish(part, nparts, ld, Xd, K, Wd, K, bd, E, Vp, Vp, loss, rsc, rsb, Xs, flag, M, K, V, dz_scale)
+    return zl, E, loss, rsc, rsb, Xs, int(flag.item())
+
+
+@pytest.mark.parametrize("nt4", [0, 2])
+@pytest.mark.parametrize("M,K,V", [(300, 128, 1000), (1024, 512, 5000), (77, 256, 777), (257, 64, 200)])
+def test_fused_softmax_head(M, K, V, nt4):
+    """label logit -> exp-epilogue GEMM -> finish: loss_rows = logsumexp - label logit, rowscale * E = dz_scale * (softmax -
+    onehot), Xs = rowscale * X; vs fp32 math on the same bf16 inputs.  Both NT tilings."""
+    X, Wt, bias, labels, Vp = _head_case(M, K, V, seed=M)
+    dz_scale = 1.0 / M
+    dh.set_option("nt4", nt4)
+    try:
+        zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale)
+    finally:
+        dh.set_option("nt4", 1)
+    assert flag == 0
+    z = X.float() @ Wt.float()[:V].t() + bias.float()[:V]
+    lab = labels.long()
+    close(zl, z[torch.arange(M), lab], 1e-4, 1e-4, "label logit")
+    ref_loss = torch.logsumexp(z, -1) - z[torch.arange(M), lab]
+    close(loss, ref_loss, 1e-4, 2e-4, "loss rows")
+    p = torch.softmax(z, -1)
+    dz_ref = (p - F.one_hot(lab, V).float()) * dz_scale
+    dz = E.float().cpu()[:, :V] * rsc.cpu()[:, None]
+    assert float(E.float()[:, V:].abs().max()) == 0.0, "pad columns must be exactly zero"
+    # bf16 rounding of E: 2^-9 relative on each entry; entries below 1e-3 of the row's largest are noise-level
+    close(dz, dz_ref, 1.6e-2, 1e-3 * dz_scale, "dlogits = rowscale * E")
+    close(Xs, X.float() * rsc.cpu()[:, None], 1.6e-2, 1e-12, "Xs")
+    close(rsb, rsc.cpu(), 8e-3, 0.0, "rowscale bf16")
+    assert abs(float((dz.sum(-1)).abs().max())) <= 2e-2 * dz_scale   # rows of dlogits sum to ~0
+
+
+def test_fused_softmax_head_overflow_rows_are_redone_exactly():
+    """rows whose label logit is ~300 below the row maximum overflow exp(logit - label logit); they are flagged and
+    recomputed with the row maximum as the shift: same loss / dlogits as fp32 math, other rows untouched."""
+    M, K, V = 130, 128, 500
+    X, Wt, bias, labels, Vp = _head_case(M, K, V, seed=11, big=[3, 64, 129])
+    dz_scale = 0.25
+    zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale)
+    assert flag == 1
+    z = X.float() @ Wt.float()[:V].t() + bias.float()[:V]
+    lab = labels.long()
+    ref_loss = torch.logsumexp(z, -1) - z[torch.arange(M), lab]
+    assert float(ref_loss[3]) > 88
+    close(loss, ref_loss, 1e-4, 2e-3, "loss rows")
+    dz_ref = (torch.softmax(z, -1) - F.one_hot(lab, V).float()) * dz_scale
+    dz = E.float().cpu()[:, :V] * rsc.cpu()[:, None]
+    close(dz, dz_ref, 1.6e-2, 1e-3 * dz_scale, "dlogits incl. redone rows")
+    close(Xs, X.float() * rsc.cpu()[:, None], 1.6e-2, 1e-12, "Xs")
 
 
 def test_colsum_and_transpose():
@@ -293,14 +347,6 @@ def test_colsum_and_transpose():
     T = torch.zeros(3, 200, 72, dtype=torch.bfloat16, device=DEV)
     dh.transpose(X.to(DEV), T, 3, 72, 200)
     assert torch.equal(T.cpu(), X.transpose(1, 2).contiguous()), "transpose"
-    # strided per-head transpose: qkv [B*S, 3d] -> vt [B,H,128,S]
-    B, S, H = 2, 48, 3
-    d = H * 128
-    qkv = rnd(B * S, 3 * d, seed=3).to(DEV)
-    vt = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
-    dh.transpose_strided(qkv.data_ptr() + 2 * d * 2, vt, B, H, S, 128, S * 3 * d, 128, 3 * d)
-    ref = qkv.cpu().view(B, S, 3, H, 128)[:, :, 2].permute(0, 2, 3, 1).contiguous()
-    assert torch.equal(vt.cpu(), ref), "strided transpose"
 
 
 # ------------------------------------------------------------------ attention
@@ -344,16 +390,6 @@ def test_transpose_batch_and_fast_sums():
             assert abs(float(out) - ref) <= 1e-5 * max(1.0, abs(ref)) + 2e-4 * (n ** 0.5) * 1e-2, (n, float(out), ref)
 
 
-def _transposes(qkv, B, H, S):
-    d = H * 128
-    outs = []
-    for i in range(3):
-        t = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
-        dh.transpose_strided(qkv.data_ptr() + i * d * 2, t, B, H, S, 128, S * 3 * d, 128, 3 * d)
-        outs.append(t)
-    return outs
-
-
 @pytest.mark.parametrize("xcd", [8, 1, 0, 3])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 2, 384), (1, 1, 72), (3, 1, 384), (5, 2, 200)])
 def test_attention_fwd_bwd(B, H, S, xcd):
@@ -374,10 +410,9 @@ def _attention_fwd_bwd(B, H, S):
     qkv[:, 0] *= 0.12
     qkv = qkv.view(B * S, 3 * d).to(torch.bfloat16)
     qkv_d = qkv.to(DEV)
-    qt, kt, vt = _transposes(qkv_d, B, H, S)
     o = torch.zeros(B * S, d, dtype=torch.bfloat16, device=DEV)
     lse = torch.zeros(B, H, S, dtype=torch.float32, device=DEV)
-    dh.attention_fwd(qkv_d, vt, o, lse, B, H, S)
+    dh.attention_fwd(qkv_d, o, lse, B, H, S)
     qr = qkv.float().requires_grad_(True)
     o_ref, lse_ref = _attn_ref(qr, B, H, S)
     close(lse, lse_ref.detach(), 2e-3, 2e-3, "attn lse")
@@ -385,11 +420,9 @@ def _attention_fwd_bwd(B, H, S):
     d_o = rnd(B * S, d, seed=9)
     o_ref.backward(d_o.float())
     d_o_d = d_o.to(DEV)
-    dot = torch.zeros(B, H, 128, S, dtype=torch.bfloat16, device=DEV)
-    dh.transpose_strided(d_o_d.data_ptr(), dot, B, H, S, 128, S * d, 128, d)
     delta = torch.zeros(3, B, H, S, dtype=torch.float32, device=DEV)
     dqkv = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device=DEV)
-    dh.attention_bwd(qkv_d, qt, kt, o, d_o_d, dot, lse, delta, dqkv, B, H, S)
+    dh.attention_bwd(qkv_d, o, d_o_d, lse, delta, dqkv, B, H, S)
     gref = qr.grad.view(B * S, 3, d)
     got = dqkv.float().cpu().view(B * S, 3, d)
     for i, nm in enumerate("qkv"):
@@ -401,10 +434,9 @@ def test_attention_row0_kat():
     """causal mask: query 0 attends only to key 0 -> o[0] == v[0] exactly (bf16 round trip)."""
     B, H, S = 1, 1, 128
     qkv = rnd(S, 3 * 128, seed=11).to(DEV)
-    _, _, vt = _transposes(qkv, B, H, S)
     o = torch.zeros(S, 128, dtype=torch.bfloat16, device=DEV)
     lse = torch.zeros(1, 1, S, dtype=torch.float32, device=DEV)
-    dh.attention_fwd(qkv, vt, o, lse, B, H, S)
+    dh.attention_fwd(qkv, o, lse, B, H, S)
     assert torch.equal(o[0].cpu(), qkv[0, 256:].cpu())
 
 

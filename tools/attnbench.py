@@ -16,8 +16,8 @@ ref = {}
 for rep in range(3):
     for x in (1, 8, 16):
         dh.set_option("attn_xcd", x)
-        tf = timeit(lambda: dh.attention_fwd(qkv, None, o, lse, B, H, S))
-        tb = timeit(lambda: dh.attention_bwd(qkv, None, None, o, d_o, None, lse, delta, dqkv, B, H, S))
+        tf = timeit(lambda: dh.attention_fwd(qkv, o, lse, B, H, S))
+        tb = timeit(lambda: dh.attention_bwd(qkv, o, d_o, lse, delta, dqkv, B, H, S))
         print(f"attn_xcd={x}: fwd {tf*1e6:7.1f} us  bwd {tb*1e6:7.1f} us", flush=True)
         key = (o.float().sum().item(), dqkv.float().abs().sum().item())
         ref.setdefault("k", key)

@@ -1,9 +1,9 @@
 """Kernel micro-benchmarks on the GPU box (torch.cuda.Event timing on the launch stream, random data).
 Prints one line per kernel/shape: time, achieved TFLOP/s or GB/s.  Used to steer optimisation; the
-judged numbers come from bench.py + rocprofv3 summaries under profiles/."""
+judged numbers come from bench.py + rocprofv3 summaries under profiles/.
+usage: python tools/kbench.py [nt] [tn] [attn] [head] [misc]   (default: all)"""
 import os
 import sys
-import math
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "dalle-mtf_amd"))
@@ -34,125 +34,94 @@ def ws(n):
     return torch.empty(max(int(n), 256), dtype=torch.uint8, device=DEV)
 
 
-def bench_gemm_nt(M, N, K, flags=0, tag=""):
+def bench_gemm_nt(M, N, K, flags=0, tag="", variants=(("auto", 1),)):
     A, Bt = rb(M, K), rb(N, K, scale=0.05)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     bias, res = rb(N), rb(M, N)
-    for name, opts in (("nt2", dict(nt2=1, glds=1, nt3=0, nt4=0)), ("nt4", dict(nt2=1, glds=1, nt3=0, nt4=2)), ("nt2 again", dict(nt2=1, glds=1, nt3=0, nt4=0))):
-        for k, v in opts.items():
-            dh.set_option(k, v)
-        t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res))
+    rs = torch.rand(M, device=DEV)
+    for name, nt4 in variants:
+        dh.set_option("nt4", nt4)
+        t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res, rowscale=rs))
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
-    dh.set_option("nt2", 1)
-    dh.set_option("nt3", 0)
     dh.set_option("nt4", 1)
-    dh.set_option("glds", 1)
 
 
-def bench_gemm_tn(M, I, J):
+def bench_gemm_tn(M, I, J, weighted=False):
     X, dY = rb(M, I), rb(M, J)
     dW = torch.empty(I, J, dtype=torch.float32, device=DEV)
     db = torch.empty(J, dtype=torch.float32, device=DEV)
+    bw = rb(M) if weighted else None
     w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
-    for v in (0, 1, 0, 1):
-        dh.set_option("tn_streamk", v)
-        t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db))
-        print(f"gemm_tn M={M} I={I} J={J} streamk={v}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
-    dh.set_option("tn_streamk", 1)
+    t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db, bias_weights=bw))
+    print(f"gemm_tn M={M} I={I} J={J} weighted_bias={int(weighted)}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
 
 
 def bench_attention(B, H, S):
     d = H * 128
     qkv = rb(B * S, 3 * d, scale=0.3)
-    T = [torch.empty(B, H, 128, S, dtype=torch.bfloat16, device=DEV) for _ in range(4)]
-    def tr():
-        for i in range(3):
-            dh.transpose_strided(qkv.data_ptr() + i * d * 2, T[i], B, H, S, 128, S * 3 * d, 128, 3 * d)
-    tr()
     o = torch.empty(B * S, d, dtype=torch.bfloat16, device=DEV)
     lse = torch.empty(B, H, S, dtype=torch.float32, device=DEV)
-    t = timeit(lambda: dh.attention_fwd(qkv, T[2], o, lse, B, H, S))
-    fl = 4.0 * B * H * S * S * 128  # dense count (QK^T + PV), as SURVEY §8(d) counts it
-    print(f"attn_fwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {fl/t/1e12:8.1f} TF/s dense-equivalent ({fl/2/t/1e12:.1f} causal)", flush=True)
     d_o = rb(B * S, d)
-    dh.transpose_strided(d_o.data_ptr(), T[3], B, H, S, 128, S * d, 128, d)
     delta = torch.empty(3, B, H, S, dtype=torch.float32, device=DEV)
     dqkv = torch.empty(B * S, 3 * d, dtype=torch.bfloat16, device=DEV)
-    t = timeit(lambda: dh.attention_bwd(qkv, T[0], T[1], o, d_o, T[3], lse, delta, dqkv, B, H, S))
-    print(f"attn_bwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {2*fl/t/1e12:8.1f} TF/s dense-equivalent", flush=True)
-    t = timeit(tr)
-    print(f"3 head transposes: {t*1e6:9.1f} us  {3*2*B*S*d*2/t/1e9:8.1f} GB/s", flush=True)
+    fl = 4.0 * B * H * S * S * 128   # dense-equivalent forward flops
+    t = timeit(lambda: dh.attention_fwd(qkv, o, lse, B, H, S))
+    print(f"attention_fwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s dense-equivalent ({fl/2/t/1e12:.1f} executed)", flush=True)
+    t = timeit(lambda: dh.attention_bwd(qkv, o, d_o, lse, delta, dqkv, B, H, S))
+    print(f"attention_bwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {2.5*fl/t/1e12:7.1f} TF/s dense-equivalent ({2.5*fl/2/t/1e12:.1f} executed)", flush=True)
 
 
-def bench_misc(M, d, V, ld):
-    x, g, b = rb(M, d), rb(d), rb(d)
-    y = torch.empty_like(x)
-    mean = torch.empty(M, dtype=torch.float32, device=DEV)
-    rstd = torch.empty(M, dtype=torch.float32, device=DEV)
-    t = timeit(lambda: dh.layernorm_fwd(x, g, b, y, mean, rstd, M, d))
-    print(f"ln_fwd M={M} d={d}: {t*1e6:9.1f} us  {2*M*d*2/t/1e9:8.1f} GB/s", flush=True)
-    dx = torch.empty_like(x)
-    dg = torch.empty(d, dtype=torch.float32, device=DEV)
-    db = torch.empty(d, dtype=torch.float32, device=DEV)
-    w = ws(dh.layernorm_bwd_workspace_bytes(M, d))
-    t = timeit(lambda: dh.layernorm_bwd(y, x, g, mean, rstd, x, dx, dg, db, w, M, d))
-    print(f"ln_bwd M={M} d={d}: {t*1e6:9.1f} us  {4*M*d*2/t/1e9:8.1f} GB/s", flush=True)
-    h = rb(M, 4 * d)
-    out = torch.empty(4 * d, dtype=torch.float32, device=DEV)
-    w2 = ws(dh.colsum_workspace_bytes(M, 4 * d))
-    t = timeit(lambda: dh.colsum(h, 4 * d, out, M, 4 * d, w2))
-    print(f"colsum M={M} N={4*d}: {t*1e6:9.1f} us  {M*4*d*2/t/1e9:8.1f} GB/s", flush=True)
-    z = rb(M, ld, scale=2.0)
+def bench_head(M, K, V):
+    Vp = (V + 127) // 128 * 128
+    X, Wt, W = rb(M, K), rb(Vp, K, scale=0.02), rb(K, Vp, scale=0.02)
+    bias = torch.zeros(Vp, device=DEV)
+    bias[V:] = -30000.0
+    bias = bias.to(torch.bfloat16)
     labels = torch.randint(0, V, (M,), device=DEV, dtype=torch.int32)
-    lr = torch.empty(M, dtype=torch.float32, device=DEV)
-    t = timeit(lambda: dh.cross_entropy(z, ld, labels, lr, None, M, V, 1e-4), iters=5)
-    print(f"cross_entropy M={M} V={V}: {t*1e6:9.1f} us  {2*M*ld*2/t/1e9:8.1f} GB/s (read+write)", flush=True)
-    n = 71_601_747 // 4 * 4
-    p, gg, m, v = (torch.randn(n, device=DEV) * 0.01 for _ in range(4))
-    v.abs_()
-    pb = torch.empty(n, dtype=torch.bfloat16, device=DEV)
-    nrm = torch.ones(1, dtype=torch.float32, device=DEV)
-    t = timeit(lambda: dh.adam_step(p, gg, m, v, pb, n, nrm, 1.0, 1e-3, 0.9, 0.999, 1e-6, 0.0, 1.0), iters=5)
-    print(f"adam n={n}: {t*1e6:9.1f} us  {n*30/t/1e9:8.1f} GB/s", flush=True)
-    w3 = ws(dh.sumsq_workspace_bytes(n))
-    t = timeit(lambda: dh.sumsq(gg, n, nrm, w3), iters=5)
-    print(f"sumsq n={n}: {t*1e6:9.1f} us  {n*4/t/1e9:8.1f} GB/s", flush=True)
-    tok = torch.randint(0, 50771, (M,), device=DEV, dtype=torch.int32)
-    tok[::3] = 50257
-    dwte = torch.zeros(50771, d, dtype=torch.float32, device=DEV)
-    dwpe = torch.zeros(1280, d, dtype=torch.float32, device=DEV)
-    t = timeit(lambda: dh.embed_bwd(tok, x, dwte, dwpe, M // 1280, 1280, d, 50771), iters=5)
-    print(f"embed_bwd M={M}: {t*1e6:9.1f} us", flush=True)
+    zl = torch.empty(M, dtype=torch.float32, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    nparts = dh.gemm_nt_softmax_partials(Vp)
+    part = torch.empty(nparts, M, dtype=torch.float32, device=DEV)
+    E = torch.empty(M, Vp, dtype=torch.bfloat16, device=DEV)
+    loss = torch.empty(M, dtype=torch.float32, device=DEV)
+    rsc = torch.empty(M, dtype=torch.float32, device=DEV)
+    rsb = torch.empty(M, dtype=torch.bfloat16, device=DEV)
+    Xs = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    dW = torch.empty(K, Vp, dtype=torch.float32, device=DEV)
+    db = torch.empty(Vp, dtype=torch.float32, device=DEV)
+    dX = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    w = ws(dh.gemm_tn_workspace_bytes(M, K, Vp))
+    fl = 2.0 * M * K * V
+    rows = [
+        ("label_logit", lambda: dh.label_logit(X, K, Wt, K, bias, labels, zl, flag, M, K, V), None),
+        ("gemm_nt (logits, bias)", lambda: dh.gemm_nt(X, K, Wt, K, E, Vp, M, Vp, K, dh.GEMM_BIAS, bias=bias), fl),
+        ("cross_entropy (old path)", lambda: dh.cross_entropy(E, Vp, labels, loss, None, M, V, 1.0 / M), None),
+        ("gemm_nt_softmax", lambda: dh.gemm_nt_softmax(X, K, Wt, K, bias, zl, E, Vp, part, M, Vp, K), fl),
+        ("softmax_finish", lambda: dh.softmax_finish(part, nparts, labels, X, K, Wt, K, bias, E, Vp, Vp, loss, rsc, rsb, Xs, flag, M, K, V, 1.0 / M), None),
+        ("head wgrad (weighted bias)", lambda: dh.gemm_tn(Xs, K, E, Vp, dW, M, K, Vp, w, dbias=db, bias_weights=rsb), fl),
+        ("head dgrad (rowscale)", lambda: dh.gemm_nt(E, Vp, W, Vp, dX, K, M, K, Vp, dh.GEMM_ROWSCALE, rowscale=rsc), fl),
+    ]
+    for name, fn, f in rows:
+        t = timeit(fn, iters=10)
+        print(f"head M={M} K={K} V={V} {name:28s}: {t*1e6:9.1f} us" + (f"  {f/t/1e12:8.1f} TF/s" if f else ""), flush=True)
 
 
 if __name__ == "__main__":
-    print(torch.cuda.get_device_name(0), flush=True)
-    M = 32 * 1280
-    which = sys.argv[1:] or ["gemm", "tn", "attn", "misc"]
-    if "pmc" in which:   # short list for counter collection
-        dh.set_option("nt3", 0)
-        for (mm, nn, kk_, fl) in ((8192, 8192, 8192, 0), (M, 50816, 512, 1), (M, 1536, 512, 0), (M, 512, 2048, 5)):
-            A, Bt = rb(mm, kk_), rb(nn, kk_, scale=0.05)
-            C = torch.empty(mm, nn, dtype=torch.bfloat16, device=DEV)
-            bias, res = rb(nn), rb(mm, nn)
-            for _ in range(3):
-                dh.gemm_nt(A, kk_, Bt, kk_, C, nn, mm, nn, kk_, fl, bias=bias, residual=res)
-            torch.cuda.synchronize()
-        bench_gemm_tn(M, 2048, 512)
-    if "gemm" in which:
-        bench_gemm_nt(M, 1536, 512, tag="[qkv]")
-        bench_gemm_nt(M, 512, 512, 5, tag="[outproj]")
-        bench_gemm_nt(M, 2048, 512, 3, tag="[ffn1]")
-        bench_gemm_nt(M, 512, 2048, 5, tag="[ffn2]")
-        bench_gemm_nt(M, 50816, 512, 1, tag="[logits]")
-        bench_gemm_nt(M, 512, 50816, 0, tag="[dlogits]")
-        bench_gemm_nt(8192, 8192, 8192, 0, tag="[square]")
-    if "tn" in which:
-        bench_gemm_tn(M, 512, 1536)
-        bench_gemm_tn(M, 512, 512)
-        bench_gemm_tn(M, 2048, 512)
-        bench_gemm_tn(M, 512, 50816)
-    if "attn" in which:
+    what = set(sys.argv[1:]) or {"nt", "tn", "attn", "head"}
+    M, d = 40960, 512
+    if "nt" in what:
+        both = (("nt2", 0), ("nt4", 2))
+        bench_gemm_nt(M, 3 * d, d, 0, " qkv", both)
+        bench_gemm_nt(M, d, d, 5, " attn-out", both)
+        bench_gemm_nt(M, 4 * d, d, 3, " ffn1", both)
+        bench_gemm_nt(M, d, 4 * d, 5, " ffn2", both)
+        bench_gemm_nt(M, 4 * d, d, 8, " ffn2-dgrad", both)
+        bench_gemm_nt(M, d, 4 * d, 0, " ffn1-dgrad", both)
+        bench_gemm_nt(M, d, 3 * d, 0, " qkv-dgrad", both)
+    if "tn" in what:
+        for I, J in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d), (d, 50816)):
+            bench_gemm_tn(M, I, J)
+    if "attn" in what:
         bench_attention(32, 4, 1280)
-    if "misc" in which:
-        bench_misc(M, 512, 50771, 50816)
+    if "head" in what:
+        bench_head(M, d, 50771)

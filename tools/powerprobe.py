@@ -46,16 +46,9 @@ def nt(N, K, **opts):
     return f, 2.0 * M * N * K
 
 
-which = sys.argv[1] if len(sys.argv) > 1 else "all"
-if which == "accfwd":
-    for rep in range(2):
-        f, fl = nt(2048, 2048, nt4=0, nt5=0, prio=0); run("nt2 kk-outer (default)", f, fl, secs=4.0)
-        f, fl = nt(2048, 2048, nt4=0, nt5=0, prio=2); run("nt2 kk-inner (same-acc chains)", f, fl, secs=4.0)
-    dh.set_option("prio", 0)
-    sys.exit(0)
-f, fl = nt(2048, 2048, nt4=0, nt5=0); run("nt2 128x128 N=2048 K=2048", f, fl)
-f, fl = nt(2048, 2048, nt4=2, nt5=0); run("nt4 256x128 N=2048 K=2048", f, fl)
-f, fl = nt(50816, 512, nt4=1, nt5=0); run("nt4 logits N=50816 K=512", f, fl)
+f, fl = nt(2048, 2048, nt4=0); run("nt2 128x128 N=2048 K=2048", f, fl)
+f, fl = nt(2048, 2048, nt4=2); run("nt4 256x128 N=2048 K=2048", f, fl)
+f, fl = nt(50816, 512, nt4=1); run("nt4 logits N=50816 K=512", f, fl)
 dh.set_option("nt4", 1)
 X, dY = rb(M, 2048), rb(M, 512)
 dW = torch.empty(2048, 512, dtype=torch.float32, device="cuda")
