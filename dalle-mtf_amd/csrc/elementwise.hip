@@ -221,14 +221,41 @@ __global__ __launch_bounds__(256) void embed_bwd_wte_combine_kernel(const int* _
   if (single && i0 > 0 && sorted_tok[i0 - 1] == tok) return;   // a continuation, not a start
   const int slot = single ? 0 : 1;
   const int64_t nchunks = (n + EB_CH - 1) / EB_CH;
-  for (int c = lane; c < d / 4; c += 64) {
-    f32x4 acc = *(const f32x4*)(part + ((int64_t)chunk * 2 + slot) * d + c * 4);
-    for (int64_t k = chunk + 1; k < nchunks; ++k) {
+  // number of following chunks that continue the run: chunk k continues iff it starts with tok; it is the last one iff
+  // the run ends inside it.  64 chunks are classified per ballot (the padding id spans hundreds of chunks; a serial walk
+  // with two dependent loads per chunk cost 110 us on the dalle_example batch).
+  int64_t cnt = 0;
+  for (int64_t base = chunk + 1; base < nchunks; base += 64) {
+    const int64_t k = base + lane;
+    bool cont = false, last = true;
+    if (k < nchunks) {
       const int64_t k0 = k * EB_CH, k1 = (k0 + EB_CH < n) ? k0 + EB_CH : n;
-      if (sorted_tok[k0] != tok) break;
-      const f32x4 v = *(const f32x4*)(part + ((int64_t)k * 2 + 0) * d + c * 4);
+      cont = sorted_tok[k0] == tok;
+      last = !(sorted_tok[k1 - 1] == tok && k1 < n && sorted_tok[k1] == tok);
+    }
+    const unsigned long long stop = __ballot(!cont || last);   // first chunk that is not a full continuation
+    if (stop == 0ull) { cnt += 64; continue; }
+    const int f = __ffsll((long long)stop) - 1;
+    const unsigned long long contb = __ballot(cont);
+    cnt += f + (((contb >> f) & 1ull) ? 1 : 0);                   // chunk f still contributes if it starts with tok
+    break;
+  }
+  const float* p0 = part + ((int64_t)chunk * 2 + slot) * d;
+  const float* pk = part + ((int64_t)(chunk + 1) * 2) * d;   // slot 0 of the following chunks, stride 2 d
+  for (int c = lane; c < d / 4; c += 64) {
+    f32x4 acc = *(const f32x4*)(p0 + c * 4);
+    int64_t k = 0;
+    for (; k + 4 <= cnt; k += 4) {   // four independent loads in flight, summed in chunk order
+      const f32x4 v0 = *(const f32x4*)(pk + (k + 0) * 2 * d + c * 4);
+      const f32x4 v1 = *(const f32x4*)(pk + (k + 1) * 2 * d + c * 4);
+      const f32x4 v2 = *(const f32x4*)(pk + (k + 2) * 2 * d + c * 4);
+      const f32x4 v3 = *(const f32x4*)(pk + (k + 3) * 2 * d + c * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = (((acc[j] + v0[j]) + v1[j]) + v2[j]) + v3[j];
+    }
+    for (; k < cnt; ++k) {
+      const f32x4 v = *(const f32x4*)(pk + k * 2 * d + c * 4);
       acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-      if (sorted_tok[k1 - 1] != tok || k1 >= n || sorted_tok[k1] != tok) break;   // the run ends in chunk k
     }
     *(f32x4*)(dwte + (int64_t)eb_clamp(tok, vocab) * d + c * 4) = acc;
   }
@@ -923,30 +950,42 @@ struct SoftmaxFinishArgs {
   int64_t M; int K, V;
   float dz_scale;
 };
+#define SF_ROWS 256
 __global__ __launch_bounds__(256) void softmax_finish_kernel(SoftmaxFinishArgs a) {
-  __shared__ float sm[4][64];
-  __shared__ float sc[64];
-  const int tid = threadIdx.x, r = tid & 63, q = tid >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * 64, m = m0 + r;
-  float s = 0.f;
-  if (m < a.M)
-    for (int p = q; p < a.nparts; p += 4) s += a.part[(int64_t)p * a.M + m];   // fixed order: deterministic
-  sm[q][r] = s;
+  __shared__ float sm[4][SF_ROWS];
+  __shared__ float sc[SF_ROWS];
+  const int tid = threadIdx.x, r4 = tid & 63, q = tid >> 6;   // thread: rows 4 r4 .. 4 r4 + 3, partials p = q (mod 4)
+  const int64_t m0 = (int64_t)blockIdx.x * SF_ROWS, m = m0 + 4 * r4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (m + 3 < a.M && (a.M & 3) == 0) {
+    for (int p = q; p < a.nparts; p += 4) {   // fixed order: deterministic
+      const f32x4 v = *(const f32x4*)(a.part + (int64_t)p * a.M + m);
+      s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
+    }
+  } else {
+    for (int j = 0; j < 4; ++j)
+      if (m + j < a.M)
+        for (int p = q; p < a.nparts; p += 4) s[j] += a.part[(int64_t)p * a.M + m + j];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sm[q][4 * r4 + j] = s[j];
   __syncthreads();
-  if (q == 0) {
+  {
+    const int r = tid;
+    const int64_t mr = m0 + r;
     float scale = 0.f;
-    if (m < a.M) {
+    if (mr < a.M) {
       const float S = ((sm[0][r] + sm[1][r]) + sm[2][r]) + sm[3][r];
       const bool bad = !(S > 0.f && S < 3.0e38f);   // inf / nan (an exponent overflowed) or an empty row
       if (bad) a.flag[0] = 1;
-      a.loss_rows[m] = bad ? INFINITY : __logf(S);
+      a.loss_rows[mr] = bad ? INFINITY : __logf(S);
       scale = bad ? 0.f : a.dz_scale / S;
       if (a.dz_scale != 0.f) {
-        a.rowscale[m] = scale;
-        a.rowscale_bf16[m] = f2bf(scale);
-        int lab = a.labels[m];
+        a.rowscale[mr] = scale;
+        a.rowscale_bf16[mr] = f2bf(scale);
+        int lab = a.labels[mr];
         lab = lab < 0 ? 0 : (lab >= a.V ? a.V - 1 : lab);
-        bf16_t* el = a.E + m * a.lde + lab;
+        bf16_t* el = a.E + mr * a.lde + lab;
         *el = f2bf(bf2f(*el) - S);   // dlogits[m, label] = rowscale * (e_label - S) = dz_scale * (p_label - 1)
       }
     }
@@ -955,7 +994,7 @@ __global__ __launch_bounds__(256) void softmax_finish_kernel(SoftmaxFinishArgs a
   __syncthreads();
   if (a.dz_scale == 0.f) return;
   const int cpr = a.K / 8;
-  for (int idx = tid; idx < 64 * cpr; idx += 256) {
+  for (int idx = tid; idx < SF_ROWS * cpr; idx += 256) {
     const int rr = idx / cpr, ch = idx - rr * cpr;
     const int64_t mm = m0 + rr;
     if (mm >= a.M) break;
@@ -1046,7 +1085,7 @@ extern "C" int dmi_softmax_finish(const float* rowsum_part, int nparts, const in
   a.loss_rows = loss_rows; a.rowscale = rowscale; a.rowscale_bf16 = rowscale_bf16; a.Xs = Xs; a.flag = flag;
   a.M = M; a.K = K; a.V = V; a.dz_scale = dz_scale;
   hipStream_t st = (hipStream_t)stream;
-  softmax_finish_kernel<<<dim3((unsigned)cdiv64(M, 64)), dim3(256), 0, st>>>(a);
+  softmax_finish_kernel<<<dim3((unsigned)cdiv64(M, SF_ROWS)), dim3(256), 0, st>>>(a);
   DMI_CHECK_LAUNCH("softmax_finish");
   softmax_fixup_kernel<<<dim3(256), dim3(256), 0, st>>>(a, Wt, ldw, bias, N);   // returns at once unless a row was flagged
   DMI_CHECK_LAUNCH("softmax_fixup");

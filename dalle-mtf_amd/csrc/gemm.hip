@@ -21,21 +21,28 @@
 // grouped / stream-K weight gradients) live on the git branch `r01-kernel-variants`, not in the product library.
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
+static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (long K, whole residencies), 2 always (tests)
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
+static int g_opt_tn8 = 1;        // 256x256 weight-gradient tile (8 waves): 0 never, 1 auto (I, J >= 256), 2 always (tests)
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;
 extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
+  if (!strcmp(name, "nt8")) return g_opt_nt8;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
+  if (!strcmp(name, "tn8")) return g_opt_tn8;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
+  if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
+  if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
   return -1;
 }
@@ -413,6 +420,126 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   }
 }
 
+// =====================================================================================
+// NT kernel v8: 256x256x64 block tile, 8 waves (2 x 4), each wave 128x64 = 4x2 MFMA tiles (128 accumulator VGPRs);
+// two stages x (A 32 KiB + B 32 KiB) = 128 KiB LDS -> ONE block of 512 threads per CU, two waves per SIMD.
+// Per output element half the L2->LDS traffic of the 128x128 tile and a quarter fewer LDS reads per MFMA; 64 MFMAs per
+// wave between barriers, so the stage issued at the top of a K-step has a whole step (~2 us) to land.  For the main-loop
+// -bound GEMMs (long K: the head's input gradient); short-K shapes keep the 2-blocks-per-CU kernels whose co-resident
+// blocks overlap prologue / epilogue with the other block's main loop.  Same k order as v2/v4 -> bit-identical results.
+// =====================================================================================
+#define BM8 256
+#define BN8 256
+template <int FLAGS>
+__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 32K | B 32K]
+  constexpr int STG = 65536;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int r = lane & 31, h = lane >> 5;
+
+  int tm, tn;
+  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
+  const int m0 = tm * BM8, n0 = tn * BN8;
+  const int kb = blockIdx.y * a.k_per_split;
+  const int ke = (kb + a.k_per_split < a.K) ? kb + a.k_per_split : a.K;
+  const int nt = (ke - kb) / BK;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda + kb), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)n0 * a.ldb + kb), 0, 0x7fffffff, 0x00020000);
+  int voa[4], vob[4];
+  {
+    const int chp = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 64 * i;
+      const int src_ch = chp ^ ((row >> 1) & 7);
+      const int ra_ = m0 + row < a.M ? row : a.M - 1 - m0;   // clamp inside the matrix (results discarded)
+      const int rb_ = n0 + row < a.N ? row : a.N - 1 - n0;
+      voa[i] = (ra_ * a.lda + 8 * src_ch) * 2;
+      vob[i] = (rb_ * a.ldb + 8 * src_ch) * 2;
+    }
+  }
+  int offa[4], offb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    offa[kk] = lds_chunk_off(wm * 128 + r, kk * 2 + h);
+    offb[kk] = 32768 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
+  }
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto stage = [&](int st, int soff) {
+    char* base = smem + st * STG + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ra, base + i * 8192, voa[i], soff);
+      glds16(rb, base + 32768 + i * 8192, vob[i], soff);
+    }
+  };
+  auto compute = [&](int st) {
+    const char* cur = smem + st * STG;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      bf16x8 fa[4], fb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = *(const bf16x8*)(cur + offb[kk] + j * 4096);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+    }
+  };
+
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int t = 0;
+  for (; t + 2 <= nt; t += 2) {
+    if (t + 1 < nt) stage(1, (t + 1) * BK * 2);
+    compute(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 2 < nt) stage(0, (t + 2) * BK * 2);
+    compute(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (t < nt) {  // odd tail (stage 0 holds it)
+    compute(0);
+    __syncthreads();
+  }
+
+  if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 128 + i * 32 + r;
+      if (m >= a.M) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
+          if (n >= a.N) continue;
+          float* cp = (float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n;
+          *(f32x4*)cp = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        }
+    }
+  } else {
+    epilogue_bf16<FLAGS, 4>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 128, n0 + wn * 64);
+  }
+}
+
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int nsplit, int64_t n4, int64_t stride4) {
@@ -429,6 +556,20 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
+  {
+    const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
+    // 256x256 tiles (one 8-wave block per CU): main-loop-bound shapes only -- long K and whole residencies of 256 blocks
+    const bool auto8 = g_opt_nt8 == 1 && a.k_per_split >= 4096 && (t8m * t8n * nsplit) % 256 == 0;
+    if (auto8 || g_opt_nt8 == 2) {
+      static bool attr8 = false;
+      if (!attr8) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8 = true; }
+      GemmArgs b = a;
+      b.tiles_m = t8m; b.tiles_n = t8n;
+      gemm_nt8_kernel<FLAGS><<<dim3(t8m * t8n, nsplit), dim3(512), 131072, st>>>(b);
+      DMI_CHECK_LAUNCH("gemm_nt8");
+      return DMI_OK;
+    }
+  }
   if constexpr (!(FLAGS & DMI_GEMM_OUT_F32)) {
     const int tiles4 = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
     // 256x128 tiles when the grid still covers >= 3 residencies; long-K shapes prefer the BK = 64 kernel.  2 = force (tests)
@@ -576,6 +717,30 @@ static int tn_splits(int M, int I, int J) {
   return s;
 }
 static int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// 256x256-tile weight-gradient kernel (8 waves, one block per CU): used when both dimensions fill 256-wide tiles
+// (measured in the dalle_example step, profiles/r02c_*: it wins where the 128x128 plan needs many row splits -- 512x512: 64 -> 57 us,
+// 512x1536: 88 -> 79 us incl. the slab reduce -- and ties or loses from 16 tiles up, where its 64-row steps give the LDS-DMA
+// no more cover than the two co-resident blocks of the 128x128 kernel have)
+static bool tn8_eligible(int M, int I, int J) {
+  if (g_opt_tn8 == 2) return true;
+  const int tiles = ((I + 255) / 256) * ((J + 255) / 256);
+  return g_opt_tn8 == 1 && I >= 256 && J >= 256 && M >= 2048 && tiles < 16;
+}
+static int tn8_splits(int M, int I, int J) {
+  const int tiles = ((I + 255) / 256) * ((J + 255) / 256);
+  const int max_s = (M + 8 * TN_BKM - 1) / (8 * TN_BKM);   // at least 8 k-steps per block
+  int best = 1;
+  double best_cost = 1e30;
+  for (int s2 = 1; s2 <= 64 && s2 <= max_s; ++s2) {
+    // makespan in units of one unsplit block: rounds of 256 resident blocks, each 1/s long, + the fp32 slab round trip
+    // (write + read of s x I x J x 4 bytes at ~4 TB/s vs the block's 2 x 256 x 256 x M flops at ~4.5 TFLOP/s per CU)
+    const double rounds = (double)(((int64_t)tiles * s2 + 255) / 256) / s2;
+    const double slab = (s2 > 1) ? (double)s2 * I * J * 8.0 / 4.0e12 / (2.0 * 256 * 256 * (double)M / 4.5e12) : 0.0;
+    const double cost = rounds + slab;
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = s2; }
+  }
+  return best;
+}
 
 extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   const int s = tn_splits(M, I, J);
@@ -584,7 +749,12 @@ extern "C" int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J) {
   // unsplit shapes with a ragged last residency: row-split slabs of the tail stripe, < 512 tiles x 64 KiB (+ bias rows)
   const int64_t tiles = (int64_t)((I + 127) / 128) * ((J + 127) / 128);
   const int64_t tail = (s == 1 && tiles > 512) ? (512 * 65536 + 512 * 128 * 4 * (int64_t)((I + 127) / 128)) : 0;
-  const int64_t base = round_up64(slabs, 256) + round_up64(cs, 256) + 256;
+  int64_t base = round_up64(slabs, 256) + round_up64(cs, 256) + 256;
+  if (I >= 256 && J >= 256) {   // the 256x256-tile kernel's split plan (whatever the option says now)
+    const int s8 = tn8_splits(M, I, J);
+    const int64_t b8 = round_up64((s8 > 1) ? (int64_t)s8 * I * J * 4 : 0, 256) + round_up64((int64_t)s8 * J * 4, 256) + 256;
+    if (b8 > base) base = b8;
+  }
   return base > tail + 256 ? base : tail + 256;
 }
 
@@ -884,6 +1054,196 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
           a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
 }
 
+// ---- 256x256-tile weight gradient (8 waves) ----------------------------------------------------------------------------
+// Same data path as tn_tile (natural-layout LDS tiles by LDS-DMA, hardware transpose reads), block tile 256 (I) x 256 (J),
+// 8 waves as 2 (I) x 4 (J) of 128 x 64 = 4 x 2 MFMA tiles; two stages x (X 64 x 256 | Y 64 x 256) bf16 = 128 KiB -> one
+// block per CU, two waves per SIMD; 0.75 transpose reads per MFMA instead of 1 and half the L2->LDS bytes per flop of the
+// 128x128 tile (measured on the NT twin: +20 % on main-loop-bound shapes).  LDS rows are 512 B; 16-B chunk index XOR
+// 4*(row&3) on the source side as in tn_tile.  Fragment sets are double-buffered across the four 16-row k-substeps of a
+// stage (counted lgkmcnt), not pre-read for all four (they would need 96 VGPRs).
+struct TrFrag8 {
+  u32x2 x[4][2], y[2][2];   // {x i | y j}{rows +0..3 | +4..7}
+};
+template <int OFF>
+__device__ __forceinline__ void tr8_issue(TrFrag8& f, const unsigned (&ax)[4], const unsigned (&ay)[2]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %12 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %1, %12 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %8, %16 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %9, %16 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %10, %17 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %11, %17 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %2, %13 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %3, %13 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %4, %14 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %5, %14 offset:%19\n\t"
+      "ds_read_b64_tr_b16 %6, %15 offset:%18\n\t"
+      "ds_read_b64_tr_b16 %7, %15 offset:%19"
+      : "=&v"(f.x[0][0]), "=&v"(f.x[0][1]), "=&v"(f.x[1][0]), "=&v"(f.x[1][1]), "=&v"(f.x[2][0]), "=&v"(f.x[2][1]),
+        "=&v"(f.x[3][0]), "=&v"(f.x[3][1]), "=&v"(f.y[0][0]), "=&v"(f.y[0][1]), "=&v"(f.y[1][0]), "=&v"(f.y[1][1])
+      : "v"(ax[0]), "v"(ax[1]), "v"(ax[2]), "v"(ax[3]), "v"(ay[0]), "v"(ay[1]), "i"(OFF), "i"(OFF + 2048)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr8_wait(TrFrag8& f) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(f.x[0][0]), "+v"(f.x[0][1]), "+v"(f.x[1][0]), "+v"(f.x[1][1]), "+v"(f.x[2][0]), "+v"(f.x[2][1]),
+                 "+v"(f.x[3][0]), "+v"(f.x[3][1]), "+v"(f.y[0][0]), "+v"(f.y[0][1]), "+v"(f.y[1][0]), "+v"(f.y[1][1])
+               : "n"(N)
+               : "memory");
+}
+#define TN8_LDS_BYTES (131072 + 512)
+__global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];  // [2 stages][X 32K | Y 32K] | 2 x 256 B weight strips
+  const int tiles = a.tiles_i * a.tiles_j;
+  const int P = xcd_remap(blockIdx.x, gridDim.x);   // split-major: an XCD works on whole row ranges (see gemm_tn_kernel)
+  const int split = P / tiles;
+  int ti, tj;
+  tile_of_block(P - split * tiles, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = split * a.m_per_split;
+  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  const int rows = me > mb ? me - mb : 0;
+  float* C = a.C + (int64_t)split * a.slab_stride;
+  float* bias_out = a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 2, wj = wid & 3;
+  const int h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
+  const int i0 = ti * 256, j0 = tj * 256;
+  const int nt = (rows + TN_BKM - 1) / TN_BKM;
+  const int wx = (a.I - i0 < 256) ? a.I - i0 : 256, wy = (a.J - j0 < 256) ? a.J - j0 : 256;
+  const int64_t nbx = rows > 0 ? ((int64_t)(rows - 1) * a.ldx + wx) * 2 : 0;
+  const int64_t nby = rows > 0 ? ((int64_t)(rows - 1) * a.ldy + wy) * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)mb * a.ldx + i0), 0, (int)(nbx > 0x7fffffff ? 0x7fffffff : nbx), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (int64_t)mb * a.ldy + j0), 0, (int)(nby > 0x7fffffff ? 0x7fffffff : nby), 0x00020000);
+  // DMA: linear LDS chunk c = tid + 512 i -> row c>>5, physical chunk c&31 holds source chunk (c&31) ^ 4*(row&3)
+  int vox[4], voy[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 5) + 16 * i;
+    const int sch = (tid & 31) ^ (4 * (row & 3));
+    vox[i] = (8 * sch < wx) ? (row * a.ldx + 8 * sch) * 2 : 0x7ffffff0;  // columns past the width read as 0
+    voy[i] = (8 * sch < wy) ? (row * a.ldy + 8 * sch) * 2 : 0x7ffffff0;
+  }
+  const int stepx = TN_BKM * a.ldx * 2, stepy = TN_BKM * a.ldy * 2;
+  const bool do_bias = (bias_out != nullptr) && (ti == 0);
+  const bool use_w = do_bias && (a.bias_w != nullptr);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(use_w ? a.bias_w + mb : a.Y), 0, (int)(use_w ? (int64_t)rows * 2 : 0), 0x00020000);
+  int vow = lane * 4;
+  // fragment read offsets (bytes): row 8h + (l16>>2) [+16kk, +4], byte in row = (wave col base + f*64 + 32*(g4&1) + 8*(l16&3)) ^ 64*(row&3)
+  const int rr = l16 >> 2;
+  const int rowb = (8 * h + rr) * 512;
+  const int cb = 32 * (g4 & 1) + 8 * (l16 & 3);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
+  unsigned ofx[4], ofy[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ofx[i] = lds0 + rowb + ((wi * 256 + i * 64 + cb) ^ (64 * rr));
+#pragma unroll
+  for (int j = 0; j < 2; ++j) ofy[j] = lds0 + 32768 + rowb + ((wj * 128 + j * 64 + cb) ^ (64 * rr));
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  f32x16 bacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
+
+  auto stage = [&](int st) {
+    char* base = smem_tn + st * 65536 + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(rx, base + i * 8192, vox[i], 0);
+      vox[i] += stepx;
+      glds16(ry, base + 32768 + i * 8192, voy[i], 0);
+      voy[i] += stepy;
+    }
+    if (use_w) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 131072 + st * 256), 4, vow, 0, 0, 0);
+      vow += TN_BKM * 2;
+    }
+  };
+  auto mfmas = [&](TrFrag8& f, const bf16x8 wa) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f.x[i][0], f.x[i][1]), tr_cat(f.y[j][0], f.y[j][1]), acc[i][j], 0, 0, 0);  // D[i][j]
+    if (do_bias) {  // waves (0, wj) / (1, wj) sum columns wj*64 + {0..31} / {32..63}
+      if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f.y[0][0], f.y[0][1]), bacc, 0, 0, 0);
+      else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f.y[1][0], f.y[1][1]), bacc, 0, 0, 0);
+    }
+  };
+  auto compute = [&](auto stc) {
+    constexpr int st = decltype(stc)::value;
+    unsigned ax[4], ay[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ax[i] = ofx[i] + st * 65536;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ay[j] = ofy[j] + st * 65536;
+    WFrag wf;
+    if (use_w) w_issue(wf, lds0 + 131072 + st * 256 + 16 * h);
+    TrFrag8 F0, F1;
+    tr8_issue<0>(F0, ax, ay);
+    tr8_issue<8192>(F1, ax, ay);
+    tr8_wait<12>(F0);
+    if (use_w) w_wait(wf);   // (drains F1 too; bias blocks only)
+    mfmas(F0, use_w ? __builtin_bit_cast(bf16x8, wf.w[0]) : ones);
+    tr8_issue<16384>(F0, ax, ay);
+    tr8_wait<12>(F1);
+    mfmas(F1, use_w ? __builtin_bit_cast(bf16x8, wf.w[1]) : ones);
+    tr8_issue<24576>(F1, ax, ay);
+    tr8_wait<12>(F0);
+    mfmas(F0, use_w ? __builtin_bit_cast(bf16x8, wf.w[2]) : ones);
+    tr8_wait<0>(F1);
+    mfmas(F1, use_w ? __builtin_bit_cast(bf16x8, wf.w[3]) : ones);
+  };
+
+  if (nt > 0) {
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 <= nt; t += 2) {
+      stage(1);
+      compute(std::integral_constant<int, 0>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 2 < nt) stage(0);
+      compute(std::integral_constant<int, 1>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (t < nt) {
+      compute(std::integral_constant<int, 0>{});
+      __syncthreads();
+    }
+  }
+  // store: reg e -> row i = (e&3) + 8*(e>>2) + 4h ; col j = lane&31
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wj * 64 + j * 32 + (lane & 31);
+      if (col >= a.J) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = i0 + wi * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row < a.I) C[(int64_t)row * a.J + col] = acc[i][j][e];
+      }
+    }
+  if (do_bias && h == 0) {  // row 0 of D (reg 0 of the lower half-wave) holds the column sums
+    const int col = j0 + wj * 64 + wi * 32 + (lane & 31);
+    if (col < a.J) bias_out[col] = bacc[0];
+  }
+}
+
 // Unsplit shapes whose tile count is not a multiple of the 512 resident blocks (the head: 4 x 397 = 1588 tiles = 3.1
 // residencies of ~0.85 ms blocks -> the last 52 blocks ran alone for ~20 % of the kernel, MFMA pipe 37 % busy, PMC
 // profiles/pmc/r01g_tn_*).  The first n_whole = 512 * floor(tiles / 512) tiles run as before; each remaining tile is cut
@@ -931,12 +1291,13 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   DMI_REQUIRE(!bias_weights || (dbias && ((uintptr_t)bias_weights & 3) == 0), "gemm_tn: bias_weights needs dbias and 4-byte alignment");
   DMI_REQUIRE((int64_t)TN_BKM * (ldx > ldy ? ldx : ldy) * 2 < 0x7fffffff, "gemm_tn: leading dimension too large");
   hipStream_t st = (hipStream_t)stream;
-  const int nsplit = tn_splits(M, I, J);
+  const bool use8 = tn8_eligible(M, I, J);
+  const int nsplit = use8 ? tn8_splits(M, I, J) : tn_splits(M, I, J);
   float* slabs = (float*)workspace;
   const int64_t slab_bytes = (nsplit > 1) ? round_up64((int64_t)nsplit * I * J * 4, 256) : 0;
   TnArgs a;
   a.X = X; a.Y = dY; a.M = M; a.I = I; a.J = J; a.ldx = ldx; a.ldy = ldy;
-  a.tiles_i = (I + 127) / 128; a.tiles_j = (J + 127) / 128;
+  a.tiles_i = use8 ? (I + 255) / 256 : (I + 127) / 128; a.tiles_j = use8 ? (J + 255) / 256 : (J + 127) / 128;
   a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
   a.C = (nsplit > 1) ? slabs : dW;
   a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
@@ -954,6 +1315,12 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   const int tiles = a.tiles_i * a.tiles_j;
   const int tail_tiles = tiles % 512, n_whole = tiles - tail_tiles;
   const int S = tail_tiles ? 512 / tail_tiles : 1;
+  if (use8) {
+    static bool attr8 = false;
+    if (!attr8) { (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN8_LDS_BYTES); attr8 = true; }
+    gemm_tn8_kernel<<<dim3(tiles * nsplit), dim3(512), TN8_LDS_BYTES, st>>>(a);
+    DMI_CHECK_LAUNCH("gemm_tn8");
+  } else
   // tiles are numbered ti-fastest: with tiles_i | n_whole the tail is the column stripe [c0, J) of dW
   if (g_opt_tn_tail && nsplit == 1 && tiles > 512 && S >= 2 && a.tiles_i <= GROUP_M && n_whole % a.tiles_i == 0 && J % 4 == 0) {
     const int c0 = (n_whole / a.tiles_i) * 128, W = J - c0;

@@ -259,7 +259,7 @@ class DalleEngine:
         wsz = max(dh.gemm_tn_workspace_bytes(M, d, Vp), dh.gemm_tn_workspace_bytes(M, 4 * d, d),
                   dh.gemm_tn_workspace_bytes(M, d, 4 * d), dh.gemm_tn_workspace_bytes(M, d, 3 * d),
                   dh.gemm_tn_workspace_bytes(M, d, d), dh.layernorm_bwd_workspace_bytes(M, d),
-                  dh.sumsq_workspace_bytes(self.lay.total), dh.gemm_nt_splitk_workspace_bytes(M, d, 2))
+                  dh.sumsq_workspace_bytes(self.lay.total), dh.gemm_nt_splitk_workspace_bytes(M // 2 + 256, d, 8))
         self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
         # tuning switch: hparams win, the environment variable gives the default (A/B runs: tools/ab_env.sh)
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
@@ -367,22 +367,22 @@ class DalleEngine:
         # head: dW = (rowscale * xnf)^T E, dbias = rowscale^T E, dxn = rowscale * (E W^T)
         self._wgrad(self.xs, d, E, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
                     dbias=self._gv("to_logits/linear_out/bias"), bias_weights=self.rowscale_bf)
-        # K = vocabulary: the 128x128 tiles of this [M, d] output run as long blocks; when the last residency of the chip
-        # (512 blocks = 2 per CU) would be partly empty, its rows are computed by a second launch with K split in two
-        tiles = ((M + 127) // 128) * ((d + 127) // 128)
-        frac = (tiles / 512.0) % 1.0
-        tail_rows = 0
-        if tiles > 512 and 0.25 <= frac <= 0.75 and self.hp["dgrad_tail_split"]:
-            tail_rows = (tiles % 512) // ((d + 127) // 128) * 128
-            tail_rows = min(tail_rows, M) // 128 * 128
+        # K = vocabulary: main-loop-bound -> 256x256 tiles, one 8-wave block per CU (the library picks that kernel for long-K
+        # launches that fill whole residencies of the 256 CUs).  The rows of the whole residencies run unsplit; the rows of the
+        # ragged last residency run with K split so that they also fill the chip (fp32 slabs, deterministic reduce).
+        # Measured per step (profiles/r02c_*): 1.46 + 0.47 ms vs 1.81 + 0.46 ms with 128x128 tiles.
         Wk = self._w("to_logits/linear_out/kernel")
-        if tail_rows > 0 and dh.gemm_nt_splitk_workspace_bytes(tail_rows, d, 2) <= self.ws.numel():
-            head_rows = M - tail_rows
-            dh.gemm_nt(E, Vp, Wk, Vp, self.dxn, d, head_rows, d, Vp, dh.GEMM_ROWSCALE, rowscale=self.rowscale)
-            dh.gemm_nt_splitk(E[head_rows:], Vp, Wk, Vp, self.dxn[head_rows:], tail_rows, d, Vp, 2, self.ws,
-                              rowscale=self.rowscale[head_rows:])
-        else:
+        tn8 = (d + 255) // 256
+        whole_rows = min(M, (((M + 255) // 256) * tn8 // 256) * 256 // tn8 * 256) if self.hp["dgrad_tail_split"] else M
+        if whole_rows in (0, M) or Vp < 8192:
             dh.gemm_nt(E, Vp, Wk, Vp, self.dxn, d, M, d, Vp, dh.GEMM_ROWSCALE, rowscale=self.rowscale)
+        else:
+            tail_rows = M - whole_rows
+            tail_tiles = ((tail_rows + 255) // 256) * tn8
+            ns = next((k for k in (2, 4, 8) if (tail_tiles * k) % 256 == 0 and Vp // k >= 4096), 2)
+            dh.gemm_nt(E, Vp, Wk, Vp, self.dxn, d, whole_rows, d, Vp, dh.GEMM_ROWSCALE, rowscale=self.rowscale)
+            dh.gemm_nt_splitk(E[whole_rows:], Vp, Wk, Vp, self.dxn[whole_rows:], tail_rows, d, Vp, ns, self.ws,
+                              rowscale=self.rowscale[whole_rows:])
         dxa, dxb = self.dx
         dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                          self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)

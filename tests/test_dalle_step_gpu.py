@@ -85,23 +85,25 @@ def test_microbatched_step_equals_full_batch_step():
 
 
 def test_head_dgrad_tail_split_matches_single_launch(monkeypatch):
-    """M = 768 row tiles of the [M, d] head input gradient = 1.5 residencies: the last 256 tiles run as a second launch
-    with K split in two.  Same gradients as the single launch up to the fp32 summation order of the two K halves."""
+    """M = 320 row tiles of 256 of the [M, d] head input gradient = 1.25 residencies of the 256 CUs: the last 64 tiles run as a
+    second launch with K (the vocabulary) split.  Same gradients as the single launch up to the fp32 summation order of the
+    K parts."""
     from oracle import dalle_oracle as do
     from src.dalle_mtf.engine import DalleEngine
-    B, T, P = 96, 24, 1000          # S = 1024, M = 98304 = 768 x 128
-    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(B, T, 300, seed=1),
-                                                 do.synthetic_image_tokens(B, P, 40, seed=2), 300)).cuda()
+    B, T, P = 80, 24, 1000          # S = 1024, M = 81920 = 320 x 256; V = 8000 + 191 + 1 = 8192
+    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(B, T, 8000, seed=1),
+                                                 do.synthetic_image_tokens(B, P, 191, seed=2), 8000)).cuda()
     grads = []
     for flag in ("0", "1"):
         monkeypatch.setenv("DALLE_DGRAD_TAIL", flag)
-        eng = DalleEngine(128, 1, 1, 300, 40, T, P, batch_size=B, hparams=dict(lr=1e-3, train_steps=10))
+        eng = DalleEngine(256, 1, 2, 8000, 191, T, P, batch_size=B, hparams=dict(lr=1e-3, train_steps=10))
         eng.init_params(seed=7)
         loss = float(eng.forward(tokens, need_grad=True))
         eng.backward()
         torch.cuda.synchronize()
         grads.append((loss, eng.g.clone()))
         del eng
+        torch.cuda.empty_cache()
     assert grads[0][0] == grads[1][0]
     num, den = float((grads[0][1] - grads[1][1]).norm()), float(grads[0][1].norm())
     assert 0 < den and num <= 5e-3 * den, (num, den)

@@ -209,6 +209,47 @@ def test_gemm_nt4_tile_256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "256-row-tile and 128-row-tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (2100, 520, 320, 5), (512, 512, 1024, 3),
+                                         (515, 136, 64, 8), (700, 264, 128, 32), (256, 256, 64, 16)])
+def test_gemm_nt8_tile_256x256(M, N, K, flags):
+    """256x256x64-tile 8-wave kernel (forced), incl. M/N tails, odd K-step counts and every epilogue: bit-identical to the
+    128x128x64 kernel (identical k order)."""
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    hsrc = torch.relu(rnd(M, N, seed=5))
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(6)) + 0.5
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None,
+              relu_src=hsrc.to(DEV) if flags & 8 else None, rowscale=rs.to(DEV) if flags & 32 else None)
+    ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res if flags & 4 else None,
+                    relu_src=hsrc if flags & 8 else None)
+    if flags & 32:
+        ref = ref * rs[:, None]
+    outs = []
+    dh.set_option("nt4", 0)
+    try:
+        for nt8 in (2, 0):
+            dh.set_option("nt8", nt8)
+            C = torch.zeros(M, N, dtype=torch.float32 if flags & 16 else torch.bfloat16, device=DEV)
+            dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
+            close(C, ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt nt8={nt8}")
+            outs.append(C.cpu())
+    finally:
+        dh.set_option("nt8", 1)
+        dh.set_option("nt4", 1)
+    assert torch.equal(outs[0], outs[1]), "256x256 and 128x128 tile kernels must be bit-identical"
+
+
+def test_gemm_nt8_splitk_rowscale():
+    """the head input-gradient form: long K split in 4, 256x256 tiles (auto: 4 x 64 tiles = 256 blocks), row scale in the reduce"""
+    M, N, K = 2048, 2048, 4096 * 4
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(3)) + 0.5
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    w = ws(dh.gemm_nt_splitk_workspace_bytes(M, N, 4))
+    dh.gemm_nt_splitk(A.to(DEV), K, Bt.to(DEV), K, C, M, N, K, 4, w, rowscale=rs.to(DEV))
+    close(C, _gemm_ref(A, Bt) * rs[:, None], 1.6e-2, 2e-2 * math.sqrt(K / 64) * 0.05, "nt8 split-K")
+
+
 @pytest.mark.parametrize("M,N,K,ns", [(300, 256, 1024, 2), (1024, 512, 4096, 2), (130, 128, 448, 3)])
 def test_gemm_nt_splitk(M, N, K, ns):
     A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.1, seed=2)
@@ -221,12 +262,15 @@ def test_gemm_nt_splitk(M, N, K, ns):
     close(C, _gemm_ref(A, Bt) * rs[:, None], 1.6e-2, 2e-2 * math.sqrt(K / 64) * 0.1, "gemm_nt_splitk row scale")
 
 
-@pytest.mark.parametrize("tail", [1, 0])
+@pytest.mark.parametrize("tail,tn8", [(1, 0), (0, 0), (1, 2), (1, 1)])
 @pytest.mark.parametrize("M,I,J", [(256, 128, 128), (544, 256, 384), (4096, 512, 256), (1000, 128, 1160), (72, 136, 200),
-                                   (48, 128, 128), (100, 64, 72), (10000, 512, 512),
+                                   (48, 128, 128), (100, 64, 72), (10000, 512, 512), (5000, 520, 776),
                                    (200, 1024, 8320), (330, 640, 13320)])   # 520 / 525 tiles: the row-split tail launch
-def test_gemm_tn(tail, M, I, J):
+def test_gemm_tn(tail, tn8, M, I, J):
+    """tn8 = 0: 128x128-tile kernel (with / without the row-split tail launch); 2: 256x256-tile 8-wave kernel forced
+    (incl. ragged tiles and tiny M); 1: automatic choice."""
     dh.set_option("tn_tail", tail)
+    dh.set_option("tn8", tn8)
     try:
         X, dY = rnd(M, I, seed=1), rnd(M, J, seed=2)
         dW = torch.full((I, J), 7.0, dtype=torch.float32, device=DEV)
@@ -248,6 +292,7 @@ def test_gemm_tn(tail, M, I, J):
         close(db2, wv.float() @ dY.float(), 1e-4, 1e-3 * math.sqrt(M), f"gemm_tn weighted bias grad tail={tail}")
     finally:
         dh.set_option("tn_tail", 1)
+        dh.set_option("tn8", 1)
 
 
 # ------------------------------------------------------------------ fused softmax head

@@ -40,20 +40,40 @@ def bench_gemm_nt(M, N, K, flags=0, tag="", variants=(("auto", 1),)):
     bias, res = rb(N), rb(M, N)
     rs = torch.rand(M, device=DEV)
     for name, nt4 in variants:
-        dh.set_option("nt4", nt4)
+        dh.set_option("nt4", nt4 if nt4 < 8 else 0)
+        dh.set_option("nt8", 2 if nt4 == 8 else 0)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res, rowscale=rs))
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     dh.set_option("nt4", 1)
+    dh.set_option("nt8", 1)
+
+
+def bench_splitk(M, N, K, ns, nt8):
+    A, Bt = rb(M, K), rb(N, K, scale=0.05)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    rs = torch.rand(M, device=DEV)
+    w = ws(dh.gemm_nt_splitk_workspace_bytes(M, N, ns))
+    dh.set_option("nt8", nt8)
+    t = timeit(lambda: dh.gemm_nt_splitk(A, K, Bt, K, C, M, N, K, ns, w, rowscale=rs), iters=10)
+    print(f"gemm_nt_splitk M={M} N={N} K={K} nsplit={ns} nt8={nt8}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
+    dh.set_option("nt8", 1)
 
 
 def bench_gemm_tn(M, I, J, weighted=False):
+    for tn8 in (0, 1):
+        dh.set_option("tn8", tn8)
+        _bench_gemm_tn(M, I, J, weighted, tn8)
+    dh.set_option("tn8", 1)
+
+
+def _bench_gemm_tn(M, I, J, weighted, tn8):
     X, dY = rb(M, I), rb(M, J)
     dW = torch.empty(I, J, dtype=torch.float32, device=DEV)
     db = torch.empty(J, dtype=torch.float32, device=DEV)
     bw = rb(M) if weighted else None
     w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
     t = timeit(lambda: dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db, bias_weights=bw))
-    print(f"gemm_tn M={M} I={I} J={J} weighted_bias={int(weighted)}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
+    print(f"gemm_tn M={M} I={I} J={J} weighted_bias={int(weighted)} tn8={tn8}: {t*1e6:9.1f} us  {2*M*I*J/t/1e12:8.1f} TF/s", flush=True)
 
 
 def bench_attention(B, H, S):
@@ -118,9 +138,19 @@ if __name__ == "__main__":
         bench_gemm_nt(M, 4 * d, d, 8, " ffn2-dgrad", both)
         bench_gemm_nt(M, d, 4 * d, 0, " ffn1-dgrad", both)
         bench_gemm_nt(M, d, 3 * d, 0, " qkv-dgrad", both)
+    if "big" in what:
+        three = (("nt2", 0), ("nt4", 2), ("nt8", 8))
+        bench_gemm_nt(M, 2048, 2048, 0, " big", three)
+        bench_gemm_nt(M, 4096, 4096, 0, " big", three)
+        bench_gemm_nt(M, 50816, 512, 1, " logits", three)
+        bench_gemm_nt(M, 2048, 512, 3, " ffn1", three)
+        bench_gemm_nt(M, 512, 2048, 5, " ffn2", three)
+        bench_gemm_nt(M, 512, 50816, 32, " head-dgrad", (("nt2", 0), ("nt8", 8)))
+        for ns, nt8 in ((2, 0), (4, 0), (4, 2), (8, 2)):
+            bench_splitk(M, 512, 50816, ns, nt8)
     if "tn" in what:
         for I, J in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d), (d, 50816)):
-            bench_gemm_tn(M, I, J)
+            bench_gemm_tn(M, I, J, weighted=(J == 50816))
     if "attn" in what:
         bench_attention(32, 4, 1280)
     if "head" in what:
