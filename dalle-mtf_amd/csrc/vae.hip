@@ -306,3 +306,142 @@ extern "C" int dmi_unpad_channels(const uint16_t* in, float* out, int64_t N, int
   DMI_CHECK_LAUNCH("unpad_channels");
   return DMI_OK;
 }
+
+// =====================================================================================
+// fp32 convolution for the TOKENISING encoder.  Inside dalle_model_fn the reference builds the VAE without use_bf16
+// (src/model_fns.py:43-51), so the image tokens fed to DALL-E come from an fp32 encoder and an fp32 `x @ codebook`
+// (src/vae_tf/models.py:81-120); argmax over bf16-computed logits flips tokens whose top-2 gap is below bf16 noise.
+// This kernel is that path: implicit-im2col convolution on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32, 1/16 of
+// the bf16 rate -- forward only, the image is tokenised once per step), weights in the TF layout [(tap, ci)][co] straight
+// from the fp32 master buffer.
+//   out[(b,oy,ox)][n] = sum_t sum_c x[b, oy*s + dy[t], ox*s + dx[t], c] * Wk[(t*C + c)][n]  + bias[n]  (ReLU) (+ residual)
+// Block = 128 output pixels x 64 channels, 4 waves of 32 x 64; the K loop walks (tap, 8-channel chunk): a chunk lies in one
+// tap (C % 8 == 0).  LDS: A chunk k-major [8][128] so both MFMA operands are read as 32 consecutive floats.
+// The codebook product is the same kernel with one tap on a 1x1 "image".
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) float v4f;
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(const float* __restrict__ x, const float* __restrict__ Wk,
+                                                         const float* __restrict__ bias, const float* __restrict__ residual,
+                                                         float* __restrict__ out, TapList taps, int B, int H, int W, int C,
+                                                         int Ho, int Wo, int stride, int N, int relu) {
+  __shared__ float As[8][128];
+  __shared__ float Ws[8][64];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int64_t M = (int64_t)B * Ho * Wo;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;
+  const int n0 = blockIdx.y * 64;
+  // loader role: pixel p, channel half
+  const int p = tid & 127, half = tid >> 7;
+  const int64_t mp = m0 + p;
+  const bool pok = mp < M;
+  const int ox = (int)(mp % Wo), oy = (int)((mp / Wo) % Ho), b = (int)(mp / ((int64_t)Wo * Ho));
+  const int wrow = tid >> 4, wc4 = (tid & 15) * 4;   // W loader (threads 0..127): row of the chunk, 4 columns
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int cchunks = C / 8;
+  for (int t = 0; t < taps.n; ++t) {
+    const int iy = oy * stride + taps.dy[t], ix = ox * stride + taps.dx[t];
+    const bool inside = pok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    const float* xp = x + (((int64_t)b * H + iy) * W + ix) * C + 4 * half;
+    for (int cc = 0; cc < cchunks; ++cc) {
+      v4f av = {0.f, 0.f, 0.f, 0.f};
+      if (inside) av = *(const v4f*)(xp + cc * 8);
+      v4f wv = {0.f, 0.f, 0.f, 0.f};
+      if (tid < 128 && n0 + wc4 < N) wv = *(const v4f*)(Wk + ((int64_t)(t * C + cc * 8 + wrow)) * N + n0 + wc4);
+      __syncthreads();   // previous chunk's fragments have been read
+#pragma unroll
+      for (int j = 0; j < 4; ++j) As[4 * half + j][p] = av[j];
+      if (tid < 128) *(v4f*)&Ws[wrow][wc4] = wv;
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const float a = As[2 * kk + (lane >> 5)][wid * 32 + (lane & 31)];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float w = Ws[2 * kk + (lane >> 5)][j * 32 + (lane & 31)];
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc[j], 0, 0, 0);   // D[pixel][channel]
+        }
+      }
+    }
+  }
+  // D layout: lane holds channel (lane & 31) for pixels (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + j * 32 + (lane & 31);
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int64_t m = m0 + wid * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      if (m >= M) continue;
+      float v = acc[j][e] + bv;
+      if (relu) v = fmaxf(v, 0.f);
+      if (residual) v += residual[m * N + n];
+      out[m * N + n] = v;
+    }
+  }
+}
+extern "C" int dmi_conv2d_f32(const float* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps, const int* dy,
+                              const int* dx, const float* Wk, const float* bias, const float* residual, float* out, int N,
+                              int relu, void* stream) {
+  DMI_REQUIRE(x && Wk && out && dy && dx, "conv2d_f32: null pointer");
+  DMI_REQUIRE(C % 8 == 0 && N % 4 == 0 && ntaps >= 1 && ntaps <= MAX_TAPS && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && stride >= 1,
+              "conv2d_f32: need C%%8==0, N%%4==0, 1..16 taps (C=%d N=%d ntaps=%d)", C, N, ntaps);
+  DMI_REQUIRE((((uintptr_t)x | (uintptr_t)Wk | (uintptr_t)out) & 15) == 0, "conv2d_f32: operands must be 16-byte aligned");
+  TapList t;
+  t.n = ntaps;
+  for (int i = 0; i < ntaps; ++i) { t.dy[i] = dy[i]; t.dx[i] = dx[i]; }
+  const int64_t M = (int64_t)B * Ho * Wo;
+  conv2d_f32_kernel<<<dim3((unsigned)cdiv64(M, 128), (unsigned)((N + 63) / 64)), dim3(256), 0, (hipStream_t)stream>>>(
+      x, Wk, bias, residual, out, t, B, H, W, C, Ho, Wo, stride, N, relu);
+  DMI_CHECK_LAUNCH("conv2d_f32");
+  return DMI_OK;
+}
+
+// tf.space_to_depth / tf.depth_to_space (NHWC, block size s; src/vae_tf/models.py:85-86,158-161), fp32, with channel
+// padding: stacked[b, y, x, (dy*s + dx)*C + c] = img[b, y*s + dy, x*s + dx, c] for c < C; stacked channels [s*s*C, Cp) = 0.
+__global__ __launch_bounds__(256) void space_to_depth_kernel(const float* __restrict__ img, float* __restrict__ out, int B, int Hs,
+                                                             int Ws_, int C, int s, int Cp) {
+  const int64_t total = (int64_t)B * Hs * Ws_ * Cp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cp = (int)(i % Cp);
+    const int64_t pix = i / Cp;
+    float v = 0.f;
+    if (cp < s * s * C) {
+      const int c = cp % C, blk = cp / C, dy = blk / s, dx = blk % s;
+      const int xx = (int)(pix % Ws_), yy = (int)((pix / Ws_) % Hs), b = (int)(pix / ((int64_t)Ws_ * Hs));
+      v = img[(((int64_t)b * Hs * s + yy * s + dy) * (Ws_ * s) + xx * s + dx) * C + c];
+    }
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void depth_to_space_kernel(const float* __restrict__ stacked, float* __restrict__ img, int B,
+                                                             int Hs, int Ws_, int C, int s, int Cp) {
+  const int64_t total = (int64_t)B * Hs * s * Ws_ * s * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t pix = i / C;
+    const int X = (int)(pix % (Ws_ * s)), Y = (int)((pix / (Ws_ * s)) % (Hs * s)), b = (int)(pix / ((int64_t)Ws_ * s * Hs * s));
+    const int yy = Y / s, dy = Y % s, xx = X / s, dx = X % s;
+    img[i] = stacked[(((int64_t)b * Hs + yy) * Ws_ + xx) * Cp + (dy * s + dx) * C + c];
+  }
+}
+extern "C" int dmi_space_to_depth_f32(const float* img, float* stacked, int B, int Hs, int Ws_, int C, int s, int Cp, void* stream) {
+  DMI_REQUIRE(img && stacked && B > 0 && Hs > 0 && Ws_ > 0 && C > 0 && s >= 1 && Cp >= s * s * C, "space_to_depth: bad args");
+  int64_t blocks = cdiv64((int64_t)B * Hs * Ws_ * Cp, 256);
+  if (blocks > 16384) blocks = 16384;
+  space_to_depth_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(img, stacked, B, Hs, Ws_, C, s, Cp);
+  DMI_CHECK_LAUNCH("space_to_depth");
+  return DMI_OK;
+}
+extern "C" int dmi_depth_to_space_f32(const float* stacked, float* img, int B, int Hs, int Ws_, int C, int s, int Cp, void* stream) {
+  DMI_REQUIRE(img && stacked && B > 0 && Hs > 0 && Ws_ > 0 && C > 0 && s >= 1 && Cp >= s * s * C, "depth_to_space: bad args");
+  int64_t blocks = cdiv64((int64_t)B * Hs * s * Ws_ * s * C, 256);
+  if (blocks > 16384) blocks = 16384;
+  depth_to_space_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(stacked, img, B, Hs, Ws_, C, s, Cp);
+  DMI_CHECK_LAUNCH("depth_to_space");
+  return DMI_OK;
+}

@@ -96,6 +96,9 @@ def _declare(L):
         "dmi_mse_workspace_bytes": (L64, []),
         "dmi_mse_loss": (I, [P, P, P, P, L64, I, I, F, P, P]),
         "dmi_add_f32": (I, [P, P, L64, P]),
+        "dmi_conv2d_f32": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, I, I, P]),
+        "dmi_space_to_depth_f32": (I, [P, P, I, I, I, I, I, I, P]),
+        "dmi_depth_to_space_f32": (I, [P, P, I, I, I, I, I, I, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -385,3 +388,21 @@ def mse_loss(img, outp, dout, loss, N, Cin, Cp, grad_scale, ws):
 def add_f32(dst, src, n):
     _dev(dst, src)
     _check(lib().dmi_add_f32(_p(dst), _p(src), n, _stream()), "add_f32")
+
+
+def conv2d_f32(x, B, H, W, C, Ho, Wo, stride, taps, Wk, bias, residual, out, N, relu=False):
+    """fp32 convolution on the exact-fp32 matrix cores (tokenising encoder); taps = [(dy, dx), ...]."""
+    _dev(x, Wk, bias, residual, out)
+    dy, dx = _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps])
+    _check(lib().dmi_conv2d_f32(_p(x), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p), ctypes.cast(dx, c_void_p),
+                                _p(Wk), _p(bias), _p(residual), _p(out), N, int(bool(relu)), _stream()), "conv2d_f32")
+
+
+def space_to_depth_f32(img, stacked, B, Hs, Ws, C, s, Cp):
+    _dev(img, stacked)
+    _check(lib().dmi_space_to_depth_f32(_p(img), _p(stacked), B, Hs, Ws, C, s, Cp, _stream()), "space_to_depth_f32")
+
+
+def depth_to_space_f32(stacked, img, B, Hs, Ws, C, s, Cp):
+    _dev(stacked, img)
+    _check(lib().dmi_depth_to_space_f32(_p(stacked), _p(img), B, Hs, Ws, C, s, Cp, _stream()), "depth_to_space_f32")

@@ -46,6 +46,8 @@ def load_vae_model(params, mode_str):
         dimensions=D,
         batch_size=params[f"{mode_str}_batch_size"] // max(_dist_info()[0], 1),
         mode="eval")
+    # the reference does not forward use_bf16 here, so its tokenising encoder is fp32: same here unless switched off
+    vae_model.fp32_tokens = bool(params.get("vae_tokens_fp32", True))
     return vae_model, vae_checkpoint_path
 
 

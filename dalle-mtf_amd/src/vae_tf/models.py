@@ -73,13 +73,18 @@ class DiscreteVAE:
         self.num_ch = input_channels
         self.H = self.W = dimensions
         self.convblocks = [tuple(b) for b in convblocks]
-        self.recompute_grad = recompute_grad     # memory-only option upstream; activations are simply kept here
+        self.recompute_grad = recompute_grad     # memory-only option: residual branches are re-run in backward()
         self.bf16 = use_bf16                     # kernels always compute in bf16 with fp32 accumulation
         assert math.log2(stack_factor).is_integer()
-        if stack_factor != 1:
-            raise NotImplementedError("stack_factor > 1 (space_to_depth) is not used by any shipped config")
+        # tf.space_to_depth in front of the encoder / tf.depth_to_space behind the decoder (reference :85-86,158-161): the
+        # network runs on [B, H/s, W/s, C*s*s]; two index kernels do the re-layout, everything else is unchanged
         self.stack_factor = stack_factor
-        assert input_channels <= IMG_CP
+        assert dimensions % stack_factor == 0
+        self.Hs = dimensions // stack_factor                 # spatial size the convolutions see
+        self.c_st = input_channels * stack_factor ** 2       # channels after space_to_depth
+        self.img_cp = _ru(self.c_st, 8)                      # ... padded for the 16-byte vector paths
+        assert self.c_st <= OUT_CP, "stack_factor too large for the padded reconstruction width"
+        self.fp32_tokens = False   # return_logits path on the exact-fp32 kernels (set by dalle_model_fn's load_vae_model)
         for _, ch in self.convblocks:
             assert ch % 16 == 0, "channel counts must be multiples of 16"
         assert num_tokens % 64 == 0, "num_tokens must be a multiple of 64"
@@ -88,7 +93,7 @@ class DiscreteVAE:
         self.dev = torch.device(device)
         self.pg, self.world = process_group, world_size
         self.n_hid = self.convblocks[-1][1]
-        self.grid = self.H // (2 ** len(self.convblocks))
+        self.grid = self.Hs // (2 ** len(self.convblocks))
         self.global_step = 0
         self._build_graph()
         self._alloc()
@@ -96,7 +101,7 @@ class DiscreteVAE:
     # ------------------------------------------------------------------ structure
     def _build_graph(self):
         convs: List[_Conv] = []
-        H, cin, cin_ref = self.H, IMG_CP, self.num_ch
+        H, cin, cin_ref = self.Hs, self.img_cp, self.c_st
         for b, (stack, ch) in enumerate(self.convblocks):
             for i in range(stack):
                 p = f"encoder/block_{b}/layer_{i}/"
@@ -118,7 +123,7 @@ class DiscreteVAE:
                     convs.append(_Conv(p + "conv_in", "res", ch, ch, H, H))
                     convs.append(_Conv(p + "conv_out", "res", ch, ch, H, H))
             cin = ch
-        convs.append(_Conv("decoder/conv2d", "final", cin, OUT_CP, H, H, cout_ref=self.num_ch))
+        convs.append(_Conv("decoder/conv2d", "final", cin, OUT_CP, H, H, cout_ref=self.c_st))
         self.convs = convs
         # flat parameter layout
         self.offset: Dict[str, int] = {}
@@ -175,11 +180,20 @@ class DiscreteVAE:
         self._col_valid = set()
         self.keep_cols = (self.mode == "train")
         # activations
-        self.x_img = torch.empty(B * self.H * self.W, IMG_CP, **b16)
+        self.x_img = torch.empty(B * self.Hs * self.Hs, self.img_cp, **b16)
+        self.img_st = torch.empty(B * self.Hs * self.Hs, self.c_st, **f32) if self.stack_factor > 1 else None
         self.act_in = [None] * len(self.convs)     # input of each conv (kept for the weight gradients)
         self.act_out = []
+        # recompute_grad (reference vae_tf/models.py:8-43,102,150): the residual branch is re-run in the backward pass instead of
+        # keeping its inner activation -- here: every conv_in output shares ONE buffer, refilled by backward() before use
+        shared = None
+        if self.recompute_grad:
+            shared = torch.empty(max([B * c.Ho * c.Wo * c.cout for c in self.convs if c.name.endswith("conv_in")] + [8]), **b16)
         for c in self.convs:
-            self.act_out.append(torch.empty(B * c.Ho * c.Wo, c.cout, **b16))
+            if shared is not None and c.name.endswith("conv_in"):
+                self.act_out.append(shared[:B * c.Ho * c.Wo * c.cout].view(B * c.Ho * c.Wo, c.cout))
+            else:
+                self.act_out.append(torch.empty(B * c.Ho * c.Wo, c.cout, **b16))
         Mg = B * self.grid * self.grid
         self.Mg = Mg
         self.logits = torch.empty(Mg, self.num_tokens, **f32)
@@ -345,8 +359,15 @@ class DiscreteVAE:
         B = self.B
         assert img.shape == (B, self.H, self.W, self.num_ch), f"expected {(B, self.H, self.W, self.num_ch)}, got {tuple(img.shape)}"
         self.img = img
+        if return_logits and self.fp32_tokens:
+            return self.encode_logits_fp32(img)
         self._col_valid.clear()
-        dh.pad_channels(img, self.x_img, B * self.H * self.W, self.num_ch, IMG_CP)
+        Np = B * self.Hs * self.Hs
+        if self.stack_factor > 1:
+            dh.space_to_depth_f32(img, self.img_st, B, self.Hs, self.Hs, self.num_ch, self.stack_factor, self.c_st)
+            img = self.img_st          # the loss is permutation-invariant: computed in the stacked layout
+        self.img_net = img
+        dh.pad_channels(img, self.x_img, Np, self.c_st, self.img_cp)
         x = self.x_img
         convs = self.convs
         i = 0
@@ -395,13 +416,57 @@ class DiscreteVAE:
             return self.reconstruction()
         need_grad = (self.mode == "train") if need_grad is None else need_grad
         # d(out) of mean((img-out)^2); 1/world folds the CrossShardOptimizer mean (src/model_fns_tf.py:61) into the gradient
-        dh.mse_loss(img, x, self.ga if need_grad else None, self.loss, B * self.H * self.W, self.num_ch, OUT_CP, 1.0, self.ws)
+        dh.mse_loss(self.img_net, x, self.ga if need_grad else None, self.loss, B * self.Hs * self.Hs, self.c_st, OUT_CP, 1.0, self.ws)
         return self.loss[0], self.reconstruction()
 
     def reconstruction(self):
         out = torch.empty(self.B, self.H, self.W, self.num_ch, dtype=torch.float32, device=self.dev)
-        dh.unpad_channels(self.out_pad, out, self.B * self.H * self.W, self.num_ch, OUT_CP)
+        if self.stack_factor == 1:
+            dh.unpad_channels(self.out_pad, out, self.B * self.H * self.W, self.num_ch, OUT_CP)
+            return out
+        st = torch.empty(self.B * self.Hs * self.Hs, self.c_st, dtype=torch.float32, device=self.dev)
+        dh.unpad_channels(self.out_pad, st, self.B * self.Hs * self.Hs, self.c_st, OUT_CP)
+        dh.depth_to_space_f32(st, out, self.B, self.Hs, self.Hs, self.num_ch, self.stack_factor, self.c_st)
         return out
+
+    # ------------------------------------------------------------------ fp32 tokenising encoder
+    def encode_logits_fp32(self, img):
+        """Encoder + `x @ codebook` entirely in fp32 from the fp32 master weights (dmi_conv2d_f32): the path the reference
+        takes when the VAE tokenises images for DALL-E (src/model_fns.py:43-51 builds it without use_bf16; encoder
+        src/vae_tf/models.py:81-120).  Forward only.  Returns logits [B, g, g, num_tokens] fp32."""
+        B, dev = self.B, self.dev
+        if getattr(self, "_f32", None) is None:
+            mx = max(B * c.Ho * c.Wo * c.cout for c in self.convs[:self.n_enc])
+            self._f32 = dict(x=torch.empty(B * self.Hs * self.Hs, self.img_cp, dtype=torch.float32, device=dev),
+                             a=[torch.empty(mx, dtype=torch.float32, device=dev) for _ in range(3)])
+        f = self._f32
+        dh.space_to_depth_f32(img, f["x"], B, self.Hs, self.Hs, self.num_ch, self.stack_factor, self.img_cp)
+        x, free = f["x"], list(f["a"])
+
+        def conv(c, xin, out, relu=False, residual=None):
+            taps, st = (TAPS4, 2) if c.kind == "down" else (TAPS3, 1)
+            dh.conv2d_f32(xin, B, c.H, c.W, c.cin, c.Ho, c.Wo, st, taps, self.view(self.p, c.name + "/kernel"),
+                          self.view(self.p, c.name + "/bias"), residual, out, c.cout, relu=relu)
+        i = 0
+        while i < self.n_enc:
+            c = self.convs[i]
+            if c.kind == "down":
+                out = free.pop(0)
+                conv(c, x, out)
+                if x is not f["x"]:
+                    free.append(x)
+                x = out
+                i += 1
+            else:
+                h, out = free.pop(0), free.pop(0)
+                conv(c, x, h, relu=True)
+                conv(self.convs[i + 1], h, out, residual=x)
+                free.extend([h, x])
+                x = out
+                i += 2
+        dh.conv2d_f32(x, self.Mg, 1, 1, self.n_hid, 1, 1, 1, [(0, 0)], self.view(self.p, "codebook/codebook"), None, None,
+                      self.logits, self.num_tokens)
+        return self.logits.view(B, self.grid, self.grid, self.num_tokens)
 
     # ------------------------------------------------------------------ backward
     def _gv(self, name):
@@ -456,6 +521,8 @@ class DiscreteVAE:
             elif c.kind == "res":           # c = conv_out of a residual pair (i-1 = conv_in)
                 cin_conv = convs[i - 1]
                 x_in, r = self.act_in[i - 1], self.act_in[i]
+                if self.recompute_grad:      # re-run the branch's first conv into the shared buffer (bit-identical to the forward)
+                    self._conv_fwd(cin_conv, x_in, r, flags=dh.GEMM_RELU)
                 self._wgrad(c, r, d)
                 da = spare[0]
                 self._dgrad3(c, d, da, flags=dh.GEMM_RELU_MASK, relu_src=r)

@@ -203,6 +203,19 @@ int dmi_pixel_interleave(const uint16_t* in4, uint16_t* out, int B, int Ht, int 
 /* fp32 [N, Cin] <-> bf16 [N, Cp] (zero-padded channels): image in, reconstruction out */
 int dmi_pad_channels(const float* in, uint16_t* out, int64_t N, int Cin, int Cp, void* stream);
 int dmi_unpad_channels(const uint16_t* in, float* out, int64_t N, int Cin, int Cp, void* stream);
+/* fp32 convolution of the TOKENISING encoder (the reference builds the VAE without use_bf16 inside dalle_model_fn,
+ * src/model_fns.py:43-51, so image tokens come from fp32 convolutions and an fp32 x @ codebook, src/vae_tf/models.py:81-120):
+ *   out[(b,oy,ox)][n] = sum_t sum_c x[b, oy*stride + dy[t], ox*stride + dx[t], c] * Wk[(t*C + c)][n] + bias[n] (ReLU) (+ residual)
+ * x NHWC fp32 [B,H,W,C] (C % 8 == 0, zero outside the image = SAME padding), Wk fp32 [(ntaps*C), N] = the TF kernel layout
+ * [kh,kw,Cin,Cout], bias / residual nullable, out fp32 [B*Ho*Wo, N], N % 4 == 0.  Exact-fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32).  One tap on a 1x1 image = a plain fp32 matmul (the codebook product). */
+int dmi_conv2d_f32(const float* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps, const int* dy,
+                   const int* dx, const float* Wk, const float* bias, const float* residual, float* out, int N, int relu,
+                   void* stream);
+/* tf.space_to_depth / tf.depth_to_space (NHWC, block s; src/vae_tf/models.py:85-86,158-161) between the image
+ * [B, Hs*s, Ws*s, C] and the stacked layout [B, Hs, Ws, Cp] with channel (dy*s + dx)*C + c, Cp >= s*s*C (pad = 0). */
+int dmi_space_to_depth_f32(const float* img, float* stacked, int B, int Hs, int Ws, int C, int s, int Cp, void* stream);
+int dmi_depth_to_space_f32(const float* stacked, float* img, int B, int Hs, int Ws, int C, int s, int Cp, void* stream);
 /* K13 gumbel_softmax (layers.py:4-21) with INJECTED uniforms u in [1e-9, 1): y = softmax((logits - log(-log u))/T);
  * hard: y = one_hot(argmax) (first max), gradient straight-through.  y, y_soft bf16 [M,T]; index int32 [M] (nullable). */
 int dmi_gumbel_softmax_fwd(const float* logits, const float* u, uint16_t* y, uint16_t* y_soft, int32_t* index,
