@@ -3,15 +3,20 @@
 `dalle_example` transformer step (n_embd=512, 6 layers, 4 heads, seq 256+1024, bf16 compute),
 synthetic captions + synthetic image-token ids, B=32 per GPU (weak scaling), one process per GPU.
 
-A "step" = forward + backward + gradient all-reduce (RCCL, N>1) + global-norm clip + Adam, nothing skipped.
-Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 (contract in the task
+A "step" = forward + backward + gradient all-reduce (RCCL behind the C ABI, N>1) + global-norm clip + Adam, nothing
+skipped.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0 (contract in the task
 statement) with two extra objects:
-  roofline     -- the vocabulary-projection GEMM launch (largest single launch of the step; kernel
-                  gemm_nt_kernel): algorithmic FLOPs 2*M*d*V per launch / mean launch duration measured live
-                  with HIP events on the launch stream inside the timed region, against the 2.5 PFLOP/s dense
-                  bf16 MFMA peak; plus the whole-step MFMA fraction (train FLOPs of SURVEY.md §8(d)).
+  roofline     -- the dominant single launch of the step: for the DALL-E models the vocabulary projection with the fused
+                  softmax epilogue (gemm_nt4_kernel<65>: flags BIAS | SOFTMAX; dispatch `dmi_gemm_nt_softmax`), algorithmic
+                  FLOPs 2*M*d*V per launch / mean launch duration measured live with HIP events on the launch stream inside
+                  the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak; plus the whole-step MFMA fraction
+                  (train FLOPs of SURVEY.md §8(d)).  `traffic` comes from profiles/<round>_traffic_vocab_gemm.json (separate
+                  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of THIS kernel, tools/traffic_summary.py) and is null when
+                  that file does not name the kernel that ran.
   cpu_baseline -- the CPU oracle (a restatement of the reference, NOT mesh-tensorflow, which cannot run
                   here) timed on this host's cores on a bounded sample of the same workload.
+--model vae_example / vae_coco time the discrete-VAE train step (BASELINE.json configs 1 and 4; 32 / 16 images per GPU):
+metric = image tokens/s (images/s x grid^2), roofline = the heaviest convolution launch (implicit-im2col MFMA GEMM).
 """
 import argparse
 import json
@@ -36,9 +41,11 @@ MODELS = {  # --model: the default is BASELINE.json's metric config; "1.3B" is S
     "1.3B": dict(n_embd=2048, n_layers=24, n_heads=16, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256,
                  image_seq_len=1024),
 }
+VAE_MODELS = {"vae_example": 32, "vae_coco": 16}     # per-GPU batch (128 images on 8 GPUs)
 HP = dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0)
 PER_GPU_BATCH = 32
 PEAK_BF16_TFLOPS = 2500.0
+ROUND_TAG = "r02"      # profiles/<ROUND_TAG>_traffic_*.json must come from this round's kernels
 
 
 def fwd_flops_per_token(d, L, S, V):
@@ -83,18 +90,47 @@ def cpu_baseline(budget_s=20.0):
             "note": "CPU restatement of the reference; the mesh-tensorflow reference itself cannot run here"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=PER_GPU_BATCH, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--model", default="dalle_example", choices=sorted(MODELS))
-    args = ap.parse_args()
-    global CFG
-    CFG = MODELS[args.model]
+def cpu_baseline_vae(p, grid, budget_s=15.0):
+    """Oracle VAE train step (fwd + autograd bwd + TF-Adam) on the host cores; a 2-image sample of the same configuration."""
+    from oracle import vae_oracle as vo
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = vo.VaeConfig(num_tokens=p["num_tokens"], dimensions=p["dataset"]["image_size"], convblocks=p["convblocks"])
+    P = vo.init_params(cfg, seed=4321)
+    m = {k: np.zeros_like(v) for k, v in P.items()}
+    v = {k: np.zeros_like(v) for k, v in P.items()}
+    B = 2
+    img = vo.synthetic_images(B, cfg.H, seed=0)
+    u = vo.synthetic_uniforms((B, cfg.grid, cfg.grid, cfg.num_tokens), seed=1)
 
+    def step(t):
+        _, g, _ = vo.loss_and_grads(P, img, u, cfg, hard=True, temp=1.0)
+        vo.tf_adam_step(P, g, m, v, t, p["lr"])
+    step(1)
+    t0, n = time.time(), 0
+    while True:
+        step(2 + n)
+        n += 1
+        if time.time() - t0 > budget_s or n >= 8:
+            break
+    dt = (time.time() - t0) / n
+    return {"value": B * grid * grid / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of {B} images (fp32 PyTorch-CPU oracle, {cores} threads), {dt:.2f} s/step",
+            "note": "CPU restatement of the reference; tensorflow itself cannot run here"}
+
+
+def load_traffic(name, kernel_substr):
+    """bytes/launch from this round's PMC passes, or None when absent / measured on another kernel"""
+    path = os.path.join(ROOT, "profiles", f"{ROUND_TAG}_traffic_{name}.json")
+    if not os.path.exists(path):
+        return None, None
+    rec = json.load(open(path))
+    if kernel_substr not in rec.get("kernel", ""):
+        return None, None
+    return rec.get("traffic_bytes"), os.path.relpath(path, ROOT)
+
+
+def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,28 +141,129 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"), __file__] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    # DALLE_BENCH_SHARE_GPU=1 (tests only): all ranks share cuda:0 and use gloo, to exercise the N>1 code path on a
-    # 1-GPU box; the driver's multi-GPU runs use one GPU per rank over RCCL (backend "nccl").
+    # DALLE_BENCH_SHARE_GPU=1 (tests only): all ranks share cuda:0 and exchange over gloo, to exercise the N>1 code path on a
+    # 1-GPU box; the driver's multi-GPU runs use one GPU per rank and RCCL behind the C ABI (src/dp.py).
     share = os.environ.get("DALLE_BENCH_SHARE_GPU") == "1"
     torch.cuda.set_device(0 if share else local_rank)
-    pg = None
+    pg = comm = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        pg = dist.group.WORLD
+        from src import dp
+        pg = dp.init_process_group(local_rank)
+        _, _, pg, comm = dp.dist_setup()
+    return world, rank, pg, comm
 
+
+def bench_vae(args, world, rank, pg, comm):
+    from src.vae_tf import DiscreteVAE
+    p = json.load(open(os.path.join(ROOT, "configs", args.model + ".json")))
+    B = args.batch or VAE_MODELS[args.model]
+    vae = DiscreteVAE(num_tokens=p["num_tokens"], dimensions=p["dataset"]["image_size"], convblocks=p["convblocks"],
+                      dim=p.get("dim") or 512, hidden_dim=p.get("hidden_dim") or 64, input_channels=p.get("n_channels") or 3,
+                      use_bf16=bool(p.get("use_bf16")), recompute_grad=bool(p.get("recompute_grad")),
+                      stack_factor=p.get("stack_factor") or 1, batch_size=B, mode="train", process_group=pg, world_size=world,
+                      comm=comm)
+    vae.init_params()
+    if world > 1:
+        vae.reducer.broadcast(vae.p)
+        vae.refresh_compute_copies(cast=True)
+    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    imgs = [(torch.randint(0, 256, (B, vae.H, vae.W, vae.num_ch), device="cuda", generator=g).float() - 127.5) / 127.5 for _ in range(4)]
+    hard = bool(p.get("train_gumbel_hard", True))
+    # the heaviest convolution launch of the forward pass (most flops among the implicit-GEMM layers)
+    heavy = max((c for c in vae.convs if c.kind in ("down", "res") and vae._implicit_ok(c)),
+                key=lambda c: c.Ho * c.Wo * c.cout * c.kk * c.cin, default=None)
+    evs = []
+    vae.event_hook = (heavy.name, evs) if heavy is not None else None
+
+    def step(i):
+        vae.forward(imgs[i % 4], return_recon_loss=True, hard_gumbel=hard, temperature=1.0)
+        vae.backward()
+        vae.optimizer_step(p["lr"])
+    import torch.distributed as dist
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    evs.clear()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    loss = float(vae.loss.item())
+    if world > 1:
+        tmax = torch.tensor([dt])
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    ms = dt / args.steps * 1e3
+    g2 = vae.grid ** 2
+    fl_img = 0
+    for c in vae.convs:   # 2*Hout*Wout*Cout*K*K*Cin per conv (transpose conv: input-sized), reference channel counts
+        hw = c.Ho * c.Wo if c.kind != "up" else c.H * c.W
+        fl_img += 2 * hw * c.cout_ref * c.kk * c.cin_ref
+    fl_img += 2 * 2 * g2 * vae.n_hid * vae.num_tokens
+    train_fl = 3 * fl_img * B
+    k_ms = [a.elapsed_time(b) for a, b in evs]
+    k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
+    roof = None
+    if heavy is not None and k_ms:
+        kfl = 2.0 * B * heavy.Ho * heavy.Wo * heavy.cout * heavy.kk * heavy.cin
+        ach = kfl / (k_avg * 1e-3) / 1e12
+        traffic, tsrc = load_traffic(f"{args.model}_conv", "conv_gemm_nt_kernel")
+        roof = {"bound": "mfma", "kernel": f"conv_gemm_nt_kernel ({heavy.name}: implicit-im2col GEMM M={B * heavy.Ho * heavy.Wo}, "
+                                           f"N={heavy.cout}, K={heavy.kk * heavy.cin})",
+                "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": traffic,
+                "traffic_source": tsrc, "launch_ms": k_avg, "launches_timed": len(k_ms),
+                "step_mfma_frac": train_fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
+                "step_tflops_per_gpu": train_fl / (ms * 1e-3) / 1e12}
+    out = {"metric": f"train image tokens/sec per node, {args.model}", "value": B * world * g2 * args.steps / dt, "unit": "tokens/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"configs/{args.model}.json discrete-VAE train step ({vae.H}x{vae.W} images, convblocks "
+                                  f"{p['convblocks']}, {vae.num_tokens} tokens, grid {vae.grid}x{vae.grid}), synthetic images",
+                      "global_batch": B * world, "per_gpu_batch": B, "images_per_s": B * world * args.steps / dt,
+                      "parallelism": f"dp{world}", "dp_transport": vae.reducer.transport if world > 1 else None,
+                      "final_loss": loss},
+           "roofline": roof}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_vae(p, vae.grid)
+    print(json.dumps(out), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); default: the model's BASELINE value")
+    ap.add_argument("--model", default="dalle_example", choices=sorted(MODELS) + sorted(VAE_MODELS))
+    args = ap.parse_args()
+    world, rank, pg, comm = setup_dist(args)
+    if args.model in VAE_MODELS:
+        bench_vae(args, world, rank, pg, comm)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+    global CFG
+    CFG = MODELS[args.model]
+    import torch.distributed as dist
     from src.dalle_mtf.engine import DalleEngine
-    B = args.batch
+    B = args.batch or PER_GPU_BATCH
     eng = DalleEngine(CFG["n_embd"], CFG["n_layers"], CFG["n_heads"], CFG["text_vocab_size"], CFG["image_vocab_size"],
                       CFG["text_seq_len"], CFG["image_seq_len"], batch_size=B, global_batch_size=B * world, hparams=HP,
-                      process_group=pg, world_size=world)
+                      process_group=pg, world_size=world, comm=comm)
     eng.init_params(seed=1234)
     if world > 1:
-        dist.broadcast(eng.p, src=0)
+        eng.reducer.broadcast(eng.p)
         eng.refresh_compute_copies(cast=True)
     S, T, P = eng.S, eng.T, eng.S - eng.T
     batches = [torch.from_numpy(synth_tokens(B, T, P, CFG["text_vocab_size"], CFG["image_vocab_size"], 1000 * rank + i)).cuda()
@@ -151,8 +288,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loss = float(eng.loss.item())
+    schedule = list(eng.reducer.last_log)
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda")
+        tmax = torch.tensor([dt])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -165,10 +303,11 @@ def main():
         k_ms = [a.elapsed_time(b) for a, b in evs]
         k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
         achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
-        traffic = None  # HBM bytes per launch of the same kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
-        tpath = os.path.join(ROOT, "profiles", "r01h_traffic_vocab_gemm.json")
-        if os.path.exists(tpath) and B == PER_GPU_BATCH and args.model == "dalle_example":
-            traffic = json.load(open(tpath)).get("traffic_bytes")
+        # 256x128 tiles when the grid covers >= 3 residencies and K <= 1024 (csrc/gemm.hip launch_nt), else 128x128
+        tiles4 = ((B * S + 255) // 256) * ((eng.Vp + 127) // 128)
+        kname = "gemm_nt4_kernel<65>" if (tiles4 >= 1536 and d <= 1024) else "gemm_nt2_kernel<65>"
+        traffic, tsrc = (load_traffic("vocab_gemm", kname) if (B == PER_GPU_BATCH and args.model == "dalle_example") else (None, None))
+        algo_bytes = (B * S * d + eng.Vp * d) * 2 + B * S * eng.Vp * 2 + (eng.Vp // 64) * B * S * 4
         out = {
             "metric": f"train tokens/sec (text+image) per node, {args.model}", "value": tokens_per_s, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -176,11 +315,16 @@ def main():
             "config": {"workload": f"configs/{args.model if args.model != '1.3B' else 'dalle_example (1.3B dimensions, SURVEY §8(d) C5)'}.json transformer train step (n_embd={d}, {L} layers, "
                                    f"{CFG['n_heads']} heads, seq 256+1024, V={V}), synthetic captions + synthetic image-token ids",
                        "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
+                       "dp_transport": eng.reducer.transport if world > 1 else None,
+                       "dp_pieces_per_step": len(schedule) if world > 1 else None,
+                       "dp_largest_piece_MB": (max(b - a for a, b in schedule) * 4 / 2 ** 20) if (world > 1 and schedule) else None,
                        "final_loss": loss},
-            "roofline": {"bound": "mfma", "kernel": f"gemm_nt_kernel (vocabulary projection M=B*S, N={eng.Vp}, K={d})",
+            "roofline": {"bound": "mfma",
+                         "kernel": f"{kname} (vocabulary projection with the softmax-numerator epilogue, dmi_gemm_nt_softmax: M=B*S={B * S}, N={eng.Vp}, K={d})",
                          "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_BF16_TFLOPS if k_ms else None, "traffic": traffic,
-                         "traffic_unit": "bytes/launch (PMC, profiles/r01h_traffic_vocab_gemm.json: FETCH_SIZE x2 + WRITE_SIZE, L2-side counters incl. Infinity-Cache hits; algorithmic 4.26e9)",
+                         "traffic_source": tsrc, "algorithmic_bytes": algo_bytes,
+                         "traffic_unit": "bytes/launch (PMC: FETCH_SIZE x2 + WRITE_SIZE, L2-side counters incl. Infinity-Cache hits)",
                          "launch_ms": k_avg, "launches_timed": len(k_ms),
                          "step_mfma_frac": train_flops_step_gpu / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "step_tflops_per_gpu": train_flops_step_gpu / (ms * 1e-3) / 1e12},

@@ -96,6 +96,13 @@ def _declare(L):
         "dmi_mse_workspace_bytes": (L64, []),
         "dmi_mse_loss": (I, [P, P, P, P, L64, I, I, F, P, P]),
         "dmi_add_f32": (I, [P, P, L64, P]),
+        "dmi_comm_load": (I, [c_char_p]),
+        "dmi_comm_unique_id_bytes": (I, []),
+        "dmi_comm_unique_id": (I, [P]),
+        "dmi_comm_init": (I, [P, I, I, P]),
+        "dmi_comm_destroy": (I, [P]),
+        "dmi_allreduce_bucket": (I, [P, P, L64, P]),
+        "dmi_comm_broadcast_f32": (I, [P, P, L64, I, P]),
         "dmi_conv2d_f32": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, I, I, P]),
         "dmi_space_to_depth_f32": (I, [P, P, I, I, I, I, I, I, P]),
         "dmi_depth_to_space_f32": (I, [P, P, I, I, I, I, I, I, P]),
@@ -406,3 +413,43 @@ def space_to_depth_f32(img, stacked, B, Hs, Ws, C, s, Cp):
 def depth_to_space_f32(stacked, img, B, Hs, Ws, C, s, Cp):
     _dev(stacked, img)
     _check(lib().dmi_depth_to_space_f32(_p(stacked), _p(img), B, Hs, Ws, C, s, Cp, _stream()), "depth_to_space_f32")
+
+
+# ------------------------------------------------------------------ data-parallel exchange (RCCL behind the C ABI)
+
+def comm_load():
+    """bind the librccl this process already maps (PyTorch-ROCm ships its own copy) or the system one."""
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    path = os.environ.get("DALLE_RCCL_LIB") or (cand if os.path.exists(cand) else "")
+    _check(lib().dmi_comm_load(path.encode()), "comm_load")
+
+
+def comm_unique_id() -> bytes:
+    comm_load()
+    buf = ctypes.create_string_buffer(lib().dmi_comm_unique_id_bytes())
+    _check(lib().dmi_comm_unique_id(ctypes.cast(buf, c_void_p)), "comm_unique_id")
+    return buf.raw
+
+
+def comm_init(nranks: int, rank: int, unique_id: bytes) -> int:
+    """blocking collective; returns the opaque communicator handle (int)."""
+    comm_load()
+    out = c_void_p()
+    buf = ctypes.create_string_buffer(unique_id, len(unique_id))
+    _check(lib().dmi_comm_init(ctypes.byref(out), nranks, rank, ctypes.cast(buf, c_void_p)), "comm_init")
+    return out.value
+
+
+def comm_destroy(comm):
+    if comm:
+        _check(lib().dmi_comm_destroy(c_void_p(comm)), "comm_destroy")
+
+
+def allreduce_bucket(comm, g, n, stream=None):
+    _dev(g)
+    _check(lib().dmi_allreduce_bucket(c_void_p(comm), _p(g), n, _stream() if stream is None else stream), "allreduce_bucket")
+
+
+def comm_broadcast_f32(comm, buf, n, root=0, stream=None):
+    _dev(buf)
+    _check(lib().dmi_comm_broadcast_f32(c_void_p(comm), _p(buf), n, root, _stream() if stream is None else stream), "comm_broadcast")

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 LIB = os.path.join(HERE, "libdalle_hip.so")
-SOURCES = ["elementwise.hip", "gemm.hip", "attention.hip", "vae.hip"]
+SOURCES = ["elementwise.hip", "gemm.hip", "attention.hip", "vae.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
 
 
@@ -56,7 +56,7 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out)
             raise RuntimeError(f"hipcc failed for {src}")
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print("[dalle_hip.build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

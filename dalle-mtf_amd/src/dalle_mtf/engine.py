@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 import dalle_hip as dh
+from ..dp import GradReducer
 
 HEAD_DIM = 128
 ALIGN = 128  # elements
@@ -81,6 +82,10 @@ class ParamLayout:
             nxt = f"layer_{i-1}/mlp/mlp_linear_2/kernel" if i > 0 else "positional_embedding/wpe"
             self.bucket_ends.append(self.offset[nxt])
         self.bucket_ends.append(self.total)
+        # offsets at which backward has finished a prefix of the flat gradient buffer, in completion order: the head's
+        # kernel + bias (right after its weight-gradient GEMM, before the input gradient), each layer (the head LayerNorm's
+        # gain / bias ride with layer L-1), finally the embeddings.  The exchange pieces follow these cuts (src/dp.py).
+        self.ready_points: List[int] = [self.offset["to_logits/layer_norm/g"]] + self.bucket_ends[1:]
 
     def numel(self, name):
         return int(np.prod(self.shape[name]))
@@ -89,7 +94,7 @@ class ParamLayout:
 class DalleEngine:
     def __init__(self, n_embd, n_layers, n_heads, text_vocab_size, image_vocab_size, text_seq_len, image_seq_len,
                  batch_size, global_batch_size=None, eos_token_id=None, hparams: Optional[dict] = None,
-                 device="cuda", process_group=None, world_size=1):
+                 device="cuda", process_group=None, world_size=1, comm=None):
         if not torch.cuda.is_available():
             raise dh.DalleHipError("DalleEngine needs a HIP device (MI355X); there is no CPU fallback")
         dh.lib()
@@ -122,7 +127,8 @@ class DalleEngine:
         self.pbt = torch.zeros(self.lay.t_total, **b16)
         self.global_step = 0
         self._alloc_activations()
-        self._pending = []  # async all-reduce handles
+        # gradient exchange: RCCL behind the C ABI when `comm` (dp.init_comm) is given, torch.distributed otherwise
+        self.reducer = GradReducer(self.g, world_size, comm=comm, pg=process_group)
 
     # ------------------------------------------------------------------ parameter access
     def view(self, buf, name):
@@ -337,36 +343,29 @@ class DalleEngine:
     def _gv(self, name):
         return self.view(self.g, name)
 
-    def _allreduce_bucket(self, idx):
-        if self.world <= 1:
-            return
-        import torch.distributed as dist
-        lo = 0 if idx == 0 else self.lay.bucket_ends[idx - 1]
-        hi = self.lay.bucket_ends[idx]
-        self._pending.append(dist.all_reduce(self.g[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-
     def _wgrad(self, X, ldx, dY, ldy, dW, M, I, J, dbias=None, bias_weights=None):
         """dW = X^T dY (+ fused bias gradient)."""
         dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws, dbias=dbias, bias_weights=bias_weights)
 
     def backward(self, allreduce=True):
-        """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  With world_size > 1 each finished
-        bucket is all-reduced (SUM) asynchronously, one layer behind the compute -- the explicit form of mtf's implicit
-        all-reduce over the `data` mesh axis (src/model_fns.py:81-82,189)."""
+        """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  With world_size > 1 every finished
+        prefix of the buffer is handed to the exchange (src/dp.py: SUM all-reduce in <= 64 MB pieces on the side stream) --
+        the explicit form of mtf's implicit all-reduce over the `data` mesh axis (src/model_fns.py:81-82,189)."""
         M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
         ws = self.ws
         E = self.z   # unnormalised dlogits: dlogits[m, :] = rowscale[m] * E[m, :]
-        pending_bucket = []
+        rp = self.lay.ready_points
+        done = [0]
 
-        def flush_buckets(keep_last):
-            while len(pending_bucket) > (1 if keep_last else 0):
-                idx = pending_bucket.pop(0)
-                if self.world > 1 and allreduce:
-                    self._allreduce_bucket(idx)
+        def ready(upto):   # g[done, upto) is final on this stream: hand it to the exchange
+            if allreduce:
+                self.reducer.ready(done[0], upto)
+            done[0] = upto
 
         # head: dW = (rowscale * xnf)^T E, dbias = rowscale^T E, dxn = rowscale * (E W^T)
         self._wgrad(self.xs, d, E, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
                     dbias=self._gv("to_logits/linear_out/bias"), bias_weights=self.rowscale_bf)
+        ready(rp[0])
         # K = vocabulary: main-loop-bound -> 256x256 tiles, one 8-wave block per CU (the library picks that kernel for long-K
         # launches that fill whole residencies of the 256 CUs).  The rows of the whole residencies run unsplit; the rows of the
         # ragged last residency run with K split so that they also fill the chip (fp32 slabs, deterministic reduce).
@@ -386,7 +385,6 @@ class DalleEngine:
         dxa, dxb = self.dx
         dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                          self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)
-        pending_bucket.append(0)
         for bi, l in enumerate(reversed(range(L))):
             p = f"layer_{l}/"
             st = self.stats[l]
@@ -409,20 +407,16 @@ class DalleEngine:
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
             dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
                              self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"), ws, M, d)
-            pending_bucket.append(1 + bi)
-            flush_buckets(keep_last=True)   # all-reduce the PREVIOUS bucket
+            ready(rp[1 + bi])
         # embeddings: positions visited in token-id order (sorted on the side stream during the forward)
         if self._sort_done is not None:
             torch.cuda.current_stream().wait_event(self._sort_done)
         dh.embed_bwd(self.tok_sorted, self.tok_perm, dxa, self._gv("embedding/wte"), self._gv("positional_embedding/wpe"),
                      B, S, d, self.V, self.embed_ws)
-        pending_bucket.append(L + 1)
-        flush_buckets(keep_last=False)
+        ready(rp[L + 1])
 
     def wait_grads(self):
-        for h in self._pending:
-            h.wait()
-        self._pending = []
+        self.reducer.finish()
 
     # ------------------------------------------------------------------ optimizer
     def learning_rate(self, step=None) -> float:
@@ -500,8 +494,7 @@ class DalleEngine:
             else:
                 dh.add_f32(self.gacc, self.g, self.lay.total)
         self.g.copy_(self.gacc)
-        for idx in range(len(self.lay.bucket_ends)):
-            self._allreduce_bucket(idx)
+        self.reducer.ready(0, self.lay.total)
         self.optimizer_step()
         return self.loss_acc
 

@@ -12,7 +12,7 @@ class DALLE:
     def __init__(self, n_embd, text_vocab_size=12800, image_vocab_size=512, text_seq_len=256, image_seq_len=1024,
                  n_layers=6, n_heads=8, batch_size=32, bf_16=True, attn_mask=None, mode="train",
                  is_incremental_inference=False, context=None, loss_fn=None, params=None, eos_token_id=None,
-                 activation_fn=None, device="cuda", process_group=None, world_size=1, global_batch_size=None):
+                 activation_fn=None, device="cuda", process_group=None, world_size=1, global_batch_size=None, comm=None):
         self.n_embd = n_embd
         self.text_vocab_size = text_vocab_size
         self.image_vocab_size = image_vocab_size
@@ -43,7 +43,7 @@ class DALLE:
         self.engine = DalleEngine(n_embd, n_layers, n_heads, text_vocab_size, image_vocab_size, text_seq_len,
                                   image_seq_len, batch_size, global_batch_size=global_batch_size,
                                   eos_token_id=eos_token_id, hparams=dict(self.params), device=device,
-                                  process_group=process_group, world_size=world_size)
+                                  process_group=process_group, world_size=world_size, comm=comm)
         self.dimensions = {"embed_dim": n_embd, "final_vocab_dim": self.total_tokens, "total_seq_dim": self.total_seq_dim,
                            "heads_dim": n_heads, "kv_dim": n_embd // n_heads, "batch_dim": batch_size}
 

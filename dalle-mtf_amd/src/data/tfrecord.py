@@ -56,7 +56,7 @@ def write_records(path: str, records: List[bytes]):
             f.write(struct.pack("<I", masked_crc32c(data)))
 
 
-def read_records(path: str, verify_crc: bool = False) -> Iterator[bytes]:
+def read_records(path: str, verify_crc: bool = True) -> Iterator[bytes]:
     with open(path, "rb") as f:
         while True:
             hdr = f.read(8)

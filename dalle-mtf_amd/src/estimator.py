@@ -43,7 +43,10 @@ class CheckpointSaverHook:
         self.max_to_keep, self.is_chief = max_to_keep, is_chief
 
     def save(self, step):
-        if not self.is_chief or not self.model_dir:
+        if not self.model_dir:
+            return
+        if not self.is_chief:
+            self._sync()
             return
         os.makedirs(self.model_dir, exist_ok=True)
         path = os.path.join(self.model_dir, f"model.ckpt-{step}.pt")
@@ -53,6 +56,12 @@ class CheckpointSaverHook:
                     key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
         for old in ck[:-self.max_to_keep] if self.max_to_keep else []:
             os.remove(old)
+        self._sync()
+
+    def _sync(self):
+        """every rank leaves save() only after the chief's file is complete (readers: evaluate(), resume)"""
+        from .dp import barrier
+        barrier()
 
     def after_step(self, step):
         if self.save_steps and step % self.save_steps == 0:
@@ -63,13 +72,20 @@ class Estimator:
     def __init__(self, model_fn, model_dir, params, log_every=100, logger=None):
         self.model_fn, self.model_dir, self.params = model_fn, model_dir, params
         self.log_every, self.logger = log_every, logger
+        self._train_it = None     # ONE input stream for the life of the estimator: train() is called once per
+                                  # steps_per_checkpoint segment when eval_steps > 0 and must not replay the stream's head
 
     def _log(self, msg):
         (self.logger.info if self.logger else print)(msg)
 
     def train(self, input_fn, max_steps):
         params = self.params
-        it = iter(input_fn(params))
+        if self._train_it is None:
+            # a resumed run continues a different stream than the one that produced the checkpoint: the start step salts
+            # the shuffle seeds (the reference's tf.data shuffle is unseeded and never replays either)
+            params["_input_start_step"] = load_global_step_from_checkpoint_dir(self.model_dir)
+            self._train_it = iter(input_fn(params))
+        it = self._train_it
         t0, n0 = time.time(), None
         spec = None
         while True:
@@ -91,9 +107,12 @@ class Estimator:
         for hk in spec.training_hooks or []:
             if isinstance(hk, CheckpointSaverHook):
                 hk.save(step)
-        if hasattr(it, "close"):
-            it.close()
         return step
+
+    def close(self):
+        if self._train_it is not None and hasattr(self._train_it, "close"):
+            self._train_it.close()
+        self._train_it = None
 
     def evaluate(self, input_fn, steps):
         it = iter(input_fn(self.params))

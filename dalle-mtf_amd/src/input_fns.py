@@ -90,7 +90,23 @@ def _synthetic_captions(rng, B, T, pad):
 
 
 def _is_synthetic(path):
-    return (not path) or str(path).startswith("synthetic") or str(path).startswith("gs://")
+    """only an explicit 'synthetic...' path selects the seeded synthetic batches; an empty path or a gs:// URL carried over
+    from a reference config is an error, not silent noise training (there is no GCS access here)"""
+    p = str(path or "")
+    if p.startswith("synthetic"):
+        return True
+    if not p or p.startswith("gs://"):
+        raise ValueError(f"dataset path {path!r}: use a local glob of *.tfrecords / image files, or 'synthetic' for seeded "
+                         "synthetic batches (gs:// buckets are not reachable from this build)")
+    return False
+
+
+def _stream_seed(params, base, eval):
+    """seed of a training stream: salted with the data-parallel rank (ranks must not draw identical synthetic batches) and
+    with the step the run (re)started from (a resumed run must not replay the stream's head)"""
+    if eval:
+        return base
+    return base + 7919 * int(params.get("dp_rank", 0)) + 104729 * int(params.get("_input_start_step", 0))
 
 
 def _batch_size(params, eval):
@@ -236,7 +252,7 @@ def _synthetic_dalle(params, eval):
     B = _batch_size(params, eval)
     size, ch = ds["image_size"], params.get("n_channels") or 3
     pad = params["padding_id"] if params.get("padding_id") is not None else params["text_vocab_size"] - 1
-    rng = np.random.default_rng(1 if not eval else 101)
+    rng = np.random.default_rng(_stream_seed(params, 1, eval) if not eval else 101)
     while True:
         img = rng.integers(0, 256, size=(B, size, size, ch), dtype=np.uint8)
         img = (img.astype(np.float32) - 127.5) / 127.5
@@ -247,7 +263,7 @@ def _synthetic_vae(params, eval):
     ds = params["dataset"]
     B = _batch_size(params, eval)
     size, ch = ds["image_size"], params.get("n_channels") or 3
-    rng = np.random.default_rng(0 if not eval else 100)
+    rng = np.random.default_rng(_stream_seed(params, 0, eval) if not eval else 100)
     while True:
         img = rng.integers(0, 256, size=(B, size, size, ch), dtype=np.uint8)
         img = torch.from_numpy((img.astype(np.float32) - 127.5) / 127.5)
@@ -267,8 +283,9 @@ def dalle_input_fn(params, eval=False):
     seed = int(params.get("input_seed", 0))
     files = _file_order(files, eval, seed)
     B = _batch_size(params, eval)
+    sseed = seed + 1 + 104729 * int(params.get("_input_start_step", 0) if not eval else 0)
     return _Prefetch(lambda: _interleave_records(files, 4), read_labeled_tfrecord(params), B,
-                     0 if eval else B * 5, seed + 1, shard=_dp_shard(params))
+                     0 if eval else B * 5, sseed, shard=_dp_shard(params))
 
 
 def vae_input_fn(params, eval=False):
@@ -284,12 +301,13 @@ def vae_input_fn(params, eval=False):
     files = _file_order(files, eval, seed)
     B = _batch_size(params, eval)
     size = ds["image_size"]
+    sseed = seed + 1 + 104729 * int(params.get("_input_start_step", 0) if not eval else 0)
     if ds.get("tfrecords"):
         return _Prefetch(lambda: _interleave_records(files, 4), read_tfrecord(params), B,
-                         0 if eval else B * 5, seed + 1, shard=_dp_shard(params))
+                         0 if eval else B * 5, sseed, shard=_dp_shard(params))
 
     def _process_path(file_path):          # input_fns.py:92-96 (decode_img with its default 3 channels)
         with open(file_path, "rb") as f:
             img = decode_img(f.read(), size)
         return img, img
-    return _Prefetch(lambda: iter(files), _process_path, B, 0 if eval else B * 5, seed + 1, shard=_dp_shard(params))
+    return _Prefetch(lambda: iter(files), _process_path, B, 0 if eval else B * 5, sseed, shard=_dp_shard(params))

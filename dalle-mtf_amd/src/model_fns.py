@@ -18,10 +18,8 @@ from .utils import ModeKeys, create_host_call, get_graph_info, mode_to_str, pars
 
 
 def _dist_info():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size(), dist.get_rank(), dist.group.WORLD
-    return 1, 0, None
+    from .dp import dist_setup
+    return dist_setup()    # (world, rank, process group, RCCL communicator behind the C ABI or None)
 
 
 def load_vae_model(params, mode_str):
@@ -44,7 +42,7 @@ def load_vae_model(params, mode_str):
         convblocks=vae_params.get("convblocks") or [(3, 64), (3, 128), (3, 256)],
         stack_factor=vae_params.get("stack_factor") or 1,
         dimensions=D,
-        batch_size=params[f"{mode_str}_batch_size"] // max(_dist_info()[0], 1),
+        batch_size=params.get("_tokenizer_batch") or params[f"{mode_str}_batch_size"] // max(_dist_info()[0], 1),
         mode="eval")
     # the reference does not forward use_bf16 here, so its tokenising encoder is fp32: same here unless switched off
     vae_model.fp32_tokens = bool(params.get("vae_tokens_fp32", True))
@@ -70,7 +68,7 @@ def serialize_num_microbatches(batch_per_replica, sequence_length, tokens_per_mi
 
 
 def _build(params, mode_str):
-    world, rank, pg = _dist_info()
+    world, rank, pg, comm = _dist_info()
     mesh = parse_mesh_shape(params.get("mesh_shape"))
     gbs = params[f"{mode_str}_batch_size"]
     assert gbs % world == 0, f"{mode_str}_batch_size {gbs} must divide over {world} data-parallel ranks"
@@ -94,7 +92,7 @@ def _build(params, mode_str):
                   image_vocab_size=params["image_vocab_size"], text_seq_len=params["text_seq_len"],
                   image_seq_len=image_seq_len, n_layers=params["n_layers"], n_heads=params["n_heads"],
                   batch_size=local_bs // nmb, bf_16=params["bf_16"], mode=mode_str, params=params,
-                  process_group=pg, world_size=world, global_batch_size=gbs // nmb)
+                  process_group=pg, world_size=world, global_batch_size=gbs // nmb, comm=comm)
     eng = model.engine
     eng.hp["num_microbatches"] = nmb   # reference model_fns.py:141-154 (1 when tokens_per_mb_per_replica is unset)
     params["num_microbatches"] = nmb
@@ -105,8 +103,13 @@ def _build(params, mode_str):
     else:
         eng.init_params(seed=params.get("seed") or 1234)
     if world > 1:
+        # every rank starts from rank 0's weights, Adam state AND step (the LR schedule and the loop length depend on it)
         import torch.distributed as dist
-        dist.broadcast(eng.p, src=0, group=pg)
+        for buf in (eng.p, eng.m, eng.v):
+            eng.reducer.broadcast(buf, root=0)
+        box = [eng.global_step]
+        dist.broadcast_object_list(box, src=0, group=pg)
+        eng.global_step = int(box[0])
         eng.refresh_compute_copies(cast=True)
     lr_fn, update_op = get_optimizer(eng, params)
     if rank == 0:
@@ -125,13 +128,28 @@ def dalle_model_fn(features, labels, mode, params):
     assert mode in (ModeKeys.TRAIN, ModeKeys.EVAL)
     key = f"_dalle_state_{mode_str}"
     if params.get(key) is None:
-        if mode == ModeKeys.EVAL and params.get("_dalle_state_train") is not None and \
-                params["eval_batch_size"] == params["train_batch_size"]:
-            params[key] = params["_dalle_state_train"]
+        tr = params.get("_dalle_state_train")
+        if mode == ModeKeys.EVAL and tr is not None and \
+                (params["eval_batch_size"] // max(tr["world"], 1)) % tr["model"].engine.B == 0:
+            params[key] = tr       # evaluated in engine-sized chunks below: no second engine, never stale
         else:
             params[key] = _build(params, mode_str)
     st = params[key]
     model, eng = st["model"], st["model"].engine
+    if mode == ModeKeys.EVAL and st is not params.get("_dalle_state_train"):
+        # a separately built eval engine scores the CURRENT weights: copied from the train engine when there is one, reloaded
+        # from the newest checkpoint otherwise (CheckpointSaverHook.save ends with a barrier, so the file is complete)
+        tr = params.get("_dalle_state_train")
+        if tr is not None:
+            if st.get("_synced_step") != tr["model"].engine.global_step:
+                eng.p.copy_(tr["model"].engine.p)
+                eng.refresh_compute_copies(cast=True)
+                st["_synced_step"] = tr["model"].engine.global_step
+        else:
+            ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
+            if ck is not None and st.get("_synced_ckpt") != ck:
+                eng.load_state_dict(torch.load(ck, map_location="cpu")["dalle"])
+                st["_synced_ckpt"] = ck
     model.mode = mode_str
     dev = eng.dev
     nmb = eng.hp.get("num_microbatches", 1) if mode == ModeKeys.TRAIN else 1
@@ -143,8 +161,13 @@ def dalle_model_fn(features, labels, mode, params):
     tokens = torch.empty(B, T + P, dtype=torch.int32, device=dev)
     if st["vae"] is not None:
         # tokens = argmax(vae_logits, -1) (model_fns.py:72-77); + text_vocab_size; concat (model_fns.py:118-119)
-        vae_logits = st["vae"].forward(features.to(dev), return_logits=True)           # [B,g,g,T] fp32
-        dh.assemble_tokens(text, vae_logits.contiguous(), tokens, B, T, P, vae_logits.shape[-1], eng.text_vocab_size)
+        vae = st["vae"]
+        feats = (features["inputs"] if isinstance(features, dict) else features).to(dev)
+        assert B % vae.B == 0, f"{B} images for a tokenizer batch of {vae.B}"
+        for c0 in range(0, B, vae.B):   # the tokenizer is sized for one engine batch
+            vae_logits = vae.forward(feats[c0:c0 + vae.B], return_logits=True)        # [b,g,g,T] fp32
+            dh.assemble_tokens(text[c0:c0 + vae.B], vae_logits.contiguous(), tokens[c0:c0 + vae.B], vae.B, T, P,
+                               vae_logits.shape[-1], eng.text_vocab_size)
     else:
         img = features["image_tokens"] if isinstance(features, dict) else features
         tokens[:, :T] = text
@@ -161,7 +184,7 @@ def dalle_model_fn(features, labels, mode, params):
         scalar_summary("loss", eng.loss_acc[0])
         scalar_summary("lr", st["lr_fn"]())
         return EstimatorSpec(mode=mode, loss=eng.loss_acc[0], train_op=train_op_mb,
-                             host_call=create_host_call(params["model_path"]) if params.get("model_path") else None,
+                             host_call=create_host_call(params["model_path"]) if (params.get("model_path") and st["rank"] == 0) else None,
                              training_hooks=[st["saver"]])
     if mode == ModeKeys.EVAL:
         # the engine may have been sized for one training micro-batch: evaluate the batch in engine-sized chunks (equal
@@ -180,4 +203,4 @@ def dalle_model_fn(features, labels, mode, params):
         st["update_op"]()
         return eng.global_step
     return EstimatorSpec(mode=mode, loss=loss, train_op=train_op, host_call=create_host_call(params["model_path"])
-                         if params.get("model_path") else None, training_hooks=[st["saver"]])
+                         if (params.get("model_path") and st["rank"] == 0) else None, training_hooks=[st["saver"]])

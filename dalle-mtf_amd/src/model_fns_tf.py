@@ -10,10 +10,8 @@ from .vae_tf import DiscreteVAE
 
 
 def _dist_info():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_world_size(), dist.get_rank(), dist.group.WORLD
-    return 1, 0, None
+    from .dp import dist_setup
+    return dist_setup()    # (world, rank, process group, RCCL communicator behind the C ABI or None)
 
 
 def temperature_schedule(step, params):
@@ -26,7 +24,7 @@ def temperature_schedule(step, params):
 
 
 def _build(params, mode_str):
-    world, rank, pg = _dist_info()
+    world, rank, pg, comm = _dist_info()
     H = params["dataset"]["image_size"]
     gbs = params[f"{mode_str}_batch_size"]
     assert gbs % world == 0
@@ -40,7 +38,7 @@ def _build(params, mode_str):
         recompute_grad=params.get("recompute_grad") or False,
         use_bf16=params.get("use_bf16") or False,
         stack_factor=params.get("stack_factor") or 1,
-        dimensions=H, batch_size=gbs // world, mode=mode_str, process_group=pg, world_size=world)
+        dimensions=H, batch_size=gbs // world, mode=mode_str, process_group=pg, world_size=world, comm=comm)
     ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
     if ck is not None:
         model.load_state_dict(torch.load(ck, map_location="cpu"))
@@ -48,7 +46,11 @@ def _build(params, mode_str):
         model.init_params(seed=params.get("seed") or 4321)
     if world > 1:
         import torch.distributed as dist
-        dist.broadcast(model.p, src=0, group=pg)
+        for buf in (model.p, model.m, model.v):
+            model.reducer.broadcast(buf, root=0)
+        box = [model.global_step]
+        dist.broadcast_object_list(box, src=0, group=pg)
+        model.global_step = int(box[0])
         model.refresh_compute_copies(cast=True)
     saver = CheckpointSaverHook(params.get("model_path"), params.get("steps_per_checkpoint"), model.state_dict,
                                 max_to_keep=params.get("max_checkpoints") or 5, is_chief=(rank == 0))
@@ -71,6 +73,19 @@ def vae_model_fn(features, labels, mode, params):
     st = params[key]
     model = st["model"]
     model.mode = mode_str
+    if mode == ModeKeys.EVAL and st is not params.get("_vae_state_train"):
+        tr = params.get("_vae_state_train")       # a separately sized eval model scores the CURRENT weights
+        if tr is not None:
+            if st.get("_synced_step") != tr["model"].global_step:
+                model.p.copy_(tr["model"].p)
+                model.global_step = tr["model"].global_step
+                model.refresh_compute_copies(cast=True)
+                st["_synced_step"] = tr["model"].global_step
+        else:
+            ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
+            if ck is not None and st.get("_synced_ckpt") != ck:
+                model.load_state_dict(torch.load(ck, map_location="cpu"))
+                st["_synced_ckpt"] = ck
     train_gumbel = params.get("train_gumbel_hard")
     eval_gumbel = params.get("eval_gumbel_hard")
     train_gumbel = True if train_gumbel is None else train_gumbel
@@ -79,7 +94,12 @@ def vae_model_fn(features, labels, mode, params):
     temp = temperature_schedule(model.global_step, params)
     loss, reconstruction = model.forward(features, return_recon_loss=True, temperature=temp, hard_gumbel=gumbel,
                                          need_grad=(mode == ModeKeys.TRAIN))
+    denormalize = lambda x: (x + 1) / 2          # reference model_fns_tf.py:71,83
+    imgs = features["inputs"] if isinstance(features, dict) else features
     if mode == ModeKeys.EVAL:
+        if st["writer"] is not None and float(loss) < 1e-9:      # the reference's record_if(loss < 1e-9) gate (:88)
+            st["writer"].images(model.global_step, "eval/input_image", denormalize(imgs))
+            st["writer"].images(model.global_step, "eval/reconstruction_image", denormalize(reconstruction))
         return EstimatorSpec(mode=mode, loss=loss, eval_metrics={"_loss": loss})
 
     def train_op():
@@ -88,6 +108,10 @@ def vae_model_fn(features, labels, mode, params):
         return model.global_step
 
     host_call = None
-    if st["writer"] is not None:
-        host_call = (lambda step, **kw: st["writer"].scalars(step, **kw), {"loss": loss, "temperature": temp})
+    if st["writer"] is not None:      # rank 0 only: loss (+ temperature), input and reconstruction images (reference :68-78)
+        def host_call_fn(step, loss, temperature, input, reconstruction):
+            st["writer"].scalars(step, loss=loss, temperature=temperature)
+            st["writer"].images(step, "input_image", denormalize(input))
+            st["writer"].images(step, "reconstruction_image", denormalize(reconstruction))
+        host_call = (host_call_fn, {"loss": loss, "temperature": temp, "input": imgs, "reconstruction": reconstruction})
     return EstimatorSpec(mode=mode, loss=loss, train_op=train_op, host_call=host_call, training_hooks=[st["saver"]])

@@ -84,14 +84,19 @@ def get_graph_info(variables):
     return get_n_trainable_vars(variables)
 
 
-def setup_logging(args, logdir="logs"):
-    """reference utils.py:184-195: file + stdout logger named after the config."""
-    os.makedirs(logdir, exist_ok=True)
+def setup_logging(args, logdir="logs", rank=0):
+    """reference utils.py:184-195: file + stdout logger named after the config.  One process per GPU here: only rank 0
+    writes the log file and the console (the other ranks log warnings and above to stderr)."""
     name = os.path.splitext(os.path.basename(args.model))[0]
     logger = logging.getLogger("dalle_mtf_amd")
-    logger.setLevel(logging.INFO)
     logger.propagate = False
-    logger.handlers = [logging.FileHandler(f"{logdir}/{name}.log"), logging.StreamHandler(sys.stdout)]
+    if rank == 0:
+        os.makedirs(logdir, exist_ok=True)
+        logger.setLevel(logging.INFO)
+        logger.handlers = [logging.FileHandler(f"{logdir}/{name}.log"), logging.StreamHandler(sys.stdout)]
+    else:
+        logger.setLevel(logging.WARNING)
+        logger.handlers = [logging.StreamHandler(sys.stderr)]
     return logger
 
 
@@ -127,6 +132,19 @@ class SummaryWriter:
             rec[k] = float(v.item() if hasattr(v, "item") else v)
         with open(self.path, "a") as f:
             f.write(json.dumps(rec) + "\n")
+
+    def images(self, step, name, x, max_images=3):
+        """tf2.summary.image stand-in (reference src/model_fns_tf.py:74-75,89-90; TF writes max_outputs = 3 images):
+        x NHWC in [0, 1] -> model_dir/images/<name>_<step>_<i>.png"""
+        import numpy as np
+        from PIL import Image
+        d = os.path.join(os.path.dirname(self.path), "images")
+        os.makedirs(d, exist_ok=True)
+        a = x[:max_images].detach().float().cpu().numpy() if hasattr(x, "detach") else np.asarray(x[:max_images], np.float32)
+        a = (np.clip(a, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+        for i, im in enumerate(a):
+            Image.fromarray(im[..., 0] if im.shape[-1] == 1 else im[..., :3]).save(
+                os.path.join(d, f"{name.replace('/', '_')}_{int(step)}_{i}.png"))
 
 
 def create_host_call(model_dir):

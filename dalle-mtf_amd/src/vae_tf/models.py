@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 import dalle_hip as dh
+from ..dp import GradReducer
 
 IMG_CP = 8     # padded image channels
 OUT_CP = 64    # padded reconstruction channels
@@ -64,7 +65,8 @@ class _Conv:
 
 class DiscreteVAE:
     def __init__(self, num_tokens, dimensions, convblocks, dim=512, hidden_dim=64, input_channels=3, recompute_grad=False,
-                 use_bf16=False, stack_factor=1, batch_size=32, mode="train", device="cuda", process_group=None, world_size=1):
+                 use_bf16=False, stack_factor=1, batch_size=32, mode="train", device="cuda", process_group=None, world_size=1,
+                 comm=None):
         if not torch.cuda.is_available():
             raise dh.DalleHipError("DiscreteVAE needs a HIP device (MI355X); there is no CPU fallback")
         dh.lib()
@@ -97,6 +99,8 @@ class DiscreteVAE:
         self.global_step = 0
         self._build_graph()
         self._alloc()
+        # gradient exchange (mean over replicas = SUM here x grad_scale 1/world in the Adam kernel), overlapped with backward
+        self.reducer = GradReducer(self.g, world_size, comm=comm, pg=process_group)
 
     # ------------------------------------------------------------------ structure
     def _build_graph(self):
@@ -324,8 +328,17 @@ class DiscreteVAE:
             taps, s = {"down": (TAPS4, 2), "res": (TAPS3, 1), "final": ([(0, 0)], 1)}[c.kind]
             if c.kind != "final" and self._implicit_ok(c):
                 # implicit im2col in forward, input gradient and weight gradient: no column matrix for this layer at all
+                hook = getattr(self, "event_hook", None)   # bench.py: HIP events around one named convolution launch
+                timed = hook is not None and hook[0] == c.name
+                if timed:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 dh.conv_gemm_nt(x, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, self.wf[c.name], Kp, out, c.cout, c.cout,
                                 flags | dh.GEMM_BIAS, bias=bias, residual=residual)
+                if timed:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()
+                    hook[1].append((e0, e1))
                 return
             col = self.col
             if self.keep_cols and c.kind != "final":
@@ -509,8 +522,15 @@ class DiscreteVAE:
         d = self.ga                       # gradient wrt the padded reconstruction [M0, 64]
         spare = [self.gb, self.gc]
         i = len(convs) - 1
+        mark = [self.total]               # g[mark, total) has been handed to the exchange
+
+        def ready_down_to(off):           # the layout follows the forward order, backward finishes it from the end
+            if off < mark[0]:
+                self.reducer.ready(off, mark[0])
+                mark[0] = off
         while i >= 0:
             c = convs[i]
+            lowest = convs[i - 1] if c.kind == "res" else c     # a residual pair is processed as one unit
             if c.kind == "final":
                 M = B * c.H * c.W
                 self._wgrad(c, self.act_in[i], d)
@@ -567,6 +587,7 @@ class DiscreteVAE:
                     dh.pixel_interleave(self.par, nd, B, c.Ho, c.Wo, c.cin)
                     spare[0], d = d, nd
                 i -= 1
+            ready_down_to(self.offset[lowest.name + "/kernel"])
             if i == self.n_enc - 1:
                 # ---- tied codebook + gumbel (between decoder and encoder); d = gradient wrt xdec [Mg, n_hid]
                 T, nh, Mg = self.num_tokens, self.n_hid, self.Mg
@@ -578,14 +599,14 @@ class DiscreteVAE:
                 nd = spare[0]
                 dh.gemm_nt(self.dlogits, T, self._w("codebook/codebook"), T, nd, nh, Mg, nh, T)          # dx_enc = dlogits . C^T
                 spare[0], d = d, nd
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.g, op=dist.ReduceOp.SUM, group=self.pg)
+                ready_down_to(self.offset["codebook/codebook"])
+        ready_down_to(0)
 
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         """tf.train.AdamOptimizer (src/model_fns_tf.py:58-60; Appendix A.8): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
         p -= lr_t*m/(sqrt(v)+eps).  grad_scale 1/world = CrossShardOptimizer's mean over replicas (:61)."""
+        self.reducer.finish()
         t = self.global_step + 1
         lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
         dh.adam_step(self.p, self.g, self.m, self.v, self.pb, self.total, None, 0.0, lr_t, beta1, beta2, eps, 0.0, 1.0 / self.world)

@@ -157,6 +157,21 @@ int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16
                   const float* gnorm_sq, float clip, float lr, float beta1, float beta2, float eps,
                   float weight_decay, float grad_scale, void* stream);
 
+/* ---- data-parallel exchange: the all-reduce mtf inserts for `layout: batch_dim:data`   src/model_fns.py:81-82,189,
+ * VAE src/model_fns_tf.py:61 (CrossShardOptimizer).  One process per GPU, RCCL over xGMI, bound at run time
+ * (dmi_comm_load(path or NULL) -- call it first when the process already maps a specific librccl, e.g. PyTorch's).
+ * Rank 0 draws dmi_comm_unique_id (HOST buffer of dmi_comm_unique_id_bytes()), the caller ships the bytes to all ranks
+ * out of band, every rank calls dmi_comm_init (blocking collective; the current HIP device is the rank's GPU).
+ * dmi_allreduce_bucket: g[0..n) <- sum over ranks (fp32, in place) enqueued on `stream` -- the caller orders it after the
+ * bucket's last gradient kernel with an event and joins the stream before clip + Adam. */
+int dmi_comm_load(const char* librccl_path);
+int dmi_comm_unique_id_bytes(void);
+int dmi_comm_unique_id(void* id_out);
+int dmi_comm_init(void** comm_out, int nranks, int rank, const void* unique_id);
+int dmi_comm_destroy(void* comm);
+int dmi_allreduce_bucket(void* comm, float* g, int64_t n, void* stream);
+int dmi_comm_broadcast_f32(void* comm, float* buf, int64_t n, int root, void* stream);
+
 /* fp32 -> bf16 cast (initial weight export) */
 int dmi_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void* stream);
 

@@ -77,3 +77,27 @@ def test_dp2_gradients_equal_single_process():
     assert rel < 2e-2, rel
     assert abs(n1 - n2) <= 1e-2 * n1
     assert np.abs(p1 - p2).max() <= 6.5 * 1e-3
+
+
+def test_comm_abi_single_rank_roundtrip():
+    """the C-ABI communicator on one GPU (nranks = 1): librccl binds at run time, the unique id / init / all-reduce /
+    broadcast / destroy entry points work on a side stream ordered by events exactly as GradReducer drives them.  (The
+    N > 1 exchange itself needs one GPU per rank: covered by the gloo tests here and on CPU, and by the driver's scaling run.)"""
+    import dalle_hip as dh
+    uid = dh.comm_unique_id()
+    assert len(uid) == 128
+    comm = dh.comm_init(1, 0, uid)
+    assert comm
+    g = torch.randn(1 << 20, device="cuda")
+    want = g.clone()
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    side.wait_event(ev)
+    dh.allreduce_bucket(comm, g, g.numel(), stream=side.cuda_stream)
+    dh.comm_broadcast_f32(comm, g, g.numel(), 0, stream=side.cuda_stream)
+    done = torch.cuda.Event()
+    done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    assert torch.equal(g, want)      # sum over one rank
+    dh.comm_destroy(comm)

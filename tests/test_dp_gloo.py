@@ -42,7 +42,8 @@ def _flat_from_named(lay, named, d, V):
 
 def _worker(rank, world, init_file, out_file):
     from oracle import dalle_oracle as do
-    from src.dalle_mtf.engine import DalleEngine, ParamLayout
+    from src.dalle_mtf.engine import ParamLayout
+    from src.dp import GradReducer
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     cfg = do.DalleConfig(**CFG)
     P = do.init_params(cfg, seed=3, perturb=0.05)
@@ -54,23 +55,28 @@ def _worker(rank, world, init_file, out_file):
     _, g_local = do.loss_and_grads(P, shard, cfg)     # gradient of the LOCAL mean loss
     scale = shard.shape[0] / B_global                 # engine scales dlogits by 1/(B_global*S)
     lay = ParamLayout(cfg.n_embd, cfg.n_layers, cfg.n_heads, cfg.total_tokens, cfg.total_seq_dim)
-
-    class Shim:  # the attributes DalleEngine._allreduce_bucket / wait_grads use
-        pass
-    sh = Shim()
-    sh.lay, sh.world, sh.pg, sh._pending = lay, world, dist.group.WORLD, []
-    sh.g = _flat_from_named(lay, {k: v * np.float32(scale) for k, v in g_local.items()}, cfg.n_embd, cfg.total_tokens)
-    for idx in range(len(lay.bucket_ends)):
-        DalleEngine._allreduce_bucket(sh, idx)
-    DalleEngine.wait_grads(sh)
+    g = _flat_from_named(lay, {k: v * np.float32(scale) for k, v in g_local.items()}, cfg.n_embd, cfg.total_tokens)
+    # the engine's schedule: ready points in completion order, pieces of at most max_bucket_bytes (tiny here: several per range)
+    red = GradReducer(g, world, comm=None, pg=dist.group.WORLD, max_bucket_bytes=16384)
+    done = 0
+    for upto in lay.ready_points:
+        red.ready(done, upto)
+        done = upto
+    log = list(red.log)
+    pending_before = len(red._pending)
+    red.finish()                                        # what optimizer_step() calls first
     if rank == 0:
         _, g_full = do.loss_and_grads(P, tokens, cfg)
         ref = _flat_from_named(lay, g_full, cfg.n_embd, cfg.total_tokens)
-        err = float((sh.g - ref).abs().max())
-        rel = float((sh.g - ref).norm() / ref.norm())
-        covered = lay.bucket_ends[-1] == lay.total and all(a < b for a, b in zip(lay.bucket_ends, lay.bucket_ends[1:]))
+        err = float((g - ref).abs().max())
+        rel = float((g - ref).norm() / ref.norm())
+        # schedule: contiguous, in order, covers [0, total), no piece above the cap, cuts at every ready point
+        ok = log[0][0] == 0 and log[-1][1] == lay.total and all(a[1] == b[0] for a, b in zip(log, log[1:]))
+        ok = ok and all(0 < b - a <= 4096 for a, b in log) and set(lay.ready_points) <= {b for _, b in log}
+        ok = ok and lay.ready_points == sorted(lay.ready_points) and lay.ready_points[-1] == lay.total
+        ok = ok and pending_before == len(log) and len(red._pending) == 0 and red.last_log == log and red.log == []
         with open(out_file, "w") as f:
-            f.write(f"{err} {rel} {int(covered)}")
+            f.write(f"{err} {rel} {int(ok)}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,6 +85,21 @@ def test_bucketed_allreduce_matches_single_process():
     with tempfile.TemporaryDirectory() as td:
         init_file, out_file = os.path.join(td, "init"), os.path.join(td, "out")
         mp.spawn(_worker, args=(2, init_file, out_file), nprocs=2, join=True)
-        err, rel, covered = open(out_file).read().split()
-        assert int(covered) == 1
+        err, rel, ok = open(out_file).read().split()
+        assert int(ok) == 1, "bucket schedule (order / sizes / coverage / join) is wrong"
         assert float(rel) < 1e-5 and float(err) < 1e-5, (err, rel)
+
+
+def test_optimizer_never_starts_before_the_exchange_is_joined():
+    """DalleEngine.optimizer_step and DiscreteVAE.optimizer_step begin with the reducer's finish(); checked on the source so
+    that it holds without a GPU (the engines need one to be constructed)."""
+    import inspect
+    from src.dalle_mtf.engine import DalleEngine
+    from src.vae_tf.models import DiscreteVAE
+    src = inspect.getsource(DalleEngine.optimizer_step)
+    body = src[src.index('"""', src.index('"""') + 3) + 3:]
+    assert body.strip().startswith("self.wait_grads()"), body[:80]
+    assert "self.reducer.finish()" in inspect.getsource(DalleEngine.wait_grads)
+    src = inspect.getsource(DiscreteVAE.optimizer_step)
+    body = src[src.index('"""', src.index('"""') + 3) + 3:]
+    assert body.strip().startswith("self.reducer.finish()"), body[:80]

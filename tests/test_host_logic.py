@@ -68,7 +68,9 @@ def test_checkpoint_hook_retention_and_latest(tmp_path):
 
 def test_estimator_loop_contract(tmp_path):
     """train(): model_fn(features, labels, TRAIN, params) per batch, train_op() returns the global step, hooks see every
-    step, a final checkpoint is written at max_steps, the input iterator is closed; evaluate() averages the loss."""
+    step, a final checkpoint is written at max_steps; ONE training input stream lives across train() calls (a train/eval
+    loop that calls train() once per checkpoint segment must not replay the stream's head -- ADVICE r01) and is closed by
+    close(); evaluate() averages the loss over its own iterator."""
     calls = {"train": 0, "eval": 0, "closed": 0, "host": []}
     state = {"step": 0}
     saver = CheckpointSaverHook(str(tmp_path / "m"), save_steps=1000, get_state=lambda: {"step": torch.tensor(state["step"])})
@@ -107,13 +109,21 @@ def test_estimator_loop_contract(tmp_path):
         info = staticmethod(logs.append)
 
     est = Estimator(model_fn, str(tmp_path / "m"), {"marker": 42}, log_every=2, logger=L)
-    assert est.train(lambda params: Feed(), max_steps=5) == 5
-    assert calls["train"] == 5 and calls["closed"] == 1
+    feeds = []
+
+    def input_fn(params):
+        feeds.append(Feed())
+        return feeds[-1]
+    assert est.train(input_fn, max_steps=5) == 5
+    assert calls["train"] == 5 and calls["closed"] == 0 and est.params["_input_start_step"] == 0
     assert load_global_step_from_checkpoint_dir(str(tmp_path / "m")) == 5          # final save although 5 % 1000 != 0
     assert [h[0] for h in calls["host"]] == [2, 4] and any("step 4" in m for m in logs)
-    assert est.train(lambda params: Feed(), max_steps=7) == 7                       # continues from the model's own step
+    assert est.train(input_fn, max_steps=7) == 7                                    # continues from the model's own step
+    assert len(feeds) == 1 and feeds[0].i == 7                                      # ... and from the SAME input stream
     out = est.evaluate(lambda params: Feed(), steps=3)
-    assert calls["eval"] == 3 and abs(out["loss"] - 2.0) < 1e-6 and calls["closed"] == 3
+    assert calls["eval"] == 3 and abs(out["loss"] - 2.0) < 1e-6 and calls["closed"] == 1
+    est.close()
+    assert calls["closed"] == 2
 
 
 def test_scalar_summaries_to_jsonl(tmp_path):

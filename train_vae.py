@@ -31,7 +31,7 @@ def parse_args():
 
 def main():
     args = parse_args()
-    logging = setup_logging(args)
+    logging = setup_logging(args, rank=int(os.environ.get("RANK", "0")))
     params = fetch_model_params(args.model)
     assert params["model_type"].lower() == "vae", f'model_type {params["model_type"]} not recognized'
     assert args.tpu is None, "TPUs are not supported by the MI355X build"
@@ -39,10 +39,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from src.dp import barrier, init_process_group
+        init_process_group(local_rank)
     if args.new and int(os.environ.get("RANK", "0")) == 0:
         maybe_remove_gs_or_filepath(params["model_path"])
+    if world > 1:
+        barrier()      # nobody looks for a checkpoint before rank 0 has cleared the directory
     current_step = int(load_global_step_from_checkpoint_dir(params["model_path"]))
     logging.info(f"Current step: {current_step}")
     params["use_tpu"] = False
