@@ -950,32 +950,37 @@ struct SoftmaxFinishArgs {
   int64_t M; int K, V;
   float dz_scale;
 };
-#define SF_ROWS 256
+#define SF_ROWS 64
+#define SF_PARTS 16
 __global__ __launch_bounds__(256) void softmax_finish_kernel(SoftmaxFinishArgs a) {
-  __shared__ float sm[4][SF_ROWS];
+  // 64 rows per block, the partials of a row summed by 16 threads (p = q mod 16) with 16-byte loads of 4 adjacent rows: 640
+  // blocks x 4 waves for the dalle_example batch (the 160-block version left 2.5 waves per CU and ran latency-bound)
+  __shared__ float sm[SF_PARTS][SF_ROWS];
   __shared__ float sc[SF_ROWS];
-  const int tid = threadIdx.x, r4 = tid & 63, q = tid >> 6;   // thread: rows 4 r4 .. 4 r4 + 3, partials p = q (mod 4)
+  const int tid = threadIdx.x, r4 = tid & 15, q = tid >> 4;   // thread: rows 4 r4 .. 4 r4 + 3, partials p = q (mod 16)
   const int64_t m0 = (int64_t)blockIdx.x * SF_ROWS, m = m0 + 4 * r4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (m + 3 < a.M && (a.M & 3) == 0) {
-    for (int p = q; p < a.nparts; p += 4) {   // fixed order: deterministic
+    for (int p = q; p < a.nparts; p += SF_PARTS) {   // fixed order: deterministic
       const f32x4 v = *(const f32x4*)(a.part + (int64_t)p * a.M + m);
       s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3];
     }
   } else {
     for (int j = 0; j < 4; ++j)
       if (m + j < a.M)
-        for (int p = q; p < a.nparts; p += 4) s[j] += a.part[(int64_t)p * a.M + m + j];
+        for (int p = q; p < a.nparts; p += SF_PARTS) s[j] += a.part[(int64_t)p * a.M + m + j];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) sm[q][4 * r4 + j] = s[j];
   __syncthreads();
-  {
+  if (tid < SF_ROWS) {
     const int r = tid;
     const int64_t mr = m0 + r;
     float scale = 0.f;
     if (mr < a.M) {
-      const float S = ((sm[0][r] + sm[1][r]) + sm[2][r]) + sm[3][r];
+      float S = 0.f;
+#pragma unroll
+      for (int k = 0; k < SF_PARTS; ++k) S += sm[k][r];
       const bool bad = !(S > 0.f && S < 3.0e38f);   // inf / nan (an exponent overflowed) or an empty row
       if (bad) a.flag[0] = 1;
       a.loss_rows[mr] = bad ? INFINITY : __logf(S);

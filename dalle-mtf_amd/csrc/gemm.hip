@@ -26,7 +26,8 @@
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
 static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (long K, whole residencies), 2 always (tests)
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
-static int g_opt_tn8 = 1;        // 256x256 weight-gradient tile (8 waves): 0 never, 1 auto (I, J >= 256), 2 always (tests)
+static int g_opt_tn8 = 1;        // 256x256 weight-gradient tile (8 waves): 0 never, 1 auto (few tiles, many row splits), 2 always (tests)
+static int g_opt_tn8_max_tiles = 16;   // auto mode: use the 256x256 weight-gradient kernel below this many tiles (A/B hook)
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;
 extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
@@ -35,6 +36,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt8")) return g_opt_nt8;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
+  if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
   return -1;
 }
@@ -43,6 +45,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
+  if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
   return -1;
 }
@@ -724,7 +727,7 @@ static int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static bool tn8_eligible(int M, int I, int J) {
   if (g_opt_tn8 == 2) return true;
   const int tiles = ((I + 255) / 256) * ((J + 255) / 256);
-  return g_opt_tn8 == 1 && I >= 256 && J >= 256 && M >= 2048 && tiles < 16;
+  return g_opt_tn8 == 1 && I >= 256 && J >= 256 && M >= 2048 && tiles < g_opt_tn8_max_tiles;
 }
 static int tn8_splits(int M, int I, int J) {
   const int tiles = ((I + 255) / 256) * ((J + 255) / 256);
@@ -1060,7 +1063,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
 // block per CU, two waves per SIMD; 0.75 transpose reads per MFMA instead of 1 and half the L2->LDS bytes per flop of the
 // 128x128 tile (measured on the NT twin: +20 % on main-loop-bound shapes).  LDS rows are 512 B; 16-B chunk index XOR
 // 4*(row&3) on the source side as in tn_tile.  Fragment sets are double-buffered across the four 16-row k-substeps of a
-// stage (counted lgkmcnt), not pre-read for all four (they would need 96 VGPRs).
+// stage (counted lgkmcnt), not pre-read for all four (they would need 96 VGPRs).  A 4-stage ring of 32-row stages with
+// counted vmcnt (loads three stages ahead) was measured equal to this 2-stage loop on every shape of the model.
 struct TrFrag8 {
   u32x2 x[4][2], y[2][2];   // {x i | y j}{rows +0..3 | +4..7}
 };

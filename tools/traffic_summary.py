@@ -6,7 +6,7 @@ import json
 import sys
 
 fetch_csv, write_csv, out_json = sys.argv[1:4]
-KERNEL = sys.argv[4] if len(sys.argv) > 4 else "gemm_nt4_kernel<1>"   # the kernel the vocabulary projection dispatches to
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else "gemm_nt4_kernel<65>"   # the kernel the vocabulary projection dispatches to
 
 
 def mean_counter(path, name):
@@ -18,7 +18,7 @@ def mean_counter(path, name):
 f, nf = mean_counter(fetch_csv, "FETCH_SIZE")
 w, nw = mean_counter(write_csv, "WRITE_SIZE")
 M, d, V, Vp = 32 * 1280, 512, 50771, 50816
-algo = (M * d + Vp * d) * 2 + M * Vp * 2
+algo = (M * d + Vp * d) * 2 + M * Vp * 2 + (Vp // 64) * M * 4   # operands + bf16 E + fp32 row-sum partials
 rec = {"kernel": KERNEL, "launches": [nf, nw], "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB_raw": w,
        "read_bytes_corrected": f * 1024 * 2, "write_bytes": w * 1024, "traffic_bytes": f * 1024 * 2 + w * 1024,
        "algorithmic_bytes": algo, "note": "FETCH_SIZE doubled per the gfx950 correction; WRITE_SIZE uncalibrated"}
