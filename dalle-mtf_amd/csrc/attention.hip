@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #define HD 128
+#define LOG2E_F 1.4426950408889634f
 #define KP 136  // pitch (elements) of a natural [rows][128] tile  : 272 B
 #define TP 68   // pitch of a transposed [128][64] tile             : 136 B
 #define TP32 36 // pitch of a transposed [128][32] tile            :  72 B
@@ -266,33 +267,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) mx = fmaxf(mx, fmaxf(s0[e], s1[e]));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = __expf(m - mn);
-    m = mn;
+    // online softmax in base 2: p = exp2(s * log2(e) - m2), m2 = running max * log2(e): one fma + one v_exp_f32 per element.
+    // The accumulator rescale (64 multiplies per lane) runs only when some row's maximum actually grew (wave-uniform
+    // branch; with alpha == 1 for every lane the skipped work is the identity, so results are unchanged) -- after the
+    // first few key tiles of a row that is rare.
+    if (__any(mx > m)) {
+      const float mn = fmaxf(m, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E_F);
+      m = mn;
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    }
+    const float m2 = m * LOG2E_F;
     float rs = 0.f;
     bf16x8 pb[4];
     {
       float pe[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        pe[e] = __expf(s0[e] - mn);
+        pe[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[e], LOG2E_F, -m2));
         rs += pe[e];
       }
       pb[0] = pack_bf8(pe);
       pb[1] = pack_bf8(pe + 8);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        pe[e] = __expf(s1[e] - mn);
+        pe[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[e], LOG2E_F, -m2));
         rs += pe[e];
       }
       pb[2] = pack_bf8(pe);
       pb[3] = pack_bf8(pe + 8);
     }
-    l = l * alpha + rs;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    l += rs;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {  // 16-key step: keys 16*ks + {4h..4h+3, 8+4h..8+4h+3}
       Tr4& c = tv[ks & 1];
@@ -389,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     dof[kk] = *(const bf16x8*)(dob + (int64_t)qrow_c * d + 16 * kk + 8 * h);
   }
   const float lse_q = lse[(int64_t)bh * S + qrow_c];
+  const float lse2_q = lse_q * LOG2E_F;   // p = exp2(s * log2(e) - lse * log2(e)): one fma + one v_exp_f32 per element
   float delta_q = 0.f;
   {
     const bf16_t* ob = o + (int64_t)b * S * d + hh * HD;
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = 64 * j + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float pe = __expf((key > qrow) ? -INFINITY : (s[e] - lse_q));  // unconditional exp: no per-element branches
+        const float pe = __builtin_amdgcn_exp2f((key > qrow) ? -INFINITY : __builtin_fmaf(s[e], LOG2E_F, -lse2_q));  // unconditional exp: no per-element branches
         ds[e] = pe * (dp[e] - delta_q);
       }
       bf16x8 dsb[2];
@@ -654,15 +664,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
     for (int g = 0; g < 4; ++g) {
       const f32x4 st0 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h));
       const f32x4 st1 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h) + 4);
-      const float lq[4] = {st0[0], st0[2], st1[0], st1[2]};
+      const float lq[4] = {st0[0] * LOG2E_F, st0[2] * LOG2E_F, st1[0] * LOG2E_F, st1[2] * LOG2E_F};   // lse in base-2 units
       const float dl[4] = {st0[1], st0[3], st1[1], st1[3]};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int e = 4 * g + j;
         const int qg = 32 * qi + 8 * g + 4 * h + j;
         const bool masked = (krow > qg) || (qg >= S);
-        const float x = masked ? -INFINITY : (s[e] - lq[j]);
-        const float pe = __expf(x);
+        const float x = masked ? -INFINITY : __builtin_fmaf(s[e], LOG2E_F, -lq[j]);
+        const float pe = __builtin_amdgcn_exp2f(x);
         pv[e] = pe;
         ds[e] = pe * (dp[e] - dl[j]);
       }

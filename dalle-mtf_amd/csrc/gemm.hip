@@ -105,6 +105,9 @@ __device__ __forceinline__ int lds_chunk_off(int row, int ch) { return (row * 8 
 // bias vector was re-loaded (a dependent ~600-cycle L2 round trip) in each of the 16 store iterations.  Here the bias is
 // loaded once per tile and the residual / ReLU-source rows of a 32-row group are requested before that group's LDS
 // round trip, so no store iteration waits on a global load it has just issued.
+// (Measured and dropped: replacing the bf16 relu_src read of the FFN-2 input gradient by 1 sign bit per element -- 8 ballots in
+// the FFN-1 epilogue, 8 broadcast 64-bit loads + shifts in the mask epilogue -- saves 158 MB of reads per layer but ran the two
+// kernels 125 / 149 us instead of 110 / 134 us: the epilogue is issue-bound, not bandwidth-bound.)
 template <int FLAGS, int MI>
 __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[MI][2], float* stg, int lane, int mrow0, int ncol0) {
   const int r = lane & 31, h = lane >> 5;
