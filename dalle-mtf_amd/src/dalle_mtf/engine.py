@@ -226,14 +226,24 @@ class DalleEngine:
         self.tokens = torch.zeros(B, S, dtype=torch.int32, device=self.dev)
         self.labels = torch.zeros(B, S, dtype=torch.int32, device=self.dev)
         self.X = [torch.empty(M, d, **b16) for _ in range(L + 1)]       # residual stream entering layer l
-        self.xn1 = [torch.empty(M, d, **b16) for _ in range(L)]
-        self.qkv = [torch.empty(M, 3 * d, **b16) for _ in range(L)]
-        self.o = [torch.empty(M, d, **b16) for _ in range(L)]
-        self.lse = [torch.empty(B, H, S, **f32) for _ in range(L)]
-        self.x1 = [torch.empty(M, d, **b16) for _ in range(L)]
-        self.xn2 = [torch.empty(M, d, **b16) for _ in range(L)]
-        self.h = [torch.empty(M, 4 * d, **b16) for _ in range(L)]
-        self.stats = [[torch.empty(M, **f32) for _ in range(4)] for _ in range(L)]  # mean1, rstd1, mean2, rstd2
+        # hparams["recompute_grad"] (the reference wraps every block in mtf.recompute_grad, src/dalle_mtf/models.py:342-343):
+        # only the residual stream X[l] is kept per layer; the block's inner activations live in ONE shared set of buffers
+        # and backward() re-runs the block's forward (bit-identical kernels) before differentiating it: 0.63 GB -> 0.1 GB per
+        # layer at B=32, S=1280, for one extra block forward (~+30 % of the step's flops).
+        self.recompute = bool(self.hp.get("recompute_grad", False))
+        nl = 1 if self.recompute else L
+
+        def per_layer(make):
+            bufs = [make() for _ in range(nl)]
+            return [bufs[l % nl] for l in range(L)]
+        self.xn1 = per_layer(lambda: torch.empty(M, d, **b16))
+        self.qkv = per_layer(lambda: torch.empty(M, 3 * d, **b16))
+        self.o = per_layer(lambda: torch.empty(M, d, **b16))
+        self.lse = per_layer(lambda: torch.empty(B, H, S, **f32))
+        self.x1 = per_layer(lambda: torch.empty(M, d, **b16))
+        self.xn2 = per_layer(lambda: torch.empty(M, d, **b16))
+        self.h = per_layer(lambda: torch.empty(M, 4 * d, **b16))
+        self.stats = per_layer(lambda: [torch.empty(M, **f32) for _ in range(4)])  # mean1, rstd1, mean2, rstd2
         self.xnf = torch.empty(M, d, **b16)
         self.statf = [torch.empty(M, **f32) for _ in range(2)]
         self.z = torch.empty(M, Vp, **b16)      # eval: logits; train: E = exp(logit - label logit), patched into unnormalised dlogits
@@ -294,19 +304,7 @@ class DalleEngine:
         dh.shift_labels(self.tokens, self.labels, B, S, self.eos)
         dh.embed_fwd(self.tokens, self._w("embedding/wte"), self._w("positional_embedding/wpe"), self.X[0], S, d, self.V)
         for l in range(L):
-            p = f"layer_{l}/"
-            x = self.X[l]
-            st = self.stats[l]
-            dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
-            dh.gemm_nt(self.xn1[l], d, self.tview(p + "attn/qkv"), d, self.qkv[l], 3 * d, M, 3 * d, d)
-            dh.attention_fwd(self.qkv[l], self.o[l], self.lse[l], B, H, S)   # no transposed copies: hardware transpose reads
-            dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
-                       bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
-            dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
-            dh.gemm_nt(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
-                       dh.GEMM_BIAS | dh.GEMM_RELU, bias=self._w(p + "mlp/mlp_linear_1/bias"))
-            dh.gemm_nt(self.h[l], 4 * d, self.tview(p + "mlp/mlp_linear_2/kernel"), 4 * d, self.X[l + 1], d, M, d, 4 * d,
-                       dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=self.x1[l])
+            self._block_forward(l)
         dh.layernorm_fwd(self.X[L], self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), self.xnf,
                          self.statf[0], self.statf[1], M, d)
         Wt, bias = self.tview("to_logits/linear_out/kernel"), self._w("to_logits/linear_out/bias")
@@ -333,6 +331,25 @@ class DalleEngine:
             dh.cross_entropy(self.z, Vp, self.labels, self.loss_rows, None, M, self.V, 0.0)
         dh.sum_f32(self.loss_rows, M, 1.0 / (M * nmb), self.loss)
         return self.loss
+
+    def _block_forward(self, l):
+        """one transformer block (src/dalle_mtf/models.py:326-335): X[l] -> X[l+1]; also what backward() re-runs under
+        recompute_grad."""
+        M, d, B, H, S = self.M, self.d, self.B, self.H, self.S
+        p = f"layer_{l}/"
+        x = self.X[l]
+        st = self.stats[l]
+        dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
+        dh.gemm_nt(self.xn1[l], d, self.tview(p + "attn/qkv"), d, self.qkv[l], 3 * d, M, 3 * d, d)
+        dh.attention_fwd(self.qkv[l], self.o[l], self.lse[l], B, H, S)   # no transposed copies: hardware transpose reads
+        dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
+                   bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
+        dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
+        dh.gemm_nt(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
+                   dh.GEMM_BIAS | dh.GEMM_RELU, bias=self._w(p + "mlp/mlp_linear_1/bias"))
+        if not getattr(self, "_in_backward", False):   # the re-run stops here: X[l+1] is already stored
+            dh.gemm_nt(self.h[l], 4 * d, self.tview(p + "mlp/mlp_linear_2/kernel"), 4 * d, self.X[l + 1], d, M, d, 4 * d,
+                       dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=self.x1[l])
 
     def logits(self) -> torch.Tensor:
         """fp32 logits [B,S,V] of the last forward(need_grad=False) ("go to full precision", models.py:395)."""
@@ -388,6 +405,10 @@ class DalleEngine:
         for bi, l in enumerate(reversed(range(L))):
             p = f"layer_{l}/"
             st = self.stats[l]
+            if self.recompute:
+                self._in_backward = True
+                self._block_forward(l)
+                self._in_backward = False
             # FFN
             self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
                         dbias=self._gv(p + "mlp/mlp_linear_2/bias"))

@@ -108,3 +108,25 @@ def test_head_dgrad_tail_split_matches_single_launch(monkeypatch):
     num, den = float((grads[0][1] - grads[1][1]).norm()), float(grads[0][1].norm())
     assert 0 < den and num <= 5e-3 * den, (num, den)
     assert num > 0, "the tail-split launch was not taken (identical bits)"
+
+
+def test_recompute_grad_is_bit_identical():
+    """hparams['recompute_grad'] (mtf.recompute_grad around every block, src/dalle_mtf/models.py:342-343): block activations live
+    in one shared set of buffers and backward() re-runs each block's forward -- same loss, same gradients, bit for bit,
+    and the same parameters after one optimizer step."""
+    from oracle import dalle_oracle as do
+    from src.dalle_mtf.engine import DalleEngine
+    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(2, 16, 300, seed=1),
+                                                 do.synthetic_image_tokens(2, 112, 64, seed=2), 300)).cuda()
+    out = []
+    for rc in (False, True):
+        eng = DalleEngine(256, 3, 2, 300, 64, 16, 112, batch_size=2, hparams=dict(lr=1e-3, train_steps=10, warmup_steps=0,
+                                                                                recompute_grad=rc))
+        eng.init_params(seed=3)
+        loss = float(eng.train_step(tokens))
+        out.append((loss, eng.g.clone(), eng.p.clone()))
+        if rc:
+            assert eng.h[0].data_ptr() == eng.h[2].data_ptr() and eng.qkv[0].data_ptr() == eng.qkv[1].data_ptr()
+        del eng
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
