@@ -101,3 +101,40 @@ def test_comm_abi_single_rank_roundtrip():
     torch.cuda.current_stream().wait_event(done)
     assert torch.equal(g, want)      # sum over one rank
     dh.comm_destroy(comm)
+
+
+def test_multi_backend_process_group_and_comm_setup_single_rank():
+    """the exact process-group setup of the multi-GPU runs (src/dp.py: gloo control plane + nccl = RCCL fallback transport,
+    device bound at init) on ONE rank: object broadcast, barrier, CPU-tensor MAX reduce, then the C-ABI communicator created
+    from the broadcast id and one reducer step on its side stream.  (world_size 1 is all a 1-GPU box can do; the code path is
+    the one bench.py / train_*.py take for N > 1.)"""
+    code = r'''
+import os, sys, torch
+sys.path[:0] = [os.environ["ROOT"], os.path.join(os.environ["ROOT"], "dalle-mtf_amd")]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29591", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+import torch.distributed as dist
+from src import dp
+import dalle_hip as dh
+pg = dp.init_process_group(0)
+box = [dh.comm_unique_id()]
+dist.broadcast_object_list(box, src=0, group=pg)
+dist.barrier()
+t = torch.tensor([3.5]); dist.all_reduce(t, op=dist.ReduceOp.MAX); assert float(t) == 3.5
+comm = dh.comm_init(1, 0, box[0])
+g = torch.randn(40_000_000, device="cuda")
+want = g.clone()
+red = dp.GradReducer(g, 2, comm=comm, pg=pg)      # world 2 only to arm the code path; the communicator has one rank
+assert red.transport == "rccl"
+red.ready(0, 17_000_000); red.ready(17_000_000, g.numel())
+assert [b - a for a, b in red.log] == [16777216, 222784, 16777216, 6222784]   # <= 64 MB pieces, cut at the ready points
+red.finish()
+torch.cuda.synchronize()
+assert torch.equal(g, want)
+red.broadcast(g)
+dh.comm_destroy(comm)
+dist.destroy_process_group()
+print("DP_SETUP_OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ROOT=ROOT), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "DP_SETUP_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
