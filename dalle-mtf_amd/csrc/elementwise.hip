@@ -902,12 +902,13 @@ extern "C" int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, fl
 // Fused softmax head (training path): the cross entropy of models.py:348-359 without a logits round trip.
 //   dmi_label_logit      zl[m] = x[m,:] . Wt[label[m],:] + bias[label[m]]        (fp32; also the per-row shift of the exponent)
 //   dmi_gemm_nt_softmax  E[m,v] = bf16(exp(logit[m,v] - zl[m])) + partial row sums  (gemm.hip)
-//   dmi_softmax_finish   S[m] = sum_v exp(.) ;  loss_row[m] = log S[m]  (= logsumexp - label logit, exactly the reference's
-//                        loss_batch);  rowscale[m] = dz_scale / S[m];  E[m,label] -= S[m]  (so that dlogits = rowscale * E);
+//   dmi_softmax_finish   S[m] = sum_v exp(.) ;  loss_row[m] = log S[m] + shift[m] - zl[m]  (= logsumexp - label logit, exactly the
+//                        reference's loss_batch);  rowscale[m] = dz_scale / S[m];  E[m,label] -= S[m]  (so that dlogits = rowscale * E);
 //                        Xs[m,:] = bf16(rowscale[m] * x[m,:])  (the weight-gradient GEMM's left operand: dW = Xs^T E)
-// label logit as the shift: exp(logit - zl) cannot underflow for any entry that matters (the label entry itself is 1) and
-// overflows only if some logit exceeds the label's by > 88, i.e. the row's loss is > 88 nats; such rows (sum = inf) are
-// flagged and redone exactly by softmax_fixup_kernel with the row maximum as the shift.
+// No shift (the engine's choice): exp(logit) is exact to rounding for logits within +-87 -- floating point keeps its relative
+// precision, the row maximum is not needed.  A row whose sum overflows (some logit > 88) or vanishes (all < -69) is flagged and
+// redone exactly by softmax_fixup_kernel with the row maximum as the shift.  With the label logit as shift (rowshift = zl) the
+// label entry is 1 and only a logit exceeding the label's by > 88 (a row loss > 88 nats) takes the fix-up path.
 // =====================================================================================
 __global__ __launch_bounds__(256) void label_logit_kernel(const bf16_t* __restrict__ X, int ldx, const bf16_t* __restrict__ Wt,
                                                           int ldw, const bf16_t* __restrict__ bias, const int* __restrict__ labels,
@@ -942,6 +943,8 @@ extern "C" int dmi_label_logit(const uint16_t* X, int ldx, const uint16_t* Wt, i
 
 struct SoftmaxFinishArgs {
   const float* part; int nparts;
+  const float* zl;        // label logits (dmi_label_logit)
+  const float* rowshift;  // nullable: the shift the GEMM epilogue subtracted in the exponent
   const int* labels;
   const bf16_t* X; int ldx;
   bf16_t* E; int lde;
@@ -981,9 +984,10 @@ __global__ __launch_bounds__(256) void softmax_finish_kernel(SoftmaxFinishArgs a
       float S = 0.f;
 #pragma unroll
       for (int k = 0; k < SF_PARTS; ++k) S += sm[k][r];
-      const bool bad = !(S > 0.f && S < 3.0e38f);   // inf / nan (an exponent overflowed) or an empty row
+      const bool bad = !(S > 1.0e-30f && S < 3.0e38f);   // inf / nan (an exponent overflowed) or a vanished row
       if (bad) a.flag[0] = 1;
-      a.loss_rows[mr] = bad ? INFINITY : __logf(S);
+      // loss = logsumexp - label logit = log S + shift - zl   (models.py:348-359: the reference's loss_batch)
+      a.loss_rows[mr] = bad ? INFINITY : __logf(S) + (a.rowshift ? a.rowshift[mr] : 0.f) - a.zl[mr];
       scale = bad ? 0.f : a.dz_scale / S;
       if (a.dz_scale != 0.f) {
         a.rowscale[mr] = scale;
@@ -1077,16 +1081,17 @@ __global__ __launch_bounds__(256) void softmax_fixup_kernel(SoftmaxFinishArgs a,
       }
   }
 }
-extern "C" int dmi_softmax_finish(const float* rowsum_part, int nparts, const int32_t* labels, const uint16_t* X, int ldx,
+extern "C" int dmi_softmax_finish(const float* rowsum_part, int nparts, const float* label_logit, const float* rowshift,
+                                  const int32_t* labels, const uint16_t* X, int ldx,
                                   const uint16_t* Wt, int ldw, const uint16_t* bias, uint16_t* E, int lde, int N,
                                   float* loss_rows, float* rowscale, uint16_t* rowscale_bf16, uint16_t* Xs, int32_t* flag,
                                   int64_t M, int K, int V, float dz_scale, void* stream) {
-  DMI_REQUIRE(rowsum_part && labels && X && Wt && bias && E && loss_rows && flag, "softmax_finish: null pointer");
+  DMI_REQUIRE(rowsum_part && label_logit && labels && X && Wt && bias && E && loss_rows && flag, "softmax_finish: null pointer");
   DMI_REQUIRE(dz_scale == 0.f || (rowscale && rowscale_bf16 && Xs), "softmax_finish: gradient outputs missing");
   DMI_REQUIRE(M > 0 && K % 8 == 0 && K <= FIX_MAXK && ldx % 8 == 0 && ldw % 8 == 0 && nparts > 0 && V > 0 && V <= N && N <= lde,
               "softmax_finish: bad sizes (K <= %d)", FIX_MAXK);
   SoftmaxFinishArgs a;
-  a.part = rowsum_part; a.nparts = nparts; a.labels = labels; a.X = X; a.ldx = ldx; a.E = E; a.lde = lde;
+  a.part = rowsum_part; a.nparts = nparts; a.zl = label_logit; a.rowshift = rowshift; a.labels = labels; a.X = X; a.ldx = ldx; a.E = E; a.lde = lde;
   a.loss_rows = loss_rows; a.rowscale = rowscale; a.rowscale_bf16 = rowscale_bf16; a.Xs = Xs; a.flag = flag;
   a.M = M; a.K = K; a.V = V; a.dz_scale = dz_scale;
   hipStream_t st = (hipStream_t)stream;

@@ -63,7 +63,7 @@ struct GemmArgs {
   const bf16_t* residual;
   const bf16_t* relu_src;
   const float* rowscale;   // DMI_GEMM_ROWSCALE: fp32 [M], C[m, :] *= rowscale[m]
-  const float* rowshift;   // GEMM_SOFTMAX: fp32 [M], C[m, n] = exp(acc + bias - rowshift[m])
+  const float* rowshift;   // GEMM_SOFTMAX: nullable fp32 [M], C[m, n] = exp(acc + bias - rowshift[m])  (NULL: no shift)
   float* rowsum_part;      // GEMM_SOFTMAX: fp32 [ceil(N/64)][M] partial row sums of the fp32 exponentials
   int M, N, K, lda, ldb, ldc;
   int tiles_m, tiles_n;
@@ -120,7 +120,12 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
     u32x4 braw = {0, 0, 0, 0};
     if (nok) braw = *(const u32x4*)(a.bias + n);
     unpack8(braw, bias);
+    if constexpr (FLAGS & GEMM_SOFTMAX) {   // the bias rides in the exponent's fma: exp2(acc * log2e + bias * log2e [- shift * log2e])
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bias[e] *= LOG2E;
+    }
   }
+  const bool shifted = (FLAGS & GEMM_SOFTMAX) && a.rowshift != nullptr;   // wave-uniform
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     u32x4 rres[4], rsrc[4];
@@ -134,7 +139,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
       if constexpr (FLAGS & DMI_GEMM_RESIDUAL) rres[it] = ok ? *(const u32x4*)(a.residual + off) : u32x4{0, 0, 0, 0};
       if constexpr (FLAGS & DMI_GEMM_RELU_MASK) rsrc[it] = ok ? *(const u32x4*)(a.relu_src + off) : u32x4{0, 0, 0, 0};
       if constexpr (FLAGS & DMI_GEMM_ROWSCALE) rsc[it] = (m < a.M) ? a.rowscale[m] : 0.f;
-      if constexpr (FLAGS & GEMM_SOFTMAX) rsc[it] = (m < a.M) ? a.rowshift[m] * LOG2E : 0.f;
+      if constexpr (FLAGS & GEMM_SOFTMAX) rsc[it] = (shifted && m < a.M) ? a.rowshift[m] * LOG2E : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -150,7 +155,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
       const f32x4 lo = *(const f32x4*)(stg + row * 68 + ocol);
       const f32x4 hi = *(const f32x4*)(stg + row * 68 + ocol + 4);
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      if constexpr (FLAGS & DMI_GEMM_BIAS) {
+      if constexpr ((FLAGS & DMI_GEMM_BIAS) && !(FLAGS & GEMM_SOFTMAX)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bias[e];
       }
@@ -174,12 +179,20 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= rsc[it];
       }
-      if constexpr (FLAGS & GEMM_SOFTMAX) {  // exp(v - shift) as one fma + v_exp_f32; the fp32 values feed the row sum
+      if constexpr (FLAGS & GEMM_SOFTMAX) {  // exp(v + bias - shift) as one fma + v_exp_f32 per element; the fp32 values feed the row sum
         float ps = 0.f;
+        if (shifted) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], LOG2E, -rsc[it]));
-          ps += v[e];
+          for (int e = 0; e < 8; ++e) {
+            v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], LOG2E, bias[e] - rsc[it]));
+            ps += v[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], LOG2E, bias[e]));
+            ps += v[e];
+          }
         }
         psum[it] = nok ? ps : 0.f;
       }
@@ -642,16 +655,18 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
 
 // Vocabulary projection with the softmax numerator fused into the epilogue (reference src/dalle_mtf/models.py:391-395 feeding
 // :348-359): E[m, n] = bf16(exp(A[m,:] . Bt[n,:] + bias[n] - rowshift[m])), rowsum_part[n / 64][m] = the fp32 sum of those
-// exponentials over columns [64 (n/64), +64).  The logits are never written: with rowshift[m] = the label logit (dmi_label_logit)
-// every exponent that matters is representable whatever the row maximum is (floating point keeps its relative precision over
-// 2^+-127), the row's normaliser is the sum of the partials (dmi_softmax_finish) and the softmax' per-row 1/sum factor moves
-// into the consumers of dlogits (DMI_GEMM_ROWSCALE of the input-gradient GEMM, the pre-scaled X operand of dmi_gemm_tn).
+// exponentials over columns [64 (n/64), +64).  The logits are never written: floating point keeps its relative precision over
+// 2^+-127, so the exponent needs no row maximum -- no shift at all (rowshift NULL: logits within +-87, one VALU op per element
+// less) or any per-row shift within ~+-60 of the row maximum (e.g. the label logit) is exact to rounding; rows that do overflow
+// or vanish are detected from their sum and redone with the row maximum (dmi_softmax_finish).  The row's normaliser is the sum
+// of the partials and the softmax' per-row 1/sum factor moves into the consumers of dlogits (DMI_GEMM_ROWSCALE of the
+// input-gradient GEMM, the pre-scaled X operand of dmi_gemm_tn).
 extern "C" int dmi_gemm_nt_softmax(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, const uint16_t* bias,
                                    const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K,
                                    void* stream) {
   int rc = check_nt(A, lda, Bt, ldb, E, lde, M, N, K);
   if (rc) return rc;
-  DMI_REQUIRE(bias && rowshift && rowsum_part, "gemm_nt_softmax: null pointer");
+  DMI_REQUIRE(bias && rowsum_part, "gemm_nt_softmax: null pointer");
   GemmArgs a;
   fill_nt_args(a, A, lda, Bt, ldb, E, lde, M, N, K);
   a.bias = bias; a.rowshift = rowshift; a.rowsum_part = rowsum_part; a.dbg = g_dbg_buf;

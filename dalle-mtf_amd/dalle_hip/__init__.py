@@ -72,7 +72,7 @@ def _declare(L):
         "dmi_label_logit": (I, [P, I, P, I, P, P, P, P, L64, I, I, P]),
         "dmi_gemm_nt_softmax_partials": (L64, [I]),
         "dmi_gemm_nt_softmax": (I, [P, I, P, I, P, P, P, I, P, I, I, I, P]),
-        "dmi_softmax_finish": (I, [P, I, P, P, I, P, I, P, P, I, I, P, P, P, P, P, L64, I, I, F, P]),
+        "dmi_softmax_finish": (I, [P, I, P, P, P, P, I, P, I, P, P, I, I, P, P, P, P, P, L64, I, I, F, P]),
         "dmi_shift_labels": (I, [P, P, I, I, I, P]),
         "dmi_cross_entropy": (I, [P, I, P, P, P, L64, I, F, P]),
         "dmi_sum_f32": (I, [P, L64, F, P, P]),
@@ -268,15 +268,16 @@ def gemm_nt_softmax_partials(N):
 
 
 def gemm_nt_softmax(X, ldx, Wt, ldw, bias, rowshift, E, lde, rowsum_part, M, N, K):
-    _dev(X, Wt, bias, rowshift, E, rowsum_part)
+    _dev(X, Wt, bias, E, rowsum_part)
     _check(lib().dmi_gemm_nt_softmax(_p(X), ldx, _p(Wt), ldw, _p(bias), _p(rowshift), _p(E), lde, _p(rowsum_part), M, N, K,
                                      _stream()), "gemm_nt_softmax")
 
 
-def softmax_finish(rowsum_part, nparts, labels, X, ldx, Wt, ldw, bias, E, lde, N, loss_rows, rowscale, rowscale_bf16, Xs, flag,
-                   M, K, V, dz_scale):
-    _dev(rowsum_part, labels, X, Wt, bias, E, loss_rows, flag)
-    _check(lib().dmi_softmax_finish(_p(rowsum_part), nparts, _p(labels), _p(X), ldx, _p(Wt), ldw, _p(bias), _p(E), lde, N,
+def softmax_finish(rowsum_part, nparts, label_logit, rowshift, labels, X, ldx, Wt, ldw, bias, E, lde, N, loss_rows, rowscale,
+                   rowscale_bf16, Xs, flag, M, K, V, dz_scale):
+    _dev(rowsum_part, label_logit, rowshift, labels, X, Wt, bias, E, loss_rows, flag)
+    _check(lib().dmi_softmax_finish(_p(rowsum_part), nparts, _p(label_logit), _p(rowshift), _p(labels), _p(X), ldx, _p(Wt), ldw,
+                                    _p(bias), _p(E), lde, N,
                                     _p(loss_rows), _p(rowscale), _p(rowscale_bf16), _p(Xs), _p(flag), M, K, V, float(dz_scale),
                                     _stream()), "softmax_finish")
 

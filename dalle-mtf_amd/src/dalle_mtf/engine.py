@@ -246,13 +246,13 @@ class DalleEngine:
         self.stats = per_layer(lambda: [torch.empty(M, **f32) for _ in range(4)])  # mean1, rstd1, mean2, rstd2
         self.xnf = torch.empty(M, d, **b16)
         self.statf = [torch.empty(M, **f32) for _ in range(2)]
-        self.z = torch.empty(M, Vp, **b16)      # eval: logits; train: E = exp(logit - label logit), patched into unnormalised dlogits
+        self.z = torch.empty(M, Vp, **b16)      # eval: logits; train: E = exp(logit), patched into unnormalised dlogits
         self.loss_rows = torch.empty(M, **f32)
         self.loss = torch.zeros(1, **f32)
         self.gnorm_sq = torch.zeros(1, **f32)
         # fused softmax head (training path, include/dalle_hip.h K7/K8 (b))
         self.nparts = dh.gemm_nt_softmax_partials(Vp)
-        self.zl = torch.empty(M, **f32)                      # label logit = exponent shift
+        self.zl = torch.empty(M, **f32)                      # label logit (loss = logsumexp - label logit)
         self.rowsum_part = torch.empty(self.nparts, M, **f32)
         self.rowscale = torch.empty(M, **f32)                # dz_scale / sum_v exp(.)
         self.rowscale_bf = torch.empty(_round_up(M, 128) + 128, **b16)
@@ -316,7 +316,7 @@ class DalleEngine:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         if need_grad:
-            dh.gemm_nt_softmax(self.xnf, d, Wt, d, bias, self.zl, self.z, Vp, self.rowsum_part, M, Vp, d)
+            dh.gemm_nt_softmax(self.xnf, d, Wt, d, bias, None, self.z, Vp, self.rowsum_part, M, Vp, d)   # no exponent shift
         else:
             dh.gemm_nt(self.xnf, d, Wt, d, self.z, Vp, M, Vp, d, dh.GEMM_BIAS, bias=bias)
         if hook is not None:
@@ -324,7 +324,7 @@ class DalleEngine:
             e1.record()
             hook().append((e0, e1))
         if need_grad:
-            dh.softmax_finish(self.rowsum_part, self.nparts, self.labels, self.xnf, d, Wt, d, bias, self.z, Vp, Vp,
+            dh.softmax_finish(self.rowsum_part, self.nparts, self.zl, None, self.labels, self.xnf, d, Wt, d, bias, self.z, Vp, Vp,
                               self.loss_rows, self.rowscale, self.rowscale_bf, self.xs, self.head_flag, M, d, self.V,
                               1.0 / (self.B_global * S * nmb))
         else:

@@ -118,22 +118,23 @@ int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, float* loss_r
                       int64_t M, int V, float dz_scale, void* stream);
 /* (b) training path: the softmax is fused into the vocabulary projection and its row normaliser is deferred, so the
  * logits never make a round trip through HBM:
- *   dmi_label_logit      zl[m] = X[m,:] . Wt[label[m],:] + bias[label[m]] (fp32) = the per-row exponent shift; clears flag[0].
- *   dmi_gemm_nt_softmax  E[m,n] = bf16(exp(X[m,:] . Wt[n,:] + bias[n] - rowshift[m])) and
+ *   dmi_label_logit      zl[m] = X[m,:] . Wt[label[m],:] + bias[label[m]] (fp32): the loss needs it; clears flag[0].
+ *   dmi_gemm_nt_softmax  E[m,n] = bf16(exp(X[m,:] . Wt[n,:] + bias[n] - rowshift[m])) (rowshift nullable = no shift) and
  *                        rowsum_part[n/64][m] = fp32 sum of those exponentials over the 64-column group
  *                        (dmi_gemm_nt_softmax_partials(N) groups; pad columns need bias << 0 so that they contribute 0).
- *   dmi_softmax_finish   S[m] = sum of the partials; loss_rows[m] = log S[m] (= logsumexp - label logit);
+ *   dmi_softmax_finish   S[m] = sum of the partials; loss_rows[m] = log S[m] + rowshift[m] - label_logit[m] (= logsumexp - label logit);
  *                        rowscale[m] = dz_scale / S[m] (+ its bf16 copy); E[m,label] -= S[m], so dlogits = rowscale[m] * E[m,:];
  *                        Xs[M,K] = bf16(rowscale[m] * X[m,:]).  Consumers: dX = dmi_gemm_nt(E, W, DMI_GEMM_ROWSCALE),
  *                        dW = dmi_gemm_tn(Xs, E, bias_weights = rowscale_bf16).  With dz_scale == 0 only loss_rows is written.
- *                        Rows whose exponent overflowed (some logit > label logit + 88) are redone exactly with the row
- *                        maximum as the shift (needs X, Wt, bias again); flag[0] != 0 afterwards tells that it happened. */
+ *                        Rows whose sum overflowed or vanished (a logit beyond +-87 of the shift) are redone exactly with the
+ *                        row maximum as the shift (needs X, Wt, bias again); flag[0] != 0 afterwards tells that it happened. */
 int dmi_label_logit(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                     const int32_t* labels, float* zl, int32_t* flag, int64_t M, int K, int V, void* stream);
 int64_t dmi_gemm_nt_softmax_partials(int N);
 int dmi_gemm_nt_softmax(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                         const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K, void* stream);
-int dmi_softmax_finish(const float* rowsum_part, int nparts, const int32_t* labels, const uint16_t* X, int ldx,
+int dmi_softmax_finish(const float* rowsum_part, int nparts, const float* label_logit, const float* rowshift,
+                       const int32_t* labels, const uint16_t* X, int ldx,
                        const uint16_t* Wt, int ldw, const uint16_t* bias, uint16_t* E, int lde, int N,
                        float* loss_rows, float* rowscale, uint16_t* rowscale_bf16, uint16_t* Xs, int32_t* flag,
                        int64_t M, int K, int V, float dz_scale, void* stream);

@@ -316,7 +316,7 @@ def _head_case(M, K, V, seed, big=None):
     return X, Wt, bias, labels, Vp
 
 
-def _run_head(X, Wt, bias, labels, V, Vp, dz_scale):
+def _run_head(X, Wt, bias, labels, V, Vp, dz_scale, shift=True):
     M, K = X.shape
     Xd, Wd, bd, ld = X.to(DEV), Wt.to(DEV), bias.to(DEV), labels.to(DEV)
     zl = torch.empty(M, dtype=torch.float32, device=DEV)
@@ -325,25 +325,27 @@ def _run_head(X, Wt, bias, labels, V, Vp, dz_scale):
     nparts = dh.gemm_nt_softmax_partials(Vp)
     part = torch.full((nparts, M), float("nan"), dtype=torch.float32, device=DEV)
     E = torch.zeros(M, Vp, dtype=torch.bfloat16, device=DEV)
-    dh.gemm_nt_softmax(Xd, K, Wd, K, bd, zl, E, Vp, part, M, Vp, K)
+    dh.gemm_nt_softmax(Xd, K, Wd, K, bd, zl if shift else None, E, Vp, part, M, Vp, K)
     loss = torch.empty(M, dtype=torch.float32, device=DEV)
     rsc = torch.empty(M, dtype=torch.float32, device=DEV)
     rsb = torch.empty(M, dtype=torch.bfloat16, device=DEV)
     Xs = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
-    dh.softmax_finish(part, nparts, ld, Xd, K, Wd, K, bd, E, Vp, Vp, loss, rsc, rsb, Xs, flag, M, K, V, dz_scale)
+    dh.softmax_finish(part, nparts, zl, zl if shift else None, ld, Xd, K, Wd, K, bd, E, Vp, Vp, loss, rsc, rsb, Xs, flag, M, K, V, dz_scale)
     return zl, E, loss, rsc, rsb, Xs, int(flag.item())
 
 
+@pytest.mark.parametrize("shift", [False, True])
 @pytest.mark.parametrize("nt4", [0, 2])
 @pytest.mark.parametrize("M,K,V", [(300, 128, 1000), (1024, 512, 5000), (77, 256, 777), (257, 64, 200)])
-def test_fused_softmax_head(M, K, V, nt4):
+def test_fused_softmax_head(M, K, V, nt4, shift):
     """label logit -> exp-epilogue GEMM -> finish: loss_rows = logsumexp - label logit, rowscale * E = dz_scale * (softmax -
-    onehot), Xs = rowscale * X; vs fp32 math on the same bf16 inputs.  Both NT tilings."""
+    onehot), Xs = rowscale * X; vs fp32 math on the same bf16 inputs.  Both NT tilings; without an exponent shift (the
+    engine's mode) and with the label logit as shift."""
     X, Wt, bias, labels, Vp = _head_case(M, K, V, seed=M)
     dz_scale = 1.0 / M
     dh.set_option("nt4", nt4)
     try:
-        zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale)
+        zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale, shift)
     finally:
         dh.set_option("nt4", 1)
     assert flag == 0
@@ -363,13 +365,14 @@ def test_fused_softmax_head(M, K, V, nt4):
     assert abs(float((dz.sum(-1)).abs().max())) <= 2e-2 * dz_scale   # rows of dlogits sum to ~0
 
 
-def test_fused_softmax_head_overflow_rows_are_redone_exactly():
-    """rows whose label logit is ~300 below the row maximum overflow exp(logit - label logit); they are flagged and
+@pytest.mark.parametrize("shift", [False, True])
+def test_fused_softmax_head_overflow_rows_are_redone_exactly(shift):
+    """rows with a logit of +200 (label logit -100) overflow exp(logit [- label logit]); they are flagged from their sum and
     recomputed with the row maximum as the shift: same loss / dlogits as fp32 math, other rows untouched."""
     M, K, V = 130, 128, 500
     X, Wt, bias, labels, Vp = _head_case(M, K, V, seed=11, big=[3, 64, 129])
     dz_scale = 0.25
-    zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale)
+    zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale, shift)
     assert flag == 1
     z = X.float() @ Wt.float()[:V].t() + bias.float()[:V]
     lab = labels.long()

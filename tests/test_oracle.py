@@ -4,6 +4,7 @@ import math
 from collections import OrderedDict
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -187,3 +188,48 @@ def test_serialize_num_microbatches_rule():
     assert f(32, 1280, 1280 * 8) == 4          # 8 sequences per micro-batch
     assert f(32, 1280, 100) == 32              # < one sequence -> micro-batch of 1
     assert f(32, 1280, 10 ** 9) == 1           # micro-batch larger than the batch
+
+
+def test_block_matches_huggingface_gpt_neo_port():
+    """Third-party pin of the Mesh-TensorFlow attention semantics the oracle restates: GPT-Neo was
+    trained with the same `mtf.transformer.attention` call path by the same authors, and HuggingFace's GPTNeoBlock is an
+    independent port of it validated against those checkpoints -- UNSCALED q.k^T in fp32, causal mask, softmax, bias-free
+    q/k/v, output projection with bias, pre-LayerNorm residual block, eps 1e-5.  With activation 'relu' (DALLE-mtf's
+    mtf.relu) the HF block must equal the oracle's block on identical weights."""
+    tr = pytest.importorskip("transformers")
+    from transformers.models.gpt_neo import modeling_gpt_neo as m
+    from transformers.models.gpt_neo.configuration_gpt_neo import GPTNeoConfig
+    d, H, S, B = 128, 2, 48, 2
+    cfg = GPTNeoConfig(hidden_size=d, num_layers=1, attention_types=[[["global"], 1]], num_heads=H, intermediate_size=4 * d,
+                       activation_function="relu", max_position_embeddings=64, vocab_size=100, resid_dropout=0.0,
+                       embed_dropout=0.0, attention_dropout=0.0, layer_norm_epsilon=1e-5, bos_token_id=0, eos_token_id=0)
+    cfg._attn_implementation = "eager"
+    blk = m.GPTNeoBlock(cfg, layer_id=0).eval()
+    g = torch.Generator().manual_seed(0)
+    P = {"g1": 1 + 0.1 * torch.randn(d, generator=g), "b1": 0.1 * torch.randn(d, generator=g),
+         "q": torch.randn(d, d, generator=g) * (d * (d // H)) ** -0.5 * 4, "k": torch.randn(d, d, generator=g) * d ** -0.5,
+         "v": torch.randn(d, d, generator=g) * d ** -0.5, "o": torch.randn(d, d, generator=g) * d ** -0.5,
+         "ob": 0.1 * torch.randn(d, generator=g), "g2": 1 + 0.1 * torch.randn(d, generator=g), "b2": 0.1 * torch.randn(d, generator=g),
+         "w1": torch.randn(d, 4 * d, generator=g) * 0.05, "c1": 0.1 * torch.randn(4 * d, generator=g),
+         "w2": torch.randn(4 * d, d, generator=g) * 0.05, "c2": 0.1 * torch.randn(d, generator=g)}
+    with torch.no_grad():
+        blk.ln_1.weight.copy_(P["g1"]); blk.ln_1.bias.copy_(P["b1"])
+        at = blk.attn.attention
+        at.q_proj.weight.copy_(P["q"].t()); at.k_proj.weight.copy_(P["k"].t()); at.v_proj.weight.copy_(P["v"].t())
+        at.out_proj.weight.copy_(P["o"].t()); at.out_proj.bias.copy_(P["ob"])
+        blk.ln_2.weight.copy_(P["g2"]); blk.ln_2.bias.copy_(P["b2"])
+        blk.mlp.c_fc.weight.copy_(P["w1"].t()); blk.mlp.c_fc.bias.copy_(P["c1"])
+        blk.mlp.c_proj.weight.copy_(P["w2"].t()); blk.mlp.c_proj.bias.copy_(P["c2"])
+    x = torch.randn(B, S, d, generator=g)
+    with torch.no_grad():
+        out = blk(x)
+        want_hf = out[0] if isinstance(out, (tuple, list)) else out
+        h = do.layer_norm(x, P["g1"], P["b1"])
+        a = do.attention(h, P["q"], P["k"], P["v"], P["o"], P["ob"], H, do.attn_mask(S))
+        x1 = x + a
+        got = x1 + do.mlp(do.layer_norm(x1, P["g2"], P["b2"]), P["w1"], P["c1"], P["w2"], P["c2"])
+    assert want_hf.shape == got.shape
+    assert float((got - want_hf).abs().max()) <= 2e-5 * max(1.0, float(want_hf.abs().max()))
+    # the scale matters: with 1/sqrt(head_dim) applied the blocks would differ visibly on these weights
+    a_scaled = do.attention(h, P["q"] / (d // H) ** 0.5, P["k"], P["v"], P["o"], P["ob"], H, do.attn_mask(S))
+    assert float((a_scaled - a).abs().max()) > 1e-2

@@ -116,8 +116,9 @@ def bench_head(M, K, V):
         ("label_logit", lambda: dh.label_logit(X, K, Wt, K, bias, labels, zl, flag, M, K, V), None),
         ("gemm_nt (logits, bias)", lambda: dh.gemm_nt(X, K, Wt, K, E, Vp, M, Vp, K, dh.GEMM_BIAS, bias=bias), fl),
         ("cross_entropy (old path)", lambda: dh.cross_entropy(E, Vp, labels, loss, None, M, V, 1.0 / M), None),
-        ("gemm_nt_softmax", lambda: dh.gemm_nt_softmax(X, K, Wt, K, bias, zl, E, Vp, part, M, Vp, K), fl),
-        ("softmax_finish", lambda: dh.softmax_finish(part, nparts, labels, X, K, Wt, K, bias, E, Vp, Vp, loss, rsc, rsb, Xs, flag, M, K, V, 1.0 / M), None),
+        ("gemm_nt_softmax (label shift)", lambda: dh.gemm_nt_softmax(X, K, Wt, K, bias, zl, E, Vp, part, M, Vp, K), fl),
+        ("gemm_nt_softmax (no shift)", lambda: dh.gemm_nt_softmax(X, K, Wt, K, bias, None, E, Vp, part, M, Vp, K), fl),
+        ("softmax_finish", lambda: dh.softmax_finish(part, nparts, zl, None, labels, X, K, Wt, K, bias, E, Vp, Vp, loss, rsc, rsb, Xs, flag, M, K, V, 1.0 / M), None),
         ("head wgrad (weighted bias)", lambda: dh.gemm_tn(Xs, K, E, Vp, dW, M, K, Vp, w, dbias=db, bias_weights=rsb), fl),
         ("head dgrad (rowscale)", lambda: dh.gemm_nt(E, Vp, W, Vp, dX, K, M, K, Vp, dh.GEMM_ROWSCALE, rowscale=rsc), fl),
     ]
