@@ -1304,8 +1304,58 @@ __global__ __launch_bounds__(256) void reduce_slabs_2d_kernel(const float* __res
   }
 }
 
+// ---- deferred slab reduces ---------------------------------------------------------------------------------------------------
+// A split weight gradient ends with two tiny launches (slabs -> dW, bias partials -> dbias: 5-15 us each, mostly launch cost);
+// a transformer block has seven of them.  With `deferred` the GEMM only records them and the caller runs all reduces of the
+// block in ONE launch (dmi_reduce_slabs_batch) -- the slabs then have to stay alive, i.e. each deferred GEMM needs its own
+// workspace.  Same summation order as the per-GEMM reduce: bit-identical results.
+#define REDUCE_BATCH_MAX 16
+struct ReduceBatch {
+  const float* slabs[REDUCE_BATCH_MAX];
+  float* out[REDUCE_BATCH_MAX];
+  int nsplit[REDUCE_BATCH_MAX];
+  int64_t n4[REDUCE_BATCH_MAX];      // float4 count of one slab
+  int first_block[REDUCE_BATCH_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_slabs_batch_kernel(ReduceBatch g) {
+  int k = 0;
+  while (k + 1 < g.n && (int)blockIdx.x >= g.first_block[k + 1]) ++k;
+  const int nb = g.first_block[k + 1] - g.first_block[k];
+  const f32x4* sl = (const f32x4*)g.slabs[k];
+  const int64_t n4 = g.n4[k];
+  for (int64_t i = (int64_t)(blockIdx.x - g.first_block[k]) * 256 + threadIdx.x; i < n4; i += (int64_t)nb * 256) {
+    f32x4 acc = sl[i];
+    for (int s2 = 1; s2 < g.nsplit[k]; ++s2) {
+      const f32x4 v = sl[(int64_t)s2 * n4 + i];
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+    ((f32x4*)g.out[k])[i] = acc;
+  }
+}
+extern "C" int dmi_reduce_slabs_batch(const dmi_reduce_item* items, int n, void* stream) {
+  if (n == 0) return DMI_OK;
+  DMI_REQUIRE(items && n > 0 && n <= REDUCE_BATCH_MAX, "reduce_slabs_batch: 1..%d items", REDUCE_BATCH_MAX);
+  ReduceBatch g;
+  g.n = n;
+  int nblk = 0;
+  for (int k = 0; k < n; ++k) {
+    DMI_REQUIRE(items[k].slabs && items[k].out && items[k].nsplit >= 1 && items[k].n4 > 0, "reduce_slabs_batch: bad item %d", k);
+    g.slabs[k] = items[k].slabs; g.out[k] = items[k].out; g.nsplit[k] = items[k].nsplit; g.n4[k] = items[k].n4;
+    g.first_block[k] = nblk;
+    int64_t b = cdiv64(items[k].n4, 256);
+    if (b > 1024) b = 1024;
+    nblk += (int)b;
+  }
+  g.first_block[n] = nblk;
+  reduce_slabs_batch_kernel<<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(g);
+  DMI_CHECK_LAUNCH("reduce_slabs_batch");
+  return DMI_OK;
+}
+
 extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias,
-                           const uint16_t* bias_weights, int M, int I, int J, void* workspace, void* stream) {
+                           const uint16_t* bias_weights, int M, int I, int J, void* workspace, dmi_reduce_item* deferred,
+                           int* n_deferred, void* stream) {
   DMI_REQUIRE(X && dY && dW && workspace, "gemm_tn: null pointer");
   DMI_REQUIRE(M > 0 && I % 8 == 0 && J % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= I && ldy >= J,
               "gemm_tn: I, J, ldx, ldy must be multiples of 8 (M=%d I=%d J=%d)", M, I, J);
@@ -1361,12 +1411,20 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
     gemm_tn_kernel<<<dim3(tiles * nsplit), dim3(256), shm, st>>>(a);
     DMI_CHECK_LAUNCH("gemm_tn");
   }
+  if (n_deferred) *n_deferred = 0;
   if (nsplit > 1) {
+    const int64_t n4 = (int64_t)I * J / 4;
+    if (deferred && n_deferred) {   // the caller reduces later (dmi_reduce_slabs_batch); the workspace must stay untouched until then
+      int k = 0;
+      if (dbias) { deferred[k].slabs = bpart; deferred[k].out = dbias; deferred[k].nsplit = nsplit; deferred[k].n4 = J / 4; ++k; }
+      deferred[k].slabs = slabs; deferred[k].out = dW; deferred[k].nsplit = nsplit; deferred[k].n4 = n4; ++k;
+      *n_deferred = k;
+      return DMI_OK;
+    }
     if (dbias) {
       reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);
       DMI_CHECK_LAUNCH("gemm_tn_bias_reduce");
     }
-    const int64_t n4 = (int64_t)I * J / 4;
     int64_t blocks = cdiv64(n4, 256);
     if (blocks > 2048) blocks = 2048;
     reduce_slabs_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(slabs, dW, nsplit, n4, n4);

@@ -63,7 +63,8 @@ def _declare(L):
         "dmi_gemm_nt_splitk_workspace_bytes": (L64, [I, I, I]),
         "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P, P]),
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
-        "dmi_gemm_tn": (I, [P, I, P, I, P, P, P, I, I, I, P, P]),
+        "dmi_gemm_tn": (I, [P, I, P, I, P, P, P, I, I, I, P, P, P, P]),
+        "dmi_reduce_slabs_batch": (I, [P, I, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
         "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
@@ -206,9 +207,38 @@ def gemm_tn_workspace_bytes(M, I, J):
     return lib().dmi_gemm_tn_workspace_bytes(M, I, J)
 
 
-def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws, dbias=None, bias_weights=None):
+class ReduceItem(ctypes.Structure):
+    """dmi_reduce_item (include/dalle_hip.h)."""
+    _fields_ = [("slabs", c_void_p), ("out", c_void_p), ("nsplit", c_int), ("n4", c_int64)]
+
+
+class DeferredReduces:
+    """collects the slab reduces that dmi_gemm_tn calls leave behind; run() launches them as one kernel"""
+
+    def __init__(self, capacity=16):
+        self.items = (ReduceItem * capacity)()
+        self.n, self.capacity = 0, capacity
+
+    def run(self):
+        if self.n:
+            _check(lib().dmi_reduce_slabs_batch(ctypes.byref(self.items), self.n, _stream()), "reduce_slabs_batch")
+        self.n = 0
+
+
+def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws, dbias=None, bias_weights=None, deferred: "DeferredReduces" = None):
+    """deferred: the final slab reduces are appended to it instead of being launched (ws must then be exclusive to this call
+    until deferred.run())."""
     _dev(X, dY, dW, ws, dbias, bias_weights)
-    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), _p(bias_weights), M, I, J, _p(ws), _stream()), "gemm_tn")
+    if deferred is None:
+        _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), _p(bias_weights), M, I, J, _p(ws), None, None,
+                                 _stream()), "gemm_tn")
+        return
+    assert deferred.n + 2 <= deferred.capacity
+    cnt = c_int(0)
+    slot = ctypes.byref(deferred.items, deferred.n * ctypes.sizeof(ReduceItem))
+    _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), _p(bias_weights), M, I, J, _p(ws), slot,
+                             ctypes.byref(cnt), _stream()), "gemm_tn")
+    deferred.n += cnt.value
 
 
 def colsum_workspace_bytes(M, N):

@@ -277,8 +277,14 @@ class DalleEngine:
                   dh.gemm_tn_workspace_bytes(M, d, d), dh.layernorm_bwd_workspace_bytes(M, d),
                   dh.sumsq_workspace_bytes(self.lay.total), dh.gemm_nt_splitk_workspace_bytes(M // 2 + 256, d, 8))
         self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=self.dev)
+        # the four weight gradients of a block keep their split-m slabs in separate workspaces and their seven slab reduces
+        # run as ONE launch at the end of the block's backward (dmi_reduce_slabs_batch)
+        self.ws_blk = [torch.empty(int(dh.gemm_tn_workspace_bytes(M, i_, j_)) + 256, dtype=torch.uint8, device=self.dev)
+                       for i_, j_ in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d))]
+        self.deferred = dh.DeferredReduces()
         # tuning switch: hparams win, the environment variable gives the default (A/B runs: tools/ab_env.sh)
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
+        self.hp.setdefault("defer_reduces", os.environ.get("DALLE_DEFER_REDUCES", "1") != "0")
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -360,9 +366,14 @@ class DalleEngine:
     def _gv(self, name):
         return self.view(self.g, name)
 
-    def _wgrad(self, X, ldx, dY, ldy, dW, M, I, J, dbias=None, bias_weights=None):
-        """dW = X^T dY (+ fused bias gradient)."""
-        dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws, dbias=dbias, bias_weights=bias_weights)
+    def _wgrad(self, X, ldx, dY, ldy, dW, M, I, J, dbias=None, bias_weights=None, slot=None):
+        """dW = X^T dY (+ fused bias gradient).  slot 0..3: one of the block's four gradients -- its slab reduces are deferred
+        to the block's single reduce launch."""
+        if slot is None or not self.hp["defer_reduces"]:
+            dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws, dbias=dbias, bias_weights=bias_weights)
+        else:
+            dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws_blk[slot], dbias=dbias, bias_weights=bias_weights,
+                       deferred=self.deferred)
 
     def backward(self, allreduce=True):
         """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  With world_size > 1 every finished
@@ -411,23 +422,24 @@ class DalleEngine:
                 self._in_backward = False
             # FFN
             self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
-                        dbias=self._gv(p + "mlp/mlp_linear_2/bias"))
+                        dbias=self._gv(p + "mlp/mlp_linear_2/bias"), slot=0)
             dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
                        relu_src=self.h[l])
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
-                        dbias=self._gv(p + "mlp/mlp_linear_1/bias"))
+                        dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
             dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
             dh.layernorm_bwd(self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
                              self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"), ws, M, d)
             # attention
             self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
-                        dbias=self._gv(p + "attn/compute_output_bias/o_b"))
+                        dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
-            self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d)
+            self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
             dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
                              self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"), ws, M, d)
+            self.deferred.run()        # the block's seven slab reduces in one launch
             ready(rp[1 + bi])
         # embeddings: positions visited in token-id order (sorted on the side stream during the forward)
         if self._sort_done is not None:

@@ -89,8 +89,15 @@ int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, 
  * w = 1, or w = bias_weights (nullable bf16 [M]) for the fused-softmax head where dY holds unnormalised dlogits.
  * workspace: dmi_gemm_tn_workspace_bytes(M, I, J). */
 int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J);
+/* deferred (nullable, room for 2 items) + n_deferred: when the gradient is split over m, its final slab reduces (dW, dbias)
+ * are not launched but described here; the caller runs the reduces of several GEMMs in ONE launch with
+ * dmi_reduce_slabs_batch (<= 16 items) -- each deferring GEMM then needs its own workspace, untouched until that call.
+ * out[i] = sum_{s < nsplit} slabs[s * 4 n4 + i], i < 4 n4, fixed order: bit-identical to the undeferred call. */
+typedef struct dmi_reduce_item { const float* slabs; float* out; int nsplit; int64_t n4; } dmi_reduce_item;
 int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias,
-                const uint16_t* bias_weights, int M, int I, int J, void* workspace, void* stream);
+                const uint16_t* bias_weights, int M, int I, int J, void* workspace, dmi_reduce_item* deferred,
+                int* n_deferred, void* stream);
+int dmi_reduce_slabs_batch(const dmi_reduce_item* items, int n, void* stream);
 
 /* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
 int64_t dmi_colsum_workspace_bytes(int64_t M, int N);

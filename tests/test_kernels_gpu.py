@@ -295,6 +295,38 @@ def test_gemm_tn(tail, tn8, M, I, J):
         dh.set_option("tn8", 1)
 
 
+def test_gemm_tn_deferred_batch_reduce_is_bit_identical():
+    """four split weight gradients (with / without bias) whose slab reduces are deferred and run as ONE launch == the same
+    calls with their own reduce launches, bit for bit; an unsplit problem defers nothing."""
+    M = 6000
+    shapes = [(256, 768, True), (256, 256, True), (1024, 256, False), (256, 1024, True)]
+    deferred = dh.DeferredReduces()
+    outs, refs = [], []
+    for k, (I, J, wb) in enumerate(shapes):
+        X, dY = rnd(M, I, seed=10 + k).to(DEV), rnd(M, J, seed=20 + k).to(DEV)
+        rW = torch.zeros(I, J, dtype=torch.float32, device=DEV)
+        rb = torch.zeros(J, dtype=torch.float32, device=DEV) if wb else None
+        dh.gemm_tn(X, I, dY, J, rW, M, I, J, ws(dh.gemm_tn_workspace_bytes(M, I, J)), dbias=rb)
+        refs.append((rW, rb))
+        dW = torch.full((I, J), 5.0, dtype=torch.float32, device=DEV)
+        db = torch.full((J,), 2.0, dtype=torch.float32, device=DEV) if wb else None
+        own_ws = ws(dh.gemm_tn_workspace_bytes(M, I, J))
+        dh.gemm_tn(X, I, dY, J, dW, M, I, J, own_ws, dbias=db, deferred=deferred)
+        outs.append((dW, db, own_ws))
+    assert deferred.n == 7          # 3 x (bias + weights) + 1 x weights
+    deferred.run()
+    assert deferred.n == 0
+    for (dW, db, _), (rW, rb) in zip(outs, refs):
+        assert torch.equal(dW, rW)
+        if db is not None:
+            assert torch.equal(db, rb)
+    X, dY = rnd(500, 1024, seed=1).to(DEV), rnd(500, 8320, seed=2).to(DEV)     # 520 tiles: unsplit (tail launch) -> nothing deferred
+    dW = torch.zeros(1024, 8320, dtype=torch.float32, device=DEV)
+    dh.gemm_tn(X, 1024, dY, 8320, dW, 500, 1024, 8320, ws(dh.gemm_tn_workspace_bytes(500, 1024, 8320)), deferred=deferred)
+    assert deferred.n == 0
+    close(dW, X.float().cpu().t() @ dY.float().cpu(), 2e-3, 2e-3 * math.sqrt(500), "unsplit with deferred arg")
+
+
 # ------------------------------------------------------------------ fused softmax head
 
 def _head_case(M, K, V, seed, big=None):
