@@ -362,6 +362,33 @@ class DalleEngine:
         # (after a training forward self.z holds unnormalised dlogits, not logits)
         return self.z.view(self.B, self.S, self.Vp)[:, :, :self.V].float()
 
+    # ------------------------------------------------------------------ sampling
+    def sample_image_tokens(self, text: torch.Tensor, temperature: float = 1.0, top_k: int = 0, seed: int = 0) -> torch.Tensor:
+        """Autoregressive image-token sampling: text int32 [B, T] -> image-token ids [B, P] in [0, image_vocab_size).
+        The reference scaffolds this (is_incremental_inference, models.py:246-254,281-285) but its predict path raises
+        NotImplementedError (model_fns.py:135-136); here the plain form: one full evaluation forward per generated position (the
+        causal mask makes the not-yet-generated tail irrelevant), logits restricted to the image vocabulary, temperature /
+        top-k / greedy (temperature 0).  No KV cache: 1024 forwards of the dalle_example shape take a few seconds."""
+        B, T, S, P = self.B, self.T, self.S, self.S - self.T
+        assert text.shape == (B, T)
+        lo, hi = self.text_vocab_size, self.text_vocab_size + self.image_vocab_size
+        toks = torch.full((B, S), lo, dtype=torch.int32, device=self.dev)
+        toks[:, :T] = text.to(device=self.dev, dtype=torch.int32)
+        gen = torch.Generator(device=self.dev).manual_seed(seed)
+        for pos in range(P):
+            self.forward(toks, need_grad=False)
+            z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi].float()       # the position before predicts token T + pos
+            if temperature <= 0:
+                nxt = z.argmax(-1)
+            else:
+                z = z / temperature
+                if top_k:
+                    kth = z.topk(min(top_k, z.shape[-1]), dim=-1).values[:, -1:]
+                    z = z.masked_fill(z < kth, float("-inf"))
+                nxt = torch.multinomial(torch.softmax(z, -1), 1, generator=gen).squeeze(-1)
+            toks[:, T + pos] = (nxt + lo).to(torch.int32)
+        return (toks[:, T:] - lo).contiguous()
+
     # ------------------------------------------------------------------ backward
     def _gv(self, name):
         return self.view(self.g, name)

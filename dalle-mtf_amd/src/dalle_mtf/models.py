@@ -62,6 +62,12 @@ class DALLE:
                     "to_logits/linear_out/kernel": (d, V), "to_logits/linear_out/bias": (V,)})
         return out
 
+    def sample(self, text_tokens, vae=None, temperature=1.0, top_k=0, seed=0):
+        """text ids [B, text_seq_len] -> image-token ids [B, image_seq_len] (and the decoded images when a DiscreteVAE is
+        given): the generation path the reference leaves unfinished (model_fns.py:135-136)."""
+        toks = self.engine.sample_image_tokens(text_tokens, temperature=temperature, top_k=top_k, seed=seed)
+        return (toks, vae.decode_tokens(toks)) if vae is not None else toks
+
     def forward(self, features, return_loss=True, return_logits=False):
         """features["tokens"]: int32 [B, S] device tensor.  Returns (loss, loss_batch[, logits]) like the
         reference (models.py:397-416); with return_loss=False returns the fp32 logits only."""

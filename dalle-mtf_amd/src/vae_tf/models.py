@@ -408,9 +408,22 @@ class DiscreteVAE:
             self.u.copy_(noise.to(self.dev).reshape(self.Mg, self.num_tokens))
         self.temperature = float(temperature)
         dh.gumbel_softmax_fwd(self.logits, self.u, self.y, self.y_soft, self.index, self.Mg, self.num_tokens, self.temperature, hard_gumbel)
+        x = self._decoder_from_y()
+        if not return_recon_loss:
+            return self.reconstruction()
+        need_grad = (self.mode == "train") if need_grad is None else need_grad
+        # d(out) of mean((img-out)^2); 1/world folds the CrossShardOptimizer mean (src/model_fns_tf.py:61) into the gradient
+        dh.mse_loss(self.img_net, x, self.ga if need_grad else None, self.loss, B * self.Hs * self.Hs, self.c_st, OUT_CP, 1.0, self.ws)
+        return self.loss[0], self.reconstruction()
+
+    def _decoder_from_y(self):
+        """decoder (vae_tf/models.py:123-163) on self.y [Mg, num_tokens] (soft / hard one-hot): y @ codebook^T, then per reversed
+        block a 4x4 s2 conv-transpose and the residual stacks, final 1x1 conv -> self.out_pad"""
+        convs = self.convs
         dh.gemm_nt(self.y, self.num_tokens, self._w("codebook/codebook"), self.num_tokens, self.xdec, self.n_hid, self.Mg, self.n_hid,
                    self.num_tokens)
         x = self.xdec
+        i = self.n_enc
         while i < len(convs):
             c = convs[i]
             self.act_in[i] = x
@@ -425,12 +438,17 @@ class DiscreteVAE:
                 x = self.act_out[i + 1]
                 i += 2
         self.out_pad = x
-        if not return_recon_loss:
-            return self.reconstruction()
-        need_grad = (self.mode == "train") if need_grad is None else need_grad
-        # d(out) of mean((img-out)^2); 1/world folds the CrossShardOptimizer mean (src/model_fns_tf.py:61) into the gradient
-        dh.mse_loss(self.img_net, x, self.ga if need_grad else None, self.loss, B * self.Hs * self.Hs, self.c_st, OUT_CP, 1.0, self.ws)
-        return self.loss[0], self.reconstruction()
+        return x
+
+    def decode_tokens(self, tokens):
+        """image-token ids [B, g*g] (what DALL-E emits) -> images [B,H,W,C] fp32: one-hot rows through the decoder.
+        The sampling half the reference leaves unfinished (predict raises upstream, src/model_fns.py:135-136)."""
+        tok = tokens.to(device=self.dev, dtype=torch.int64).reshape(self.Mg)
+        assert int(tok.min()) >= 0 and int(tok.max()) < self.num_tokens
+        self.y.zero_()
+        self.y.scatter_(1, tok.view(-1, 1), 1.0)       # index plumbing: the one-hot the hard Gumbel path would produce
+        self._decoder_from_y()
+        return self.reconstruction()
 
     def reconstruction(self):
         out = torch.empty(self.B, self.H, self.W, self.num_ch, dtype=torch.float32, device=self.dev)
