@@ -482,6 +482,20 @@ def test_attention_fwd_bwd(B, H, S, xcd):
         dh.set_option("attn_xcd", 8)
 
 
+@pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 1, 72), (1, 2, 520), (1, 1, 1280)])
+def test_attention_bwd_dkv_kernel_versions_agree(B, H, S):
+    """dK/dV kernel v3 (S / dP of tile t+1 issued among the softmax of tile t) against v2 (phases one after the other):
+    both against fp32 autograd, and bit-for-bit against each other (same products, same accumulation order)."""
+    outs = []
+    for v in (0, 1):
+        dh.set_option("attn_dkv", v)
+        try:
+            outs.append(_attention_fwd_bwd(B, H, S))
+        finally:
+            dh.set_option("attn_dkv", 1)
+    assert torch.equal(outs[0], outs[1])
+
+
 def _attention_fwd_bwd(B, H, S):
     d = H * 128
     # q small (the reference folds 1/sqrt(k) into Wq's init), k/v O(1): logits O(1)
@@ -508,6 +522,7 @@ def _attention_fwd_bwd(B, H, S):
     for i, nm in enumerate("qkv"):
         scale = float(gref[:, i].abs().max())
         close(got[:, i], gref[:, i], 3e-2, 2e-2 * scale, f"attn bwd d{nm}")
+    return dqkv
 
 
 def test_attention_row0_kat():
