@@ -164,7 +164,6 @@ __device__ __forceinline__ void fr3_wait(Fr3& f) {
 }
 
 extern int g_opt_attn_xcd;
-extern int g_opt_attn_dkv;   // dK/dV kernel: 0 = v2 (sequential phases), 1 = v3 (software-pipelined)
 // (tile, batch*head) of this block.  remap = 0: plain grid order.  remap = G >= 1: hardware block b (dispatched to XCD
 // b % 8) takes the b-th entry of a per-XCD contiguous range of the sequence below, so the tiles of one (batch, head)
 // share that XCD's L2 copy of K/V/Q/dO; inside the range, groups of G (batch, head) pairs are visited tile-major
@@ -540,235 +539,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
 }
 
-// ---- dK/dV kernel v2 -------------------------------------------------------------------------------------------
+// ---- dK/dV kernel ---------------------------------------------------------------------------------------------------
 // Block = 128 keys (4 waves x 32), loop over 32-query tiles from the diagonal down.
 //   S = Q K^T, dP = dO V^T           : A operands (rows = queries) read with ds_read_b128 from the NATURAL Q / dO tiles
 //   dV^T += dO^T P, dK^T += Q^T dS   : A operands (rows = d) are the TRANSPOSE of the same tiles -> ds_read_b64_tr_b16
-// so only two 8-KiB tiles (+ 256 B of (lse, delta) pairs) stream per step, by LDS-DMA into a 2-stage ring: loads of
-// step t+1 are in flight during the MFMAs of step t, one barrier per step.  LDS rows are 256 B linear (DMA), 16-B chunk
-// index XOR ((row&3)<<2 | (row>>2)&3) on the source side: 16 consecutive rows hit 16 distinct chunks (b128 reads
-// conflict-free) and the 4 rows x 64 B of a transpose-read group cover all banks once.
-// Transposed reads go through inline asm (see gemm.hip: hipcc serialises the intrinsic behind in-flight LDS-DMA).
-#define DKV_STAGE 16640  // Q 8192 | dO 8192 | (lse,delta) pairs 256
+// so only two 8-KiB tiles (+ 256 B of (lse * log2 e, delta) pairs) stream per step, by LDS-DMA into a 4-slot ring.  LDS rows
+// are 256 B linear (DMA), 16-B chunk index XOR ((row&3)<<2 | (row>>2)&3) on the source side: 16 consecutive rows hit 16
+// distinct chunks (b128 reads conflict-free) and the 4 rows x 64 B of a transpose-read group cover all banks once.
+// Every LDS read goes through inline asm with counted lgkmcnt waits (hipcc serialises the intrinsics behind in-flight
+// LDS-DMA, see gemm.hip) -- which also makes a RUN-TIME ring slot index safe: a x4 unroll with literal slot offsets
+// makes LICM hoist ~100 per-slot fragment addresses out of the loop.
+// Software pipeline (one wave per SIMD: 128 accumulator registers for dV / dK leave no room for a second block): a step is
+//   phase A:  S / dP MFMAs of tile t+1 (slot t+1)   interleaved with   softmax + dS of tile t (one element pair per two MFMAs)
+//   phase B:  dV / dK MFMAs of tile t (slot t)       interleaved with   the DMA issue of tile t+3 and the stats fetch of tile t+1
+// Measured (profiles/r02_attn_dkv_phases.log): the phases-one-after-the-other version took 211 us per call at (32, 4, 1280),
+// this one 160 us, bit-identical results; per-step cycle counters: A 1240, B 527 (= its 16 MFMAs), DMA wait + barrier 200.
+// A two-blocks-per-CU variant (<= 256 registers, 65 KiB LDS) spilled and was not faster.
+#define DKV_STAGE 16640  // Q 8192 | dO 8192 | (lse * log2 e, delta) pairs 256
 #define DKV_NSTAGE 4
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                              const float* __restrict__ stats /* [B,H,S,2] (lse * log2 e, delta) */,
-                                                              bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
-  const int d = H * HD, ld3 = 3 * d;
-  int ktile, bh;
-  attn_block(remap, ktile, bh);
-  const int b = bh / H, hh = bh % H;
-  const int key0 = ktile * 128;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
-  const int krow = key0 + wid * 32 + r;
-  const int krow_c = krow < S ? krow : S - 1;
-  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
-  const bf16_t* kb = qb + d;
-  const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
-
-  // buffer descriptors: num_records ends with the last valid row so tail rows read as zeros
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(((int64_t)(S - 1) * d + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)(stats + (int64_t)bh * S * 2), 0, S * 8, 0x00020000);
-
-  bf16x8 kf[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kb + (int64_t)krow_c * ld3 + 16 * kk + 8 * h);
-
-  // resident V tile: 128 rows x 16 chunks = 2048 chunks, 8 per thread; rows past S clamp (their keys are never stored)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
-    int gr = key0 + row;
-    gr = gr < S ? gr : S - 1;
-    dma16(rv, sm + (wid * 64 + 256 * i) * 16, (gr * ld3 + 8 * (pc ^ swz(row))) * 2);
-  }
-  // per-step DMA offsets (2 chunks of Q, 2 of dO per thread; tile row = c>>4, rows advance by 32 per step)
-  int voq[2], vod[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
-    voq[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
-    vod[i] = (row * d + 8 * (pc ^ swz(row))) * 2;
-  }
-  auto stage = [&](int st, int q0) {
-    char* base = sm + 32768 + st * DKV_STAGE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      dma16(rq, base + (wid * 64 + 256 * i) * 16, voq[i] + q0 * ld3 * 2);
-      dma16(rdo, base + 8192 + (wid * 64 + 256 * i) * 16, vod[i] + q0 * d * 2);
-    }
-    dma4(rst, base + 16384, (q0 * 2 + lane) * 4);  // 32 (lse, delta) pairs; every wave (identical bytes): uniform DMA count
-  };
-  // hoisted fragment offsets
-  int ofa[8];  // natural A operand: row r, chunk (2kk+h) ^ swz(r)
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) ofa[kk] = r * 256 + (((2 * kk + h) ^ swz(r)) << 4);
-  // transposed A operand: rows 16*s2 + 4h + (l16>>2) [+8], byte in row (dt*64 + 32*(g4&1) + 8*(l16&3)) swizzled
-  const int rr = l16 >> 2;
-  unsigned oft[4][2];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int w2 = 0; w2 < 2; ++w2) {
-      const int row = 4 * h + rr + 8 * w2;  // + 16*s2 does not change swz
-      const int chunk = dt * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);
-      oft[dt][w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
-    }
-
-  f32x16 dv[4], dk[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dv[i][e] = dk[i][e] = 0.f;
-
-  const int wave_kmin = key0 + wid * 32;
-  const int nqi = (S + 31) / 32;
-  const int qi0 = key0 / 32;
-
-  unsigned aq[8], av[8];  // per-lane LDS addresses of the natural fragments: stage region / this wave's V rows
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) {
-    aq[kk] = lds0 + 32768 + ofa[kk];
-    av[kk] = lds0 + wid * 8192 + ofa[kk];
-  }
-  auto compute = [&](auto stc, int qi) {
-    constexpr int st = decltype(stc)::value;
-    if (32 * qi + 31 < wave_kmin) return;  // wave-uniform: every query of the tile precedes every key of this wave
-    const char* base = sm + 32768 + st * DKV_STAGE;
-    const unsigned lb = lds0 + 32768 + st * DKV_STAGE;
-    const float* sst = (const float*)(base + 16384);
-    f32x16 s, dp;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-    {
-      Fr3 F[3];  // ring of operand triples, two k-steps ahead of the MFMAs
-      fr3_issue<st * DKV_STAGE>(F[0], aq[0], av[0]);
-      fr3_issue<st * DKV_STAGE>(F[1], aq[1], av[1]);
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        Fr3& c = F[kk % 3];
-        if (kk == 0) fr3_wait<3>(c);
-        else if (kk < 7) fr3_wait<3>(c, F[(kk + 2) % 3]);
-        else fr3_wait<0>(c, F[(kk + 2) % 3]);
-        if (kk + 2 < 8) fr3_issue<st * DKV_STAGE>(F[(kk + 2) % 3], aq[kk + 2], av[kk + 2]);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.q), kf[kk], s, 0, 0, 0);            // S[q][key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.d), __builtin_bit_cast(bf16x8, c.v), dp, 0, 0, 0);  // dP[q][key]
-      }
-    }
-    Tr4 tdo, tq;  // first 16 queries (s2 = 0): dO^T then Q^T fragments, issued before the softmax VALU work
-    tr4_issue(tdo, lb + 8192 + oft[0][0], lb + 8192 + oft[0][1], lb + 8192 + oft[1][0], lb + 8192 + oft[1][1],
-              lb + 8192 + oft[2][0], lb + 8192 + oft[2][1], lb + 8192 + oft[3][0], lb + 8192 + oft[3][1]);
-    // (lse, delta) pairs of this lane's 16 query rows: rows (e&3) + 8*(e>>2) + 4h -> 4 consecutive pairs per e>>2.
-    // Loaded unconditionally with vector reads; the exponential is unconditional too (exp(-inf) = 0 for masked
-    // entries) -- a ternary around exp() is compiled into per-element branches with an LDS wait inside each.
-    float pv[16], ds[16];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 st0 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h));
-      const f32x4 st1 = *(const f32x4*)(sst + 2 * (8 * g + 4 * h) + 4);
-      const float lq[4] = {st0[0], st0[2], st1[0], st1[2]};   // lse in base-2 units (pre-scaled by the dQ kernel)
-      const float dl[4] = {st0[1], st0[3], st1[1], st1[3]};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = 4 * g + j;
-        const int qg = 32 * qi + 8 * g + 4 * h + j;
-        const bool masked = (krow > qg) || (qg >= S);
-        const float x = masked ? -INFINITY : __builtin_fmaf(s[e], LOG2E_F, -lq[j]);
-        const float pe = __builtin_amdgcn_exp2f(x);
-        pv[e] = pe;
-        ds[e] = pe * (dp[e] - dl[j]);
-      }
-    }
-    bf16x8 pb[2], dsb[2];
-    pb[0] = pack_bf8(pv);
-    pb[1] = pack_bf8(pv + 8);
-    dsb[0] = pack_bf8(ds);
-    dsb[1] = pack_bf8(ds + 8);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const unsigned o = lb + s2 * 4096;
-      tr4_wait(tdo);
-      tr4_issue(tq, o + oft[0][0], o + oft[0][1], o + oft[1][0], o + oft[1][1], o + oft[2][0], o + oft[2][1], o + oft[3][0], o + oft[3][1]);
-      dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.a0, tdo.a1), pb[s2], dv[0], 0, 0, 0);   // dV^T[d][key]
-      dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.b0, tdo.b1), pb[s2], dv[1], 0, 0, 0);
-      dv[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.c0, tdo.c1), pb[s2], dv[2], 0, 0, 0);
-      dv[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.d0, tdo.d1), pb[s2], dv[3], 0, 0, 0);
-      tr4_wait(tq);
-      if (s2 == 0) {
-        const unsigned o2 = lb + 8192 + 4096;
-        tr4_issue(tdo, o2 + oft[0][0], o2 + oft[0][1], o2 + oft[1][0], o2 + oft[1][1], o2 + oft[2][0], o2 + oft[2][1], o2 + oft[3][0], o2 + oft[3][1]);
-      }
-      dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.a0, tq.a1), dsb[s2], dk[0], 0, 0, 0);    // dK^T[d][key]
-      dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.b0, tq.b1), dsb[s2], dk[1], 0, 0, 0);
-      dk[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.c0, tq.c1), dsb[s2], dk[2], 0, 0, 0);
-      dk[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.d0, tq.d1), dsb[s2], dk[3], 0, 0, 0);
-    }
-  };
-
-  // 4-stage DMA ring, loads issued 3 steps ahead; counted vmcnt (5 DMA per wave per stage) + raw barriers so the
-  // loads stay in flight across barriers; ONE barrier per step:
-  //   [barrier: everyone finished compute(t-1) and everyone's stage-t data landed] issue t+3 -> compute t -> wait t+1
-  const int nsteps = nqi - qi0;
-#define DKV_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define DKV_BARRIER()                                  \
-  do {                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                      \
-  } while (0)
-  if (nsteps > 0) stage(0, 32 * qi0);
-  if (nsteps > 1) stage(1, 32 * (qi0 + 1));
-  if (nsteps > 2) stage(2, 32 * (qi0 + 2));
-  if (nsteps > 2) DKV_WAIT(10); else if (nsteps > 1) DKV_WAIT(5); else DKV_WAIT(0);
-  DKV_BARRIER();
-  int t = 0;
-#define DKV_STEP(ST)                                                        \
-  {                                                                         \
-    if (t + 3 < nsteps) stage((ST + 3) & 3, 32 * (qi0 + t + 3));            \
-    compute(std::integral_constant<int, ST>{}, qi0 + t);                    \
-    const int rem = nsteps - 1 - t; /* steps after this one */              \
-    if (rem >= 3) DKV_WAIT(10); else if (rem == 2) DKV_WAIT(5); else DKV_WAIT(0); \
-    DKV_BARRIER();                                                          \
-    ++t;                                                                    \
-  }
-  while (t + 4 <= nsteps) {
-    DKV_STEP(0) DKV_STEP(1) DKV_STEP(2) DKV_STEP(3)
-  }
-  if (t < nsteps) DKV_STEP(0)
-  if (t < nsteps) DKV_STEP(1)
-  if (t < nsteps) DKV_STEP(2)
-#undef DKV_STEP
-#undef DKV_WAIT
-#undef DKV_BARRIER
-
-  if (krow < S) {
-    bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
-    bf16_t* ovp = okp + d;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int dd = dt * 32 + 8 * q4 + 4 * h;
-        *(u32x2*)(okp + dd) = u32x2{pack2bf(dk[dt][4 * q4], dk[dt][4 * q4 + 1]), pack2bf(dk[dt][4 * q4 + 2], dk[dt][4 * q4 + 3])};
-        *(u32x2*)(ovp + dd) = u32x2{pack2bf(dv[dt][4 * q4], dv[dt][4 * q4 + 1]), pack2bf(dv[dt][4 * q4 + 2], dv[dt][4 * q4 + 3])};
-      }
-  }
-}
-
-// ---- dK/dV kernel v3: software-pipelined ------------------------------------------------------------------------
-// Same data path as v2 (resident V tile, 4-stage Q / dO / stats DMA ring, natural + hardware-transposed fragment reads).
-// v2 runs one wave per SIMD and executes  S/dP MFMAs -> softmax VALU -> dV/dK MFMAs  strictly one after the other: the
-// matrix pipe idles during the ~800 VALU cycles of every 32-query step and nothing else is resident to fill it.  Here
-// the S / dP products of tile t+1 are issued in the same program region as the softmax of tile t (independent work: the
-// MFMAs execute in the matrix pipe while the wave issues the VALU instructions), with the source order pinned by
-// sched_barriers: 2 k-steps (4 MFMAs) then one 4-row softmax group.  The ring therefore keeps tile t (transposed
-// fragments + stats) and tile t+1 (natural fragments) resident with tiles t+2, t+3 in flight.
 struct St8 {
   f32x4 v[8];   // (lse, delta) pairs of this lane's 16 query rows: v[2g], v[2g+1] = rows 8g + 4h + {0,1}, {2,3}
 };
@@ -793,8 +581,7 @@ __device__ __forceinline__ void st8_wait(St8& f) {
                : "n"(N)
                : "memory");
 }
-template <int DBG>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ stats /* [B,H,S,2] (lse * log2 e, delta) */,
                                                                bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
@@ -802,8 +589,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
   int ktile, bh;
   attn_block(remap, ktile, bh);
   const int b = bh / H, hh = bh % H;
-  unsigned long long t00 = 0, r00 = 0;
-  if constexpr (DBG == 6) { t00 = __builtin_readcyclecounter(); r00 = __builtin_amdgcn_s_memrealtime(); }
   const int key0 = ktile * 128;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -848,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
     }
     dma4(rst, base + 16384, (q0 * 2 + lane) * 4);
   };
-  auto stage_q = [&](int st, int q0, int i) {   // one quarter of a stage (Q + dO chunks i) / the stats strip: issued between MFMAs
+  auto stage_q = [&](int st, int q0, int i) {   // half of a stage's Q + dO chunks / its stats strip: issued between the dV / dK MFMAs
     char* base = sm + 32768 + st * DKV_STAGE;
     dma16(rq, base + (wid * 64 + 256 * i) * 16, voq[i] + q0 * ld3 * 2);
     dma16(rdo, base + 8192 + (wid * 64 + 256 * i) * 16, vod[i] + q0 * d * 2);
@@ -887,10 +672,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) aq[kk] = lds0 + 32768 + ofa[kk];
   const unsigned vrel = (unsigned)(wid * 8192 - 32768);
-  // The stage index is a run-time value here: every LDS read of the loop goes through inline asm, which the compiler's
-  // LDS-DMA alias bookkeeping does not see (no vmcnt drain), and a x4 unroll with literal stage offsets makes LICM hoist
-  // ~100 per-stage fragment addresses out of the loop (measured: 900 spilled VGPRs).
-  // S / dP of the tile in stage slot st, nothing interleaved (first tile of a block)
+  // S / dP of the tile in ring slot st, nothing interleaved (first tile of a block)
   auto sdp_only = [&](int st, f32x16& s, f32x16& dp) {
     const unsigned so = st * DKV_STAGE;
 #pragma unroll
@@ -909,10 +691,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
       dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.d), __builtin_bit_cast(bf16x8, c.v), dp, 0, 0, 0);
     }
   };
-  // softmax + dS of ONE accumulator element e (query row (e&3) + 8(e>>2) + 4h of the tile, this lane's key); the stats hold
-  // (lse * log2(e), delta) pairs.  MASK: only the four tiles that touch the block's diagonal need the causal predicate.
-  // Rows past S need no mask: their Q / dO rows and stats read as zeros (buffer bounds), so dS = 0 and P multiplies a zero dO row.
-  // softmax + dS of the accumulator-element pair (2i, 2i+1), packed to bf16 (pw / dw = the MFMA B operands).
+  // softmax + dS of the accumulator-element pair (2i, 2i+1) = query rows (e&3) + 8(e>>2) + 4h of the tile, this lane's key,
+  // packed to bf16 (pw / dw = the B operands of the dV / dK MFMAs); the stats hold (lse * log2(e), delta) pairs.
+  // MASK: only the four tiles that touch the block's diagonal need the causal predicate.  Rows past S need no mask: their
+  // Q / dO rows and stats read as zeros (buffer bounds), so dS = 0 and P multiplies a zero dO row.
   auto softmax_pair = [&](auto mask_c, int i, const St8& stt, const f32x16& s, const f32x16& dp, int kd, unsigned* pw, unsigned* dw) {
     constexpr bool MASK = decltype(mask_c)::value;
     const int g = i >> 1;                       // elements 4g + {0,1} (i even) or 4g + {2,3} (i odd)
@@ -929,12 +711,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
     dw[i] = pack2bf(q0, q1);
     asm volatile("" : "+v"(pw[i]), "+v"(dw[i]));   // pin here: otherwise the exponentials sink below the last MFMA
   };
-  unsigned long long tA = 0, tB = 0, tW = 0, tmark = 0;   // DBG 6: cycles in phase A / phase B / DMA wait + barrier
   St8 stt;       // stats of the CURRENT tile: fetched during the previous step's dV / dK phase (the first one before the loop)
   Tr4 tdo, tq;   // transposed dO / Q fragments of the current tile's first 16 queries: fetched at the top of the step
   auto body = [&](int st, int qi, int t, f32x16& s, f32x16& dp, f32x16& sn, f32x16& dpn, auto has_next_c, auto mask_c) {
     constexpr bool has_next = decltype(has_next_c)::value;
-    if constexpr (DBG == 6) tmark = __builtin_readcyclecounter();
     const unsigned lb = lds0 + 32768 + st * DKV_STAGE;
     const unsigned so = ((st + 1) & 3) * DKV_STAGE;
     tr4_issue(tdo, lb + 8192 + oft[0][0], lb + 8192 + oft[0][1], lb + 8192 + oft[1][0], lb + 8192 + oft[1][1],
@@ -957,9 +737,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
         else if (kk == 6) fr3_wait<3>(c, F[(kk + 3) & 3]);
         else fr3_wait<0>(c, F[(kk + 3) & 3]);
         if (kk + 3 < 8) fr3_issue<0>(F[(kk + 3) & 3], aq[kk + 3] + so, aq[kk + 3] + vrel);
-        if constexpr (DBG != 3) sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.q), kf[kk], sn, 0, 0, 0);
-        if constexpr (DBG != 3) dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.d), __builtin_bit_cast(bf16x8, c.v), dpn, 0, 0, 0);
-        if constexpr (DBG != 2) softmax_pair(mask_c, kk, stt, s, dp, kd, pw, dw);
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.q), kf[kk], sn, 0, 0, 0);
+        dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.d), __builtin_bit_cast(bf16x8, c.v), dpn, 0, 0, 0);
+        softmax_pair(mask_c, kk, stt, s, dp, kd, pw, dw);
         // one MFMA, then half of the pair's VALU chain (two independent elements interleaved: a single resident wave has
         // nothing else to cover the VALU / transcendental latencies), twice
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -968,15 +748,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
         __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (DBG == 2) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pw[i] = dw[i] = 0x3c003c00u;
-      }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) softmax_pair(mask_c, i, stt, s, dp, kd, pw, dw);
     }
-    if constexpr (DBG == 6) { const unsigned long long c = __builtin_readcyclecounter(); tA += c - tmark; tmark = c; }
     bf16x8 pb[2], dsb[2];
     pb[0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
     pb[1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
@@ -985,15 +760,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
     // dV / dK phase: 16 MFMAs, no VALU work of its own -> the DMA issue of tile t+3 and the stats fetch of tile t+1 ride here.
     // Fragment sets: (tdo, tq) hold the first 16 queries (in since the top of the step); t2 takes dO^T of the second 16,
     // then tdo's registers are reused for Q^T of the second 16.
-    const bool do_dma = (DBG != 4) && (t + 3 < nsteps);
+    const bool do_dma = t + 3 < nsteps;
     const int st3 = (st + 3) & 3, q3 = 32 * (qi + 3);
     Tr4 t2;
-    if constexpr (DBG == 1) {
-      tr4_wait(tdo);
-      dv[0][0] += (float)(pw[0] + pw[3] + pw[5] + dw[1] + dw[6] + tdo.a0[0] + tq.a0[0]);
-      if (do_dma) stage(st3, q3);
-      if constexpr (has_next) { st8_issue(stt, lds0 + 32768 + so + 16384 + 32 * h); st8_wait<0>(stt); }
-    } else {
+    {
       const unsigned o2 = lb + 8192 + 4096, o1 = lb + 4096;
       tr4_wait(tq);   // (tdo, tq) of the first 16 queries
       tr4_issue(t2, o2 + oft[0][0], o2 + oft[0][1], o2 + oft[1][0], o2 + oft[1][1], o2 + oft[2][0], o2 + oft[2][1], o2 + oft[3][0], o2 + oft[3][1]);
@@ -1048,10 +818,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
 #define DKV_STEP(CS, CD, NS, ND, NEXT, MASK)                                \
   {                                                                         \
     body(t & 3, qi0 + t, t, CS, CD, NS, ND, std::integral_constant<bool, NEXT>{}, std::integral_constant<bool, MASK>{}); \
-    if (DBG == 6) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); const unsigned long long c = __builtin_readcyclecounter(); tB += c - tmark; tmark = c; } \
     if (nsteps - 1 - t >= 3) DKV_WAIT(5); else DKV_WAIT(0);                 \
-    if (DBG != 5) DKV_BARRIER();                                            \
-    if (DBG == 6) { const unsigned long long c = __builtin_readcyclecounter(); tW += c - tmark; } \
+    DKV_BARRIER();                                                          \
     ++t;                                                                    \
   }
   // tiles 0..3 of a block touch its diagonal (masked variant); pairs of steps keep the A / B accumulator roles fixed
@@ -1069,234 +837,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv3_kernel(const bf16_t* __r
 #undef DKV_STEP
 #undef DKV_WAIT
 #undef DKV_BARRIER
-
-  if constexpr (DBG == 6) {
-    if (tid == 0) {
-      float* dbgp = (float*)(dqkv + ((int64_t)b * S + key0) * ld3 + d + hh * HD);
-      dbgp[0] = (float)tA; dbgp[1] = (float)tB; dbgp[2] = (float)tW; dbgp[3] = (float)(__builtin_readcyclecounter() - t00); dbgp[4] = (float)nsteps; dbgp[5] = (float)(__builtin_amdgcn_s_memrealtime() - r00);
-    }
-    return;
-  }
-  if (krow < S) {
-    bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
-    bf16_t* ovp = okp + d;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int dd = dt * 32 + 8 * q4 + 4 * h;
-        *(u32x2*)(okp + dd) = u32x2{pack2bf(dk[dt][4 * q4], dk[dt][4 * q4 + 1]), pack2bf(dk[dt][4 * q4 + 2], dk[dt][4 * q4 + 3])};
-        *(u32x2*)(ovp + dd) = u32x2{pack2bf(dv[dt][4 * q4], dv[dt][4 * q4 + 1]), pack2bf(dv[dt][4 * q4 + 2], dv[dt][4 * q4 + 3])};
-      }
-  }
-}
-
-// ---- dK/dV kernel v4: two blocks per CU --------------------------------------------------------------------------
-// Measured on v3 (cycle counters per phase, profiles/r02_attn_dkv_phases.log): a wave's instruction stream does not overlap
-// with its own MFMAs -- the time of a step is the SUM of its MFMA passes (32 x 32 cycles), VALU, LDS-issue and DMA-issue
-// cycles, whatever their order -- so one wave per SIMD cannot get past ~50 % MFMA occupancy however it is pipelined.
-// v4 makes room for a SECOND block per CU instead: <= 256 registers per wave (run-time stage index: no per-stage address
-// sets hoisted out of the loop; S / dP live only until the softmax; shallow fragment rings -- the co-resident block covers
-// the latencies) and 65 KiB of LDS (resident V tile + a 2-stage Q / dO / stats ring).  Phases of a step run one after the
-// other; the DMA of the next tile is issued between the MFMAs of the dV / dK phase.
-struct St4 {
-  f32x4 v[4];
-};
-__device__ __forceinline__ void st4_issue(St4& f, unsigned a) {   // (l2, delta) pairs of 8 of this lane's 16 query rows
-  asm volatile(
-      "ds_read_b128 %0, %4\n\t"
-      "ds_read_b128 %1, %4 offset:16\n\t"
-      "ds_read_b128 %2, %4 offset:64\n\t"
-      "ds_read_b128 %3, %4 offset:80"
-      : "=&v"(f.v[0]), "=&v"(f.v[1]), "=&v"(f.v[2]), "=&v"(f.v[3])
-      : "v"(a)
-      : "memory");
-}
-template <int N>
-__device__ __forceinline__ void st4_wait(St4& f) {
-  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]) : "n"(N) : "memory");
-}
-#define DKV4_LDS (32768 + 2 * DKV_STAGE)
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv4_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                               const float* __restrict__ stats /* [B,H,S,2] (lse * log2 e, delta) */,
-                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 2 x DKV_STAGE
-  const int d = H * HD, ld3 = 3 * d;
-  int ktile, bh;
-  attn_block(remap, ktile, bh);
-  const int b = bh / H, hh = bh % H;
-  const int key0 = ktile * 128;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
-  const int krow = key0 + wid * 32 + r;
-  const int krow_c = krow < S ? krow : S - 1;
-  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
-  const bf16_t* kb = qb + d;
-  const bf16_t* vb = qb + 2 * d;
-  const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
-
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(((int64_t)(S - 1) * d + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)vb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rst = __builtin_amdgcn_make_buffer_rsrc((void*)(stats + (int64_t)bh * S * 2), 0, S * 8, 0x00020000);
-
-  bf16x8 kf[8];
-#pragma unroll
-  for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const bf16x8*)(kb + (int64_t)krow_c * ld3 + 16 * kk + 8 * h);
-
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {   // resident V tile; rows past S clamp (their keys are never stored)
-    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
-    int gr = key0 + row;
-    gr = gr < S ? gr : S - 1;
-    dma16(rv, sm + (wid * 64 + 256 * i) * 16, (gr * ld3 + 8 * (pc ^ swz(row))) * 2);
-  }
-  int voq[2], vod[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
-    voq[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
-    vod[i] = (row * d + 8 * (pc ^ swz(row))) * 2;
-  }
-  auto stage_q = [&](int st, int q0, int i) {   // half of a stage's Q + dO chunks
-    char* base = sm + 32768 + st * DKV_STAGE;
-    dma16(rq, base + (wid * 64 + 256 * i) * 16, voq[i] + q0 * ld3 * 2);
-    dma16(rdo, base + 8192 + (wid * 64 + 256 * i) * 16, vod[i] + q0 * d * 2);
-  };
-  auto stage_st = [&](int st, int q0) {         // 32 (l2, delta) pairs; every wave (identical bytes): uniform DMA count
-    dma4(rst, sm + 32768 + st * DKV_STAGE + 16384, (q0 * 2 + lane) * 4);
-  };
-  // Fragment addresses are rebuilt per use with one v_xad_u32 each ((const ^ lane swizzle) + lane base) instead of being
-  // kept in 24 registers: the 16-B chunk index of a row is XOR-ed with swz(row) on the DMA source side.
-  //   natural A operand (Q / dO / V rows): row r, chunk (2kk+h) ^ swz(r)           -> (32kk ^ nsw) + base
-  //   transposed A operand: rows 16 s2 + 4h + (l16>>2) + 8 w2, chunk (4dt + c2) ^ swz(row) -> (64dt ^ tsw) + base + 2048 w2
-  const unsigned nsw = (unsigned)((h ^ swz(r)) << 4);             // (2kk + h) ^ swz = 2kk ^ (h ^ swz): 2kk is even, h only touches bit 0
-  const unsigned nbase = lds0 + 32768 + r * 256;
-  const unsigned vbase = lds0 + wid * 8192 + r * 256;
-  const int trow = 4 * h + (l16 >> 2);
-  const int c2 = 2 * (g4 & 1) + ((l16 & 3) >> 1);
-  const unsigned tsw = (unsigned)((c2 ^ swz(trow)) << 4);        // swz(trow + 8) = swz(trow) ^ 2: folded into the constant below
-  const unsigned tbase = lds0 + 32768 + trow * 256 + 8 * (l16 & 1);
-  auto nat_addr = [&](int kk, unsigned base) { return ((unsigned)(kk << 5) ^ nsw) + base; };
-  auto tr_addr = [&](int dt, int w2, unsigned base) { return ((unsigned)((dt << 6) ^ (w2 ? 32 : 0)) ^ tsw) + base + (w2 ? 2048u : 0u); };
-  auto tr4_issue_at = [&](Tr4& f, unsigned base) {
-    tr4_issue(f, tr_addr(0, 0, base), tr_addr(0, 1, base), tr_addr(1, 0, base), tr_addr(1, 1, base), tr_addr(2, 0, base), tr_addr(2, 1, base),
-              tr_addr(3, 0, base), tr_addr(3, 1, base));
-  };
-
-  f32x16 dv[4], dk[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dv[i][e] = dk[i][e] = 0.f;
-
-  const int nqi = (S + 31) / 32;
-  const int qi0 = key0 / 32;
-  const int nsteps = nqi - qi0;
-
-  // softmax + dS of the accumulator-element pair (2i, 2i+1) -> bf16 pairs (the MFMA B operands of the dV / dK products).
-  // MASK: only the four tiles that touch the block's diagonal need the causal predicate.  Rows past S need none: their
-  // Q / dO rows and stats read as zeros (buffer bounds), so dS = 0 and P multiplies a zero dO row.
-  auto softmax_pair = [&](auto mask_c, int i, const f32x4 sv, const f32x16& s, const f32x16& dp, int kd, unsigned* pw, unsigned* dw) {
-    constexpr bool MASK = decltype(mask_c)::value;
-    const int g = i >> 1;
-    float x0 = __builtin_fmaf(s[2 * i], LOG2E_F, -sv[0]);
-    float x1 = __builtin_fmaf(s[2 * i + 1], LOG2E_F, -sv[2]);
-    if constexpr (MASK) {
-      x0 = (kd > 8 * g + 2 * (i & 1)) ? -INFINITY : x0;   // key > query
-      x1 = (kd > 8 * g + 2 * (i & 1) + 1) ? -INFINITY : x1;
-    }
-    const float p0 = __builtin_amdgcn_exp2f(x0), p1 = __builtin_amdgcn_exp2f(x1);
-    const float q0 = p0 * (dp[2 * i] - sv[1]), q1 = p1 * (dp[2 * i + 1] - sv[3]);
-    pw[i] = pack2bf(p0, p1);
-    dw[i] = pack2bf(q0, q1);
-  };
-  // One step = tile qi in stage slot st; every wave works on every tile (tiles above a wave's diagonal contribute exact zeros
-  // through the mask: the steps are barrier-synchronised, skipping would not shorten the block).
-  auto step = [&](int st, int qi, bool do_dma, auto mask_c) {
-    unsigned so = st * DKV_STAGE;
-    asm volatile("" : "+s"(so));   // opaque: otherwise the loop is unrolled by the ring period and every per-stage fragment
-                                   // address (2 x ~50 VGPRs) is hoisted out of it
-    f32x16 s, dp;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
-    {
-      const unsigned qbase = nbase + so;
-      Fr3 F;   // one operand triple: the next one is issued into the same registers right behind the MFMAs that read it (they
-               // take their sources at issue, the LDS data returns >= 64 cycles later); the co-resident block covers the wait
-      fr3_issue<0>(F, nat_addr(0, qbase), nat_addr(0, vbase));
-#pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        fr3_wait<0>(F);
-        const bf16x8 fq = __builtin_bit_cast(bf16x8, F.q), fd = __builtin_bit_cast(bf16x8, F.d), fv = __builtin_bit_cast(bf16x8, F.v);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq, kf[kk], s, 0, 0, 0);    // S[q][key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fd, fv, dp, 0, 0, 0);      // dP[q][key]
-        if (kk + 1 < 8) fr3_issue<0>(F, nat_addr(kk + 1, qbase), nat_addr(kk + 1, vbase));
-      }
-    }
-    unsigned pw[8], dw[8];
-    {
-      const int kd = krow - 32 * qi - 4 * h;   // key - (first query row of this lane in the tile)
-      const unsigned sa = lds0 + 32768 + so + 16384 + 32 * h;
-      St4 s4;   // 8 rows at a time (the co-resident block covers the second fetch)
-      st4_issue(s4, sa);
-      st4_wait<0>(s4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) softmax_pair(mask_c, i, s4.v[i], s, dp, kd, pw, dw);
-      asm volatile("" : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]), "+v"(dw[0]), "+v"(dw[1]), "+v"(dw[2]), "+v"(dw[3]));
-      st4_issue(s4, sa + 128);
-      st4_wait<0>(s4);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) softmax_pair(mask_c, 4 + i, s4.v[i], s, dp, kd, pw, dw);
-    }
-    bf16x8 pb[2], dsb[2];
-    pb[0] = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
-    pb[1] = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
-    dsb[0] = __builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]});
-    dsb[1] = __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]});
-    // dV / dK: 16 MFMAs; the DMA of the next tile (other stage slot) is issued in between
-    const int stn = st ^ 1, qn = 32 * (qi + 1);
-    Tr4 ta, tb;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      const unsigned o = tbase + so + s2 * 4096;
-      if (s2 == 0) tr4_issue_at(ta, o + 8192);
-      tr4_issue_at(tb, o);
-      tr4_wait8(ta, tb);   // dO^T fragments in, Q^T still in flight
-      dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(ta.a0, ta.a1), pb[s2], dv[0], 0, 0, 0);   // dV^T[d][key]
-      dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(ta.b0, ta.b1), pb[s2], dv[1], 0, 0, 0);
-      if (do_dma) stage_q(stn, qn, s2);
-      dv[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(ta.c0, ta.c1), pb[s2], dv[2], 0, 0, 0);
-      dv[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(ta.d0, ta.d1), pb[s2], dv[3], 0, 0, 0);
-      tr4_wait(tb);
-      if (s2 == 0) {
-        tr4_issue_at(ta, o + 8192 + 4096);
-      } else if (do_dma) stage_st(stn, qn);
-      dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tb.a0, tb.a1), dsb[s2], dk[0], 0, 0, 0);    // dK^T[d][key]
-      dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tb.b0, tb.b1), dsb[s2], dk[1], 0, 0, 0);
-      dk[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tb.c0, tb.c1), dsb[s2], dk[2], 0, 0, 0);
-      dk[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tb.d0, tb.d1), dsb[s2], dk[3], 0, 0, 0);
-    }
-  };
-
-  // 2-stage ring: the loads of tile t+1 are issued inside step t (into the slot tile t-1 left at the previous barrier);
-  // one barrier per step: everyone's part of tile t+1 has landed and everyone is done reading tile t.
-  if (nsteps > 0) { stage_q(0, 32 * qi0, 0); stage_q(0, 32 * qi0, 1); stage_st(0, 32 * qi0); }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int t = 0;
-  for (; t < 4 && t < nsteps; ++t) {   // tiles 0..3 touch the block's diagonal (separate loops: one body with both
-    step(t & 1, qi0 + t, t + 1 < nsteps, std::true_type{});   // variants behind a branch costs ~100 more registers)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-  for (; t < nsteps; ++t) {
-    step(t & 1, qi0 + t, t + 1 < nsteps, std::false_type{});
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
 
   if (krow < S) {
     bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
@@ -1324,28 +864,11 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV4_LDS);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv3_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     attr_done = true;
   }
   attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dq");
-#define DKV3_LAUNCH(D) attn_bwd_dkv3_kernel<D><<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd)
-  if (g_opt_attn_dkv == 1) DKV3_LAUNCH(0);
-  else if (g_opt_attn_dkv == 2) DKV3_LAUNCH(1);
-  else if (g_opt_attn_dkv == 3) DKV3_LAUNCH(2);
-  else if (g_opt_attn_dkv == 4) DKV3_LAUNCH(3);
-  else if (g_opt_attn_dkv == 5) DKV3_LAUNCH(4);
-  else if (g_opt_attn_dkv == 6) DKV3_LAUNCH(5);
-  else if (g_opt_attn_dkv == 7) DKV3_LAUNCH(6);
-  else if (g_opt_attn_dkv == 8) attn_bwd_dkv4_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), DKV4_LDS, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
-  else attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
+  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
 }

@@ -25,7 +25,6 @@
 
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
 static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (long K, whole residencies), 2 always (tests)
-int g_opt_attn_dkv = 1;          // attention dK/dV kernel: 0 = v2, 1 = v3 (software-pipelined)
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn8 = 1;        // 256x256 weight-gradient tile (8 waves): 0 never, 1 auto (few tiles, many row splits), 2 always (tests)
 static int g_opt_tn8_max_tiles = 16;   // auto mode: use the 256x256 weight-gradient kernel below this many tiles (A/B hook)
@@ -39,7 +38,6 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "tn8")) return g_opt_tn8;
   if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
-  if (!strcmp(name, "attn_dkv")) return g_opt_attn_dkv;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
@@ -49,7 +47,6 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
   if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
-  if (!strcmp(name, "attn_dkv")) { g_opt_attn_dkv = value; return 0; }
   return -1;
 }
 
