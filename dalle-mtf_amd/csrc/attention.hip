@@ -164,36 +164,45 @@ __device__ __forceinline__ void fr3_wait(Fr3& f) {
 }
 
 extern int g_opt_attn_xcd;
-// (tile, batch*head) of this block.  remap = 0: plain grid order.  remap = G >= 1: hardware block b (dispatched to XCD
-// b % 8) takes the b-th entry of a per-XCD contiguous range of the sequence below, so the tiles of one (batch, head)
-// share that XCD's L2 copy of K/V/Q/dO; inside the range, groups of G (batch, head) pairs are visited tile-major
-// (all G heaviest tiles, then the next heaviest, ...): causal tiles differ 10:1 in work, and longest-first dispatch over
-// a group of 8 cuts the list-scheduling tail from ~+45 % (fwd/dQ, 2 blocks/CU) / +20 % (dK/dV) of the ideal makespan to
-// ~+9 % / +2 % (simulated for 16 pairs x 10 tiles per XCD) while the group's working set still cycles through L2.
-__device__ __forceinline__ void attn_block(int remap, int& tile, int& bh) {
-  if (!remap) { tile = blockIdx.x; bh = blockIdx.y; return; }
-  const int T = gridDim.x, BH = gridDim.y;
-  const int n = T * BH, L = blockIdx.x + blockIdx.y * T;
-  const int xcd = L & 7, idx = L >> 3, q = n >> 3, r = n & 7;
-  const int P = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int G = remap;
-  const int grp = P / (G * T), base = grp * G;
-  const int gg = (BH - base < G) ? BH - base : G;
-  const int in_g = P - grp * G * T;
-  tile = in_g / gg;
-  bh = base + in_g % gg;
+// Persistent-block schedule: the grid is one (dK/dV) or two (forward, dQ) blocks per CU; hardware block L (dispatched to XCD L % 8) owns
+// bin k = L / 8 of its XCD.  The XCD's work items -- (tile, batch*head) for its contiguous eighth of the (batch, head) pairs,
+// sorted heaviest tile first -- are dealt to the bins in serpentine order (round 0: bins 0..P-1, round 1: P-1..0, ...): with
+// causal tiles of 40, 36, ..., 4 steps and 16 pairs per XCD every bin gets 108 or 112 steps, there are no block launch gaps
+// (measured: a CU's five blocks summed to 114 us inside a 160 us kernel) and no atomics.  perxcd = 0 (option attn_xcd = 0, or
+// shapes that do not divide by 8): one serpentine over all blocks.
+struct AttnSched {
+  int nbh, bh_lo, P, k, nitems;
+};
+__device__ __forceinline__ AttnSched attn_sched(int T, int BH, int perxcd) {
+  AttnSched s;
+  const int L = blockIdx.x, G = gridDim.x;
+  if (perxcd) { s.nbh = BH >> 3; s.bh_lo = (L & 7) * s.nbh; s.P = G >> 3; s.k = L >> 3; }
+  else { s.nbh = BH; s.bh_lo = 0; s.P = G; s.k = L; }
+  s.nitems = T * s.nbh;
+  return s;
+}
+__device__ __forceinline__ bool attn_item(const AttnSched& s, int r, int& tile, int& bh) {
+  const int j = (r & 1) ? (r + 1) * s.P - 1 - s.k : r * s.P + s.k;   // increasing in r: the first miss ends the block
+  if (j >= s.nitems) return false;
+  tile = j / s.nbh;
+  bh = s.bh_lo + j - tile * s.nbh;
+  return true;
 }
 #define QK_STAGE 32768  // K 16384 | V 16384
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                          float* __restrict__ lse, int B, int H, int S, int remap) {
+                                                          float* __restrict__ lse, int B, int H, int S, int perxcd) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
+  const int T = (S + 127) / 128;
+  const AttnSched sched = attn_sched(T, B * H, perxcd);
   int tile_, bh;
-  attn_block(remap, tile_, bh);
-  const int qt = gridDim.x - 1 - tile_;  // heaviest (latest) query tiles first
+  for (int round = 0; attn_item(sched, round, tile_, bh); ++round) {   // persistent: two blocks per CU walk their item lists
+  const int qt = T - 1 - tile_;  // heaviest (latest) query tiles first
   const int b = bh / H, hh = bh % H;
   const int q0 = qt * 128;
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque per item (see attn_bwd_dkv_kernel)
+  const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
   const int qrow = q0 + wid * 32 + r;
@@ -355,6 +364,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
       }
     if (h == 0) lse[(int64_t)bh * S + qrow] = m + __logf(l);
   }
+  __syncthreads();   // the last step's LDS reads are done before the next item's first DMA
+  }   // items
+}
+
+static int attn_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
+    else n = 256;
+  }
+  return n;
 }
 
 extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int H, int S, void* stream) {
@@ -363,7 +385,12 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_fwd: sequence too long for 32-bit buffer offsets");
   static bool attr_done = false;
   if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE); attr_done = true; }
-  attn_fwd_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, g_opt_attn_xcd);
+  {
+    const int items = ((S + 127) / 128) * B * H;
+    const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
+    const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
+    attn_fwd_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd);
+  }
   DMI_CHECK_LAUNCH("attention_fwd");
   return DMI_OK;
 }
@@ -379,15 +406,19 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, float* __restrict__ stats,
-                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
+                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
+  const int T = (S + 127) / 128;
+  const AttnSched sched = attn_sched(T, B * H, perxcd);
   int tile_, bh;
-  attn_block(remap, tile_, bh);
-  const int qt = gridDim.x - 1 - tile_;
+  for (int round = 0; attn_item(sched, round, tile_, bh); ++round) {   // persistent: two blocks per CU walk their item lists
+  const int qt = T - 1 - tile_;
   const int b = bh / H, hh = bh % H;
   const int q0 = qt * 128;
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque per item (see attn_bwd_dkv_kernel)
+  const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
   const int qrow = q0 + wid * 32 + r;
@@ -537,6 +568,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         *(u32x2*)(op + dd) = u32x2{pack2bf(dq[dt][4 * q4], dq[dt][4 * q4 + 1]), pack2bf(dq[dt][4 * q4 + 2], dq[dt][4 * q4 + 3])};
       }
   }
+  __syncthreads();   // the last step's LDS reads are done before the next item's first DMA
+  }   // items
 }
 
 // ---- dK/dV kernel ---------------------------------------------------------------------------------------------------
@@ -583,14 +616,20 @@ __device__ __forceinline__ void st8_wait(St8& f) {
 }
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ stats /* [B,H,S,2] (lse * log2 e, delta) */,
-                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int remap) {
+                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
   const int d = H * HD, ld3 = 3 * d;
+  const AttnSched sched = attn_sched((S + 127) / 128, B * H, perxcd);
   int ktile, bh;
-  attn_block(remap, ktile, bh);
+  // persistent loop over this block's work items; every step of an item ends with a barrier, so the next item may overwrite
+  // the LDS straight away
+  for (int round = 0; attn_item(sched, round, ktile, bh); ++round) {
   const int b = bh / H, hh = bh % H;
   const int key0 = ktile * 128;
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque per item: otherwise every lane constant of the body (fragment offsets, DMA offsets, ...)
+                                  // is hoisted out of the item loop and stays live across it -- 716 B/lane of spills measured
+  const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
   const int krow = key0 + wid * 32 + r;
@@ -850,6 +889,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
         *(u32x2*)(ovp + dd) = u32x2{pack2bf(dv[dt][4 * q4], dv[dt][4 * q4 + 1]), pack2bf(dv[dt][4 * q4 + 2], dv[dt][4 * q4 + 3])};
       }
   }
+  }   // items
 }
 
 extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta,
@@ -866,9 +906,18 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     attr_done = true;
   }
-  attn_bwd_dq_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, g_opt_attn_xcd);
+  const int items = ((S + 127) / 128) * B * H;
+  {
+    const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
+    const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
+    attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd);
+  }
   DMI_CHECK_LAUNCH("attention_bwd_dq");
-  attn_bwd_dkv_kernel<<<dim3((S + 127) / 128, B * H), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, g_opt_attn_xcd);
+  {
+    const int grid = items < attn_num_cus() ? items : attn_num_cus();   // one persistent block per CU
+    const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
+    attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd);
+  }
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
 }
