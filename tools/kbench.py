@@ -136,6 +136,9 @@ def bench_head(M, K, V):
 
 if __name__ == "__main__":
     what = set(sys.argv[1:]) or {"nt", "tn", "attn", "head"}
+    for kv in os.environ.get("KB_OPTIONS", "").split(","):   # e.g. KB_OPTIONS=nt4_stages=2,tn8=0
+        if "=" in kv:
+            dh.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     M, d = 40960, 512
     if "nt" in what:
         both = (("nt2", 0), ("nt4", 2))
