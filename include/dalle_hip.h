@@ -29,8 +29,9 @@ typedef enum {
 const char* dmi_last_error_string(void);
 int dmi_version(void);
 /* Test hooks (every setting computes the same results): "nt4" 0/1/2 = never / auto / always use the 256x128 NT tile,
- * "tn_tail" 0/1 = row-split the ragged last residency of unsplit weight gradients, "attn_xcd" G = attention block order
- * (0 plain grid, G >= 1 per-XCD ranges in groups of G (batch, head) pairs).  Unknown name -> -1. */
+ * "nt8" / "tn8" 0/1/2 = the 256x256 8-wave NT / weight-gradient tiles, "tn_tail" 0/1 = row-split the ragged last residency of
+ * unsplit weight gradients, "attn_xcd" = schedule of the persistent attention blocks (0: one serpentine over all blocks,
+ * != 0: per-XCD item lists when the (batch, head) count divides by 8).  Unknown name -> -1. */
 int dmi_get_option(const char* name);
 int dmi_set_option(const char* name, int value);
 /* Diagnostics (tools/phases.py): u64 device buffer [blocks][5 or 8] that the 256x128 NT kernel and the weight-gradient

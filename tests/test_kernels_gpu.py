@@ -473,8 +473,20 @@ def test_transpose_batch_and_fast_sums():
 @pytest.mark.parametrize("xcd", [8, 1, 0, 3])
 @pytest.mark.parametrize("B,H,S", [(1, 1, 128), (2, 2, 272), (1, 2, 384), (1, 1, 72), (3, 1, 384), (5, 2, 200)])
 def test_attention_fwd_bwd(B, H, S, xcd):
-    """xcd = G >= 1: per-XCD block ranges, groups of G (batch, head) pairs visited heaviest-tile-first (default 8);
-    0: plain grid order.  Grids of 9 and 20 blocks exercise uneven per-XCD ranges and partial groups."""
+    """persistent attention blocks; attn_xcd != 0: per-XCD item lists when the (batch, head) count divides by 8 (default),
+    0 (or any other count): one serpentine over all blocks.  These grids are smaller than the chip: one item per block."""
+    dh.set_option("attn_xcd", xcd)
+    try:
+        _attention_fwd_bwd(B, H, S)
+    finally:
+        dh.set_option("attn_xcd", 8)
+
+
+@pytest.mark.parametrize("xcd", [8, 0])
+@pytest.mark.parametrize("B,H,S", [(4, 2, 272), (8, 8, 1152)])
+def test_attention_persistent_schedules(B, H, S, xcd):
+    """(batch, head) counts that divide by 8 (per-XCD item lists) and, at (8, 8, 1152), 576 items: more than the 256 dK/dV
+    / 512 forward and dQ blocks of the chip, so every block walks several rounds of its serpentine list."""
     dh.set_option("attn_xcd", xcd)
     try:
         _attention_fwd_bwd(B, H, S)
