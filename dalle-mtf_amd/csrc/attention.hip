@@ -91,6 +91,22 @@ __device__ __forceinline__ void tr4_issue(Tr4& f, unsigned lo0, unsigned hi0, un
       : "v"(lo0), "v"(hi0), "v"(lo1), "v"(hi1), "v"(lo2), "v"(hi2), "v"(lo3), "v"(hi3)
       : "memory");
 }
+// the same eight reads at a compile-time byte offset from eight per-step base addresses (no address VALU per fragment set)
+template <int OFF>
+__device__ __forceinline__ void tr4_issue_off(Tr4& f, const unsigned (&a)[8]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %1, %9 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %2, %10 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %3, %11 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %4, %12 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %5, %13 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %6, %14 offset:%16\n\t"
+      "ds_read_b64_tr_b16 %7, %15 offset:%16"
+      : "=&v"(f.a0), "=&v"(f.a1), "=&v"(f.b0), "=&v"(f.b1), "=&v"(f.c0), "=&v"(f.c1), "=&v"(f.d0), "=&v"(f.d1)
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "i"(OFF)
+      : "memory");
+}
 __device__ __forceinline__ void tr4_wait(Tr4& f) {
   asm volatile("s_waitcnt lgkmcnt(0)"
                : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.c0), "+v"(f.c1), "+v"(f.d0), "+v"(f.d1)
@@ -756,9 +772,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
     constexpr bool has_next = decltype(has_next_c)::value;
     const unsigned lb = lds0 + 32768 + st * DKV_STAGE;
     const unsigned so = ((st + 1) & 3) * DKV_STAGE;
-    tr4_issue(tdo, lb + 8192 + oft[0][0], lb + 8192 + oft[0][1], lb + 8192 + oft[1][0], lb + 8192 + oft[1][1],
-              lb + 8192 + oft[2][0], lb + 8192 + oft[2][1], lb + 8192 + oft[3][0], lb + 8192 + oft[3][1]);
-    tr4_issue(tq, lb + oft[0][0], lb + oft[0][1], lb + oft[1][0], lb + oft[1][1], lb + oft[2][0], lb + oft[2][1], lb + oft[3][0], lb + oft[3][1]);
+    // eight transposed-fragment base addresses of this slot; the four fragment sets of a step (dO^T / Q^T x first / second 16
+    // queries) are immediate offsets from them
+    const unsigned ta[8] = {lb + oft[0][0], lb + oft[0][1], lb + oft[1][0], lb + oft[1][1], lb + oft[2][0], lb + oft[2][1], lb + oft[3][0], lb + oft[3][1]};
+    tr4_issue_off<8192>(tdo, ta);
+    tr4_issue_off<0>(tq, ta);
     unsigned pw[8], dw[8];
     const int kd = krow - 32 * qi - 4 * h;   // key - (first query row of this lane in the tile)
     if constexpr (has_next) {
@@ -803,16 +821,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
     const int st3 = (st + 3) & 3, q3 = 32 * (qi + 3);
     Tr4 t2;
     {
-      const unsigned o2 = lb + 8192 + 4096, o1 = lb + 4096;
       tr4_wait(tq);   // (tdo, tq) of the first 16 queries
-      tr4_issue(t2, o2 + oft[0][0], o2 + oft[0][1], o2 + oft[1][0], o2 + oft[1][1], o2 + oft[2][0], o2 + oft[2][1], o2 + oft[3][0], o2 + oft[3][1]);
+      tr4_issue_off<8192 + 4096>(t2, ta);
       dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.a0, tdo.a1), pb[0], dv[0], 0, 0, 0);   // dV^T[d][key]
       dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.b0, tdo.b1), pb[0], dv[1], 0, 0, 0);
       if (do_dma) stage_q(st3, q3, 0);
       dv[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.c0, tdo.c1), pb[0], dv[2], 0, 0, 0);
       dv[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.d0, tdo.d1), pb[0], dv[3], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      tr4_issue(tdo, o1 + oft[0][0], o1 + oft[0][1], o1 + oft[1][0], o1 + oft[1][1], o1 + oft[2][0], o1 + oft[2][1], o1 + oft[3][0], o1 + oft[3][1]);   // Q^T, second 16
+      tr4_issue_off<4096>(tdo, ta);   // Q^T, second 16
       dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.a0, tq.a1), dsb[0], dk[0], 0, 0, 0);    // dK^T[d][key]
       dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.b0, tq.b1), dsb[0], dk[1], 0, 0, 0);
       if (do_dma) stage_q(st3, q3, 1);
