@@ -41,6 +41,10 @@ def lib():
                 "There is no CPU fallback for the product path.")
         _lib = ctypes.CDLL(LIB_PATH)
         _declare(_lib)
+        for kv in os.environ.get("DALLE_HIP_OPTIONS", "").split(","):   # A/B hook: e.g. DALLE_HIP_OPTIONS=tn8=0,attn_xcd=0
+            if "=" in kv:
+                if _lib.dmi_set_option(kv.split("=")[0].strip().encode(), int(kv.split("=")[1])) != 0:
+                    raise DalleHipError(f"DALLE_HIP_OPTIONS: unknown option {kv!r}")
     return _lib
 
 
