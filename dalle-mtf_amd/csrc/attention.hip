@@ -782,18 +782,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
     if constexpr (has_next) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) sn[e] = dpn[e] = 0.f;
-      Fr3 F[4];   // operand triples three k-steps ahead of the MFMAs (9 reads in flight: LDS latency x bandwidth)
+      Fr3 F[2];   // one operand triple ahead of the MFMAs, issued right after the wait for the current one: the two MFMAs + the
+                  // softmax pair of a k-step cover the read; deeper rings (2, 3 triples ahead) measured the same or 1 % slower
       fr3_issue<0>(F[0], aq[0] + so, aq[0] + vrel);
-      fr3_issue<0>(F[1], aq[1] + so, aq[1] + vrel);
-      fr3_issue<0>(F[2], aq[2] + so, aq[2] + vrel);
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
-        Fr3& c = F[kk & 3];
-        if (kk == 0) fr3_wait<6>(c);
-        else if (kk < 6) fr3_wait<6>(c, F[(kk + 3) & 3]);
-        else if (kk == 6) fr3_wait<3>(c, F[(kk + 3) & 3]);
-        else fr3_wait<0>(c, F[(kk + 3) & 3]);
-        if (kk + 3 < 8) fr3_issue<0>(F[(kk + 3) & 3], aq[kk + 3] + so, aq[kk + 3] + vrel);
+        Fr3& c = F[kk & 1];
+        if (kk == 0) fr3_wait<0>(c); else fr3_wait<0>(c, F[(kk + 1) & 1]);
+        if (kk + 1 < 8) fr3_issue<0>(F[(kk + 1) & 1], aq[kk + 1] + so, aq[kk + 1] + vrel);
         sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.q), kf[kk], sn, 0, 0, 0);
         dpn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.d), __builtin_bit_cast(bf16x8, c.v), dpn, 0, 0, 0);
         softmax_pair(mask_c, kk, stt, s, dp, kd, pw, dw);
