@@ -55,6 +55,7 @@ def _declare(L):
         "dmi_version": (I, []),
         "dmi_get_option": (I, [c_char_p]),
         "dmi_set_option": (I, [c_char_p, I]),
+        "dmi_set_debug_buffer": (I, [P]),
         "dmi_embed_fwd": (I, [P, P, P, P, L64, I, I, I, P]),
         "dmi_sort_tokens_workspace_bytes": (L64, [L64]),
         "dmi_sort_tokens": (I, [P, P, P, L64, I, P, P]),
