@@ -32,13 +32,22 @@ def init_comm(world: int, rank: int, pg=None) -> Optional[int]:
     import torch.distributed as dist
     box = [dh.comm_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(box, src=0, group=pg)
+    handle, err = None, None
     try:
-        return dh.comm_init(world, rank, box[0])
+        handle = dh.comm_init(world, rank, box[0])
     except dh.DalleHipError as e:   # surfaced, not swallowed: the caller logs which transport runs
         if os.environ.get("DALLE_DP_STRICT") == "1":
             raise
-        print(f"[dp] RCCL communicator not available ({e}); falling back to torch.distributed", flush=True)
-        return None
+        err = e
+    # every rank must end up on the same transport: agree over the CPU side of the process group
+    ok = torch.tensor([1 if handle else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
+    if int(ok.item()) == 1:
+        return handle
+    if handle:
+        dh.comm_destroy(handle)
+    print(f"[dp] rank {rank}: RCCL communicator not available on every rank ({err}); falling back to torch.distributed", flush=True)
+    return None
 
 
 _SETUP = {}

@@ -103,3 +103,34 @@ def test_optimizer_never_starts_before_the_exchange_is_joined():
     src = inspect.getsource(DiscreteVAE.optimizer_step)
     body = src[src.index('"""', src.index('"""') + 3) + 3:]
     assert body.strip().startswith("self.reducer.finish()"), body[:80]
+
+
+def _agree_worker(rank, world, init_file, out_file):
+    """rank 0's RCCL communicator comes up, rank 1's does not: both must end on the torch transport (and rank 0 must give
+    its communicator back) -- a split decision would hang the first collective."""
+    import dalle_hip as dh
+    from src import dp
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    calls = {"destroyed": []}
+
+    def fake_init(world_, rank_, uid):
+        assert uid == b"uid-from-rank-0"
+        if rank_ == 1:
+            raise dh.DalleHipError("comm_init: simulated failure on rank 1")
+        return 4242
+
+    dh.comm_unique_id = lambda: b"uid-from-rank-0"
+    dh.comm_init = fake_init
+    dh.comm_destroy = lambda h: calls["destroyed"].append(h)
+    handle = dp.init_comm(world, rank, dist.group.WORLD)
+    torch.save({"handle": handle, "destroyed": calls["destroyed"]}, f"{out_file}.{rank}")
+    dist.destroy_process_group()
+
+
+def test_transport_choice_is_collective():
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out")
+        mp.spawn(_agree_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        r0, r1 = torch.load(f"{out_file}.0"), torch.load(f"{out_file}.1")
+        assert r0["handle"] is None and r1["handle"] is None
+        assert r0["destroyed"] == [4242] and r1["destroyed"] == []
