@@ -150,6 +150,9 @@ def setup_dist(args):
         from src import dp
         pg = dp.init_process_group(local_rank)
         _, _, pg, comm = dp.dist_setup()
+        # one GPU per rank = the measured product path: the exchange must be RCCL behind the C ABI (dp.init_comm raises on
+        # every rank when it cannot be -- DALLE_DP_STRICT defaults to 1); only the shared-GPU test mode runs on gloo
+        assert share or comm, "bench.py --gpus N: the gradient exchange must run on RCCL (dmi_allreduce_bucket), not a fallback"
     return world, rank, pg, comm
 
 

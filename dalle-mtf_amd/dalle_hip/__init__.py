@@ -112,6 +112,7 @@ def _declare(L):
         "dmi_conv2d_f32": (I, [P, I, I, I, I, I, I, I, I, P, P, P, P, P, P, I, I, P]),
         "dmi_space_to_depth_f32": (I, [P, P, I, I, I, I, I, I, P]),
         "dmi_depth_to_space_f32": (I, [P, P, I, I, I, I, I, I, P]),
+        "dmi_crc32c": (ctypes.c_uint32, [c_char_p, ctypes.c_size_t]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -6,13 +6,15 @@ their gradients are final, on a side HIP stream that an event orders after the b
 wait for the side stream.  Two transports:
   * "rccl"  -- RCCL over xGMI behind the C ABI (dmi_comm_init / dmi_allreduce_bucket, include/dalle_hip.h): the product path
                on a multi-GPU node;
-  * "torch" -- torch.distributed.all_reduce(async_op=True) on a process group: the CPU (gloo) tests, ranks sharing one GPU
-               in the GPU-box tests, and the fallback when the RCCL communicator cannot be created.
+  * "torch" -- torch.distributed.all_reduce(async_op=True) on a process group: the CPU (gloo) tests and ranks sharing one GPU
+               in the GPU-box tests (DALLE_DP_TRANSPORT=torch).  It is NOT a silent fallback: when ranks own distinct GPUs a
+               failing RCCL communicator is fatal unless DALLE_DP_STRICT=0.
 xGMI is point to point (7 links x ~153 GB/s per GPU): a ring all-reduce of the 286 MB dalle_example gradient is ~3.3 ms
 per-link bound against ~17 ms of compute per step, so the exchange hides behind backward as long as the last bucket is
 small -- hence <= 64 MB pieces, issued in the order backward finishes them."""
 from __future__ import annotations
 
+import atexit
 import os
 from typing import List, Optional, Tuple
 
@@ -23,31 +25,68 @@ import dalle_hip as dh
 MAX_BUCKET_BYTES = 64 << 20
 
 
+def agree_ok(flag: bool, pg=None) -> bool:
+    """True iff `flag` is true on EVERY rank (MIN all-reduce of a CPU scalar over the control-plane group); without a
+    process group it is just `flag`.  Used wherever one rank's local failure must not leave the others in a collective."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    ok = torch.tensor([1 if flag else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
+    return int(ok.item()) == 1
+
+
 def init_comm(world: int, rank: int, pg=None) -> Optional[int]:
     """Create this rank's RCCL communicator behind the C ABI.  The 128-byte unique id travels over the (CPU-capable)
-    torch.distributed process group, which is control plane only.  Returns the opaque handle, or None when RCCL refuses
-    (e.g. several ranks on one GPU in the tests) -- the caller then uses the "torch" transport."""
+    torch.distributed process group, which is control plane only.
+
+    Failure policy: ranks that own distinct GPUs are the product path, and there an RCCL failure is FATAL on every rank
+    (DALLE_DP_STRICT defaults to 1) -- a silent drop to torch.distributed would hide exactly the failure the first
+    multi-GPU run has to surface.  DALLE_DP_STRICT=0 allows the collective fallback to the "torch" transport (returns None
+    on every rank).  Order of events, so that no rank can be left alone in a blocking call:
+      1. every rank binds librccl locally (dlopen + symbols), rank 0 also draws the unique id;     -> agree (MIN)
+      2. the id is broadcast;  3. every rank enters dmi_comm_init (blocking collective);            -> agree (MIN)."""
     if world <= 1:
         return None
     import torch.distributed as dist
-    box = [dh.comm_unique_id() if rank == 0 else None]
+    strict = os.environ.get("DALLE_DP_STRICT", "1") != "0"
+
+    def give_up(stage, err):
+        msg = f"[dp] rank {rank}: RCCL {stage} did not succeed on every rank (this rank: {err or 'ok'})"
+        if strict:
+            raise RuntimeError(msg + "; set DALLE_DP_STRICT=0 to fall back to torch.distributed")
+        print(msg + "; falling back to torch.distributed", flush=True)
+        return None
+
+    uid, err = None, None
+    try:
+        dh.comm_load()
+        if rank == 0:
+            uid = dh.comm_unique_id()
+    except (dh.DalleHipError, OSError) as e:
+        err = e
+    if not agree_ok(err is None, pg):
+        return give_up("library load", err)
+    box = [uid]
     dist.broadcast_object_list(box, src=0, group=pg)
-    handle, err = None, None
+    handle = None
     try:
         handle = dh.comm_init(world, rank, box[0])
-    except dh.DalleHipError as e:   # surfaced, not swallowed: the caller logs which transport runs
-        if os.environ.get("DALLE_DP_STRICT") == "1":
-            raise
+    except dh.DalleHipError as e:
         err = e
-    # every rank must end up on the same transport: agree over the CPU side of the process group
-    ok = torch.tensor([1 if handle else 0], dtype=torch.int32)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=pg)
-    if int(ok.item()) == 1:
-        return handle
-    if handle:
+    if not agree_ok(handle is not None, pg):
+        if handle:
+            dh.comm_destroy(handle)
+        return give_up("communicator init", err)
+    atexit.register(_destroy_comm, handle)
+    return handle
+
+
+def _destroy_comm(handle):
+    try:
         dh.comm_destroy(handle)
-    print(f"[dp] rank {rank}: RCCL communicator not available on every rank ({err}); falling back to torch.distributed", flush=True)
-    return None
+    except Exception:       # interpreter exit: the device context may already be gone
+        pass
 
 
 _SETUP = {}

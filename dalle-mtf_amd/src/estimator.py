@@ -48,20 +48,26 @@ class CheckpointSaverHook:
         if not self.is_chief:
             self._sync()
             return
-        os.makedirs(self.model_dir, exist_ok=True)
-        path = os.path.join(self.model_dir, f"model.ckpt-{step}.pt")
-        torch.save(self.get_state(), path + ".tmp")
-        os.replace(path + ".tmp", path)
-        ck = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
-                    key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
-        for old in ck[:-self.max_to_keep] if self.max_to_keep else []:
-            os.remove(old)
-        self._sync()
+        err = None
+        try:
+            os.makedirs(self.model_dir, exist_ok=True)
+            path = os.path.join(self.model_dir, f"model.ckpt-{step}.pt")
+            torch.save(self.get_state(), path + ".tmp")
+            os.replace(path + ".tmp", path)
+            ck = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
+                        key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
+            for old in ck[:-self.max_to_keep] if self.max_to_keep else []:
+                os.remove(old)
+        except BaseException as e:       # the other ranks are waiting in _sync(): reach it, then fail everywhere
+            err = e
+        self._sync(err)
 
-    def _sync(self):
-        """every rank leaves save() only after the chief's file is complete (readers: evaluate(), resume)"""
-        from .dp import barrier
-        barrier()
+    def _sync(self, err=None):
+        """every rank leaves save() only after the chief's file is complete (readers: evaluate(), resume); a failed write
+        on the chief (disk full, permissions) raises on EVERY rank instead of leaving the others in the barrier"""
+        from .dp import agree_ok
+        if not agree_ok(err is None):
+            raise RuntimeError(f"checkpoint save failed on the chief rank: {err!r}") from err
 
     def after_step(self, step):
         if self.save_steps and step % self.save_steps == 0:
@@ -110,18 +116,28 @@ class Estimator:
         return step
 
     def close(self):
+        """stop and JOIN the input producer (src/input_fns._Prefetch.close): every entry point calls this in a `finally`
+        (or uses the estimator as a context manager) so no producer thread is alive at interpreter exit"""
         if self._train_it is not None and hasattr(self._train_it, "close"):
             self._train_it.close()
         self._train_it = None
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def evaluate(self, input_fn, steps):
         it = iter(input_fn(self.params))
         tot = 0.0
-        for _ in range(steps):
-            features, labels = next(it)
-            spec = self.model_fn(features, labels, ModeKeys.EVAL, self.params)
-            tot += float(spec.loss)
-        if hasattr(it, "close"):
-            it.close()
+        try:
+            for _ in range(steps):
+                features, labels = next(it)
+                spec = self.model_fn(features, labels, ModeKeys.EVAL, self.params)
+                tot += float(spec.loss)
+        finally:
+            if hasattr(it, "close"):
+                it.close()          # joins the eval producer
         self._log(f"eval: mean loss {tot / max(steps, 1):.4f} over {steps} steps")
         return {"loss": tot / max(steps, 1)}

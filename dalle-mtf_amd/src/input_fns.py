@@ -3,15 +3,18 @@
 Two sources behind the reference's two entry points `dalle_input_fn` / `vae_input_fn`:
   * real data: TFRecord shards of tf.train.Example{"image": JPEG bytes, "caption": int64[]} (written by
     src/data/create_tfrecords.py:47-56) or, for the VAE, a glob of JPEG files.  Framing/proto parsing is in
-    data/tfrecord.py; JPEG decode is PIL (libjpeg, same codec family as tf.image.decode_jpeg); the reference's
+    data/tfrecord.py; JPEG decode is PIL's libjpeg (pixel-exactness against tf.image.decode_jpeg's IDCT / upsampling settings is
+    UNVERIFIED: TensorFlow cannot run here); the reference's
     tf.data graph (file shuffle -> 4-way interleave -> map -> shuffle(5*batch) -> batch(drop_remainder) -> prefetch
     -> repeat, input_fns.py:23-29,104-120) is restated as a Python generator with a decode thread pool and a
     bounded prefetch queue feeding the GPU step;
   * `synthetic*` / `gs://` paths: seeded synthetic batches of the same shapes (the bench metric's data, §8(d)).
 """
+import atexit
 import glob as _glob
 import queue
 import threading
+import weakref
 from concurrent.futures import ThreadPoolExecutor
 import io
 
@@ -140,22 +143,32 @@ def read_tfrecord(params):
     return read_fn
 
 
-def _interleave_records(files, cycle_length=4):
+def _interleave_records(files, cycle_length=4, rank=0, world=1):
     """tf.data parallel_interleave(TFRecordDataset, cycle_length=4, sloppy=False, block_length=1): round-robin one
-    record at a time over up to cycle_length open files; an exhausted file's slot is refilled with the next file."""
+    record at a time over up to cycle_length open files; an exhausted file's slot is refilled with the next file.
+    Data-parallel sharding happens HERE: element n of the interleaved stream belongs to rank n % world, and the records
+    of other ranks are seeked past without being read or CRC-checked."""
     pending = list(files)
+    n = [0]
+
+    def mine():
+        return n[0] % world == rank
+
     slots = []
     while pending and len(slots) < cycle_length:
-        slots.append(read_records(pending.pop(0)))
+        slots.append(read_records(pending.pop(0), want=mine))
     i = 0
     while slots:
         i %= len(slots)
         try:
-            yield next(slots[i])
+            rec = next(slots[i])
+            n[0] += 1
+            if rec is not None:
+                yield rec
             i += 1
         except StopIteration:
             if pending:
-                slots[i] = read_records(pending.pop(0))
+                slots[i] = read_records(pending.pop(0), want=mine)
             else:
                 slots.pop(i)
 
@@ -175,61 +188,87 @@ def _shuffle(it, buffer_size, rng):
         yield buf.pop(j)
 
 
+_LIVE_PREFETCH = weakref.WeakSet()
+
+
+def _close_live_prefetchers():
+    """atexit: a producer still running when the interpreter finalises is unwound by force (pthread_exit through C++
+    frames of torch/numpy -> std::terminate -> SIGABRT after an otherwise clean run).  atexit callbacks run before
+    finalisation freezes daemon threads, so stopping and JOINING every live producer here makes the exit clean even
+    when an entry point forgot close()."""
+    for p in list(_LIVE_PREFETCH):
+        p.close()
+
+
+atexit.register(_close_live_prefetchers)
+
+
 class _Prefetch:
-    """Bounded background producer (tf.data prefetch): decodes on a thread pool so JPEG work overlaps the GPU step."""
+    """Bounded background producer (tf.data prefetch): decodes on a thread pool so JPEG work overlaps the GPU step.
+    close() stops the producer, drains the queue and joins the thread (idempotent; also a context manager)."""
 
     def __init__(self, make_epoch, map_fn, batch, shuffle_buf, seed, workers=8, depth=4, shard=(0, 1)):
         self._q = queue.Queue(maxsize=depth)
         self._stop = threading.Event()
         self._args = (make_epoch, map_fn, batch, shuffle_buf, seed, workers, shard)
-        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t = threading.Thread(target=self._run, daemon=True, name="dalle-prefetch")
+        _LIVE_PREFETCH.add(self)
         self._t.start()
+
+    def _put(self, item):
+        """bounded put that gives up when the consumer has closed the stream"""
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def _run(self):
         make_epoch, map_fn, batch, shuffle_buf, seed, workers, (rank, world) = self._args
         rng = np.random.default_rng(seed)
+        pool = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="dalle-decode")
         try:
-            with ThreadPoolExecutor(max_workers=workers) as pool:
-                def mapped():             # ordered map with a bounded number of decodes in flight
-                    inflight, ahead = [], workers * 4
-                    for n, raw in enumerate(make_epoch()):
-                        if n % world != rank:
-                            continue
-                        inflight.append(pool.submit(map_fn, raw))
-                        if len(inflight) >= ahead:
-                            yield inflight.pop(0).result()
-                    for f in inflight:
-                        yield f.result()
+            def mapped():             # ordered map with a bounded number of decodes in flight
+                inflight, ahead = [], workers * 4
+                for raw in make_epoch(rank, world):          # make_epoch yields this rank's elements only
+                    inflight.append(pool.submit(map_fn, raw))
+                    if len(inflight) >= ahead:
+                        yield inflight.pop(0).result()
+                for f in inflight:
+                    yield f.result()
 
-                while not self._stop.is_set():     # .repeat() sits after batch(): every epoch drops its remainder
-                    stream = mapped()
-                    if shuffle_buf:
-                        stream = _shuffle(stream, shuffle_buf, rng)
-                    window, produced = [], 0
-                    for el in stream:
-                        if self._stop.is_set():
-                            return
-                        window.append(el)
-                        if len(window) < batch:
-                            continue
-                        a = torch.from_numpy(np.stack([w[0] for w in window]))
-                        b = torch.from_numpy(np.stack([w[1] for w in window]))
-                        window, produced = [], produced + 1
-                        while not self._stop.is_set():
-                            try:
-                                self._q.put((a, b), timeout=0.2)
-                                break
-                            except queue.Full:
-                                pass
-                    if produced == 0:
-                        raise ValueError(f"input pipeline: an epoch holds fewer than batch_size={batch} elements")
+            while not self._stop.is_set():     # .repeat() sits after batch(): every epoch drops its remainder
+                stream = mapped()
+                if shuffle_buf:
+                    stream = _shuffle(stream, shuffle_buf, rng)
+                window, produced = [], 0
+                for el in stream:
+                    if self._stop.is_set():
+                        return
+                    window.append(el)
+                    if len(window) < batch:
+                        continue
+                    a = torch.from_numpy(np.stack([w[0] for w in window]))
+                    b = torch.from_numpy(np.stack([w[1] for w in window]))
+                    window, produced = [], produced + 1
+                    if not self._put((a, b)):
+                        return
+                if produced == 0:
+                    raise ValueError(f"input pipeline: an epoch holds fewer than batch_size={batch} elements")
         except BaseException as e:  # surfaced to the consumer
-            self._q.put(e)
+            if not self._stop.is_set():
+                self._put(e)
+        finally:
+            pool.shutdown(wait=True, cancel_futures=True)
 
     def __iter__(self):
         return self
 
     def __next__(self):
+        if self._stop.is_set():
+            raise StopIteration
         item = self._q.get()
         if isinstance(item, BaseException):
             raise item
@@ -237,6 +276,21 @@ class _Prefetch:
 
     def close(self):
         self._stop.set()
+        t = self._t
+        while t.is_alive():            # a producer blocked in put() wakes within its 0.1 s timeout; drain so it can leave
+            try:
+                while True:
+                    self._q.get_nowait()
+            except queue.Empty:
+                pass
+            t.join(timeout=0.05)
+        _LIVE_PREFETCH.discard(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def _file_order(files, eval, seed):
@@ -284,7 +338,7 @@ def dalle_input_fn(params, eval=False):
     files = _file_order(files, eval, seed)
     B = _batch_size(params, eval)
     sseed = seed + 1 + 104729 * int(params.get("_input_start_step", 0) if not eval else 0)
-    return _Prefetch(lambda: _interleave_records(files, 4), read_labeled_tfrecord(params), B,
+    return _Prefetch(lambda r, w: _interleave_records(files, 4, r, w), read_labeled_tfrecord(params), B,
                      0 if eval else B * 5, sseed, shard=_dp_shard(params))
 
 
@@ -303,11 +357,11 @@ def vae_input_fn(params, eval=False):
     size = ds["image_size"]
     sseed = seed + 1 + 104729 * int(params.get("_input_start_step", 0) if not eval else 0)
     if ds.get("tfrecords"):
-        return _Prefetch(lambda: _interleave_records(files, 4), read_tfrecord(params), B,
+        return _Prefetch(lambda r, w: _interleave_records(files, 4, r, w), read_tfrecord(params), B,
                          0 if eval else B * 5, sseed, shard=_dp_shard(params))
 
     def _process_path(file_path):          # input_fns.py:92-96 (decode_img with its default 3 channels)
         with open(file_path, "rb") as f:
             img = decode_img(f.read(), size)
         return img, img
-    return _Prefetch(lambda: iter(files), _process_path, B, 0 if eval else B * 5, sseed, shard=_dp_shard(params))
+    return _Prefetch(lambda r, w: iter(files[r::w]), _process_path, B, 0 if eval else B * 5, sseed, shard=_dp_shard(params))

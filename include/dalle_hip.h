@@ -14,6 +14,7 @@
  */
 #ifndef DALLE_HIP_H
 #define DALLE_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -251,6 +252,11 @@ int64_t dmi_mse_workspace_bytes(void);
 int dmi_mse_loss(const float* img, const uint16_t* outp, uint16_t* dout, float* loss, int64_t N, int Cin, int Cp,
                  float grad_scale, void* workspace, void* stream);
 int dmi_add_f32(float* dst, const float* src, int64_t n, void* stream);
+
+
+/* ---- input format (host only): CRC-32C (Castagnoli) of a TFRecord length header / payload, as tf.data.TFRecordDataset
+ * verifies them (reference src/input_fns.py:111); the caller applies TFRecord's mask.  No device work, thread-safe. */
+uint32_t dmi_crc32c(const void* data, size_t n);
 
 #ifdef __cplusplus
 }

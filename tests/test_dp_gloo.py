@@ -7,6 +7,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -105,32 +106,55 @@ def test_optimizer_never_starts_before_the_exchange_is_joined():
     assert body.strip().startswith("self.reducer.finish()"), body[:80]
 
 
-def _agree_worker(rank, world, init_file, out_file):
-    """rank 0's RCCL communicator comes up, rank 1's does not: both must end on the torch transport (and rank 0 must give
-    its communicator back) -- a split decision would hang the first collective."""
+def _agree_worker(rank, world, init_file, out_file, scenario, strict):
+    """scenario "init": rank 0's RCCL communicator comes up, rank 1's does not.  scenario "load": rank 1 cannot even bind
+    librccl (before any blocking call).  Either way the DECISION is collective: with DALLE_DP_STRICT=0 both ranks end on the
+    torch transport (rank 0 gives its communicator back); by default (strict) both ranks raise -- a split decision would
+    hang the first collective, and a silent fallback would hide the failure on a real multi-GPU node."""
     import dalle_hip as dh
     from src import dp
+    os.environ["DALLE_DP_STRICT"] = "1" if strict else "0"
+    if strict == "default":
+        del os.environ["DALLE_DP_STRICT"]
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
-    calls = {"destroyed": []}
+    calls = {"destroyed": [], "init_entered": False}
+
+    def fake_load():
+        if scenario == "load" and rank == 1:
+            raise dh.DalleHipError("comm_load: simulated dlopen failure on rank 1")
 
     def fake_init(world_, rank_, uid):
+        calls["init_entered"] = True
         assert uid == b"uid-from-rank-0"
         if rank_ == 1:
             raise dh.DalleHipError("comm_init: simulated failure on rank 1")
         return 4242
 
+    dh.comm_load = fake_load
     dh.comm_unique_id = lambda: b"uid-from-rank-0"
     dh.comm_init = fake_init
     dh.comm_destroy = lambda h: calls["destroyed"].append(h)
-    handle = dp.init_comm(world, rank, dist.group.WORLD)
-    torch.save({"handle": handle, "destroyed": calls["destroyed"]}, f"{out_file}.{rank}")
+    handle, raised = None, None
+    try:
+        handle = dp.init_comm(world, rank, dist.group.WORLD)
+    except RuntimeError as e:
+        raised = str(e)
+    torch.save({"handle": handle, "raised": raised, **calls}, f"{out_file}.{rank}")
     dist.destroy_process_group()
 
 
-def test_transport_choice_is_collective():
+@pytest.mark.parametrize("scenario,strict", [("init", False), ("init", "default"), ("load", False), ("load", True)])
+def test_transport_choice_is_collective(scenario, strict):
     with tempfile.TemporaryDirectory() as d:
         init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out")
-        mp.spawn(_agree_worker, args=(2, init_file, out_file), nprocs=2, join=True)
+        mp.spawn(_agree_worker, args=(2, init_file, out_file, scenario, strict), nprocs=2, join=True)
         r0, r1 = torch.load(f"{out_file}.0"), torch.load(f"{out_file}.1")
         assert r0["handle"] is None and r1["handle"] is None
-        assert r0["destroyed"] == [4242] and r1["destroyed"] == []
+        if strict:
+            assert r0["raised"] and r1["raised"] and "DALLE_DP_STRICT=0" in r0["raised"]
+        else:
+            assert r0["raised"] is None and r1["raised"] is None
+        if scenario == "init":
+            assert r0["destroyed"] == [4242] and r1["destroyed"] == []
+        else:      # nobody may enter the blocking communicator init when one rank could not load the library
+            assert not r0["init_entered"] and not r1["init_entered"] and r0["destroyed"] == []

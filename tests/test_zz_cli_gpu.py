@@ -65,3 +65,20 @@ def test_train_vae_then_dalle_cli_with_resume(tmp_path):
     json.dump(dalle, open(dcfg, "w"))
     out = _run("train_dalle.py", dcfg, str(tmp_path))       # resumes from step 3
     assert "Current step: 3" in out, out[-1500:]
+
+
+def test_train_vae_cli_exits_cleanly_every_time(tmp_path):
+    """GPUTEST_r02 regression: the input producer was still alive at interpreter exit and the process died with SIGABRT
+    ('terminate called without an active exception') AFTER a complete, correct run -- a race, so run it ten times.
+    The reference's train_vae_tf.py:63-95 simply returns."""
+    glob = _shards(tmp_path, n=24)
+    ds = {"train_path": glob, "eval_path": glob, "image_size": 32, "tfrecords": True}
+    vae = json.load(open(os.path.join(ROOT, "configs", "vae_example.json")))
+    vae.update(dataset=ds, train_batch_size=4, eval_batch_size=4, train_steps=2, steps_per_checkpoint=1, eval_steps=1,
+               iterations=1)
+    for k in range(10):
+        vae["model_path"] = str(tmp_path / f"run_{k}")
+        cfg = str(tmp_path / f"vae_{k}.json")
+        json.dump(vae, open(cfg, "w"))
+        out = _run("train_vae_tf.py" if k % 2 == 0 else "train_vae.py", cfg, str(tmp_path))
+        assert "terminate called" not in out and "eval: mean loss" in out, out[-1500:]

@@ -1,71 +1,7 @@
-"""train_vae.py -- the reference's train_vae.py imports a non-existent symbol (train_vae.py:8);
-the working upstream entry is train_vae_tf.py.  This script has that behaviour and the same CLI:
+"""train_vae.py -- the reference's train_vae.py imports a non-existent symbol (train_vae.py:8); the working
+upstream entry is train_vae_tf.py.  Same program, same CLI:
     python train_vae.py --model vae_example [--new]"""
-import argparse
-import os
-import sys
-from functools import partial
-
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "dalle-mtf_amd"))
-
-import torch  # noqa: E402
-from src.utils import *  # noqa: E402,F401,F403
-from src.model_fns_tf import vae_model_fn  # noqa: E402
-from src.input_fns import vae_input_fn  # noqa: E402
-from src.estimator import Estimator, load_global_step_from_checkpoint_dir  # noqa: E402
-
-
-def parse_args():
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--tpu", type=str, help="Accepted for CLI compatibility; TPUs are not a target of this build.")
-    parser.add_argument("--gpu_ids", nargs="+", type=str, default=["device:GPU:0"],
-                        help="Kept for CLI compatibility: with one process per GPU the device is LOCAL_RANK.")
-    parser.add_argument("--model", type=str, default=None, help="JSON file that contains model parameters.")
-    parser.add_argument("--new", action="store_true", help="If set, deletes previous checkpoint, if it exists, and "
-                                                           "starts a new training run")
-    args = parser.parse_args()
-    assert args.model is not None, "Model must be set"
-    return args
-
-
-def main():
-    args = parse_args()
-    logging = setup_logging(args, rank=int(os.environ.get("RANK", "0")))
-    params = fetch_model_params(args.model)
-    assert params["model_type"].lower() == "vae", f'model_type {params["model_type"]} not recognized'
-    assert args.tpu is None, "TPUs are not supported by the MI355X build"
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        from src.dp import barrier, init_process_group
-        init_process_group(local_rank)
-    if args.new and int(os.environ.get("RANK", "0")) == 0:
-        maybe_remove_gs_or_filepath(params["model_path"])
-    if world > 1:
-        barrier()      # nobody looks for a checkpoint before rank 0 has cleared the directory
-    current_step = int(load_global_step_from_checkpoint_dir(params["model_path"]))
-    logging.info(f"Current step: {current_step}")
-    params["use_tpu"] = False
-    params["gpu_ids"] = args.gpu_ids
-    params["batch_size"] = params["train_batch_size"] // world
-    params["dp_rank"], params["dp_world"] = int(os.environ.get("RANK", "0")), world
-    estimator = Estimator(model_fn=vae_model_fn, model_dir=params["model_path"], params=params,
-                          log_every=min(params["iterations"] or 100, 100), logger=logging)
-    has_predict_or_eval_steps = params["predict_steps"] > 0 or params["eval_steps"] > 0
-    while current_step < params["train_steps"]:
-        nxt = params["train_steps"]
-        if has_predict_or_eval_steps:
-            nxt = min(current_step + params["steps_per_checkpoint"], params["train_steps"])
-        current_step = estimator.train(input_fn=partial(vae_input_fn, eval=False), max_steps=nxt)
-        logging.info(f"Current step: {current_step}")
-        if params["predict_steps"] > 0:
-            raise NotImplementedError
-        if params["eval_steps"] > 0:
-            logging.info("Starting eval")
-            estimator.evaluate(input_fn=partial(vae_input_fn, eval=True), steps=params["eval_steps"])
-
+from train_vae_tf import main, parse_args  # noqa: F401
 
 if __name__ == "__main__":
     main()

@@ -53,18 +53,21 @@ def main():
     params["dp_rank"], params["dp_world"] = int(os.environ.get("RANK", "0")), world
     estimator = Estimator(model_fn=vae_model_fn, model_dir=params["model_path"], params=params,
                           log_every=min(params["iterations"] or 100, 100), logger=logging)
-    has_predict_or_eval_steps = params["predict_steps"] > 0 or params["eval_steps"] > 0
-    while current_step < params["train_steps"]:
-        nxt = params["train_steps"]
-        if has_predict_or_eval_steps:
-            nxt = min(current_step + params["steps_per_checkpoint"], params["train_steps"])
-        current_step = estimator.train(input_fn=partial(vae_input_fn, eval=False), max_steps=nxt)
-        logging.info(f"Current step: {current_step}")
-        if params["predict_steps"] > 0:
-            raise NotImplementedError
-        if params["eval_steps"] > 0:
-            logging.info("Starting eval")
-            estimator.evaluate(input_fn=partial(vae_input_fn, eval=True), steps=params["eval_steps"])
+    try:
+        has_predict_or_eval_steps = params["predict_steps"] > 0 or params["eval_steps"] > 0
+        while current_step < params["train_steps"]:
+            nxt = params["train_steps"]
+            if has_predict_or_eval_steps:
+                nxt = min(current_step + params["steps_per_checkpoint"], params["train_steps"])
+            current_step = estimator.train(input_fn=partial(vae_input_fn, eval=False), max_steps=nxt)
+            logging.info(f"Current step: {current_step}")
+            if params["predict_steps"] > 0:
+                raise NotImplementedError
+            if params["eval_steps"] > 0:
+                logging.info("Starting eval")
+                estimator.evaluate(input_fn=partial(vae_input_fn, eval=True), steps=params["eval_steps"])
+    finally:
+        estimator.close()      # stops and joins the input producer: no thread may be alive at interpreter exit
 
 
 if __name__ == "__main__":
