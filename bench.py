@@ -63,8 +63,26 @@ def synth_tokens(B, T, P, text_vocab, image_vocab, seed):
     return out
 
 
+def reference_baseline():
+    """the unmodified mesh-tensorflow reference timed on this host, when it can run here at all (tools/ref_probe.py:
+    `import tensorflow, mesh_tensorflow` + a reference checkout); None otherwise -- the expected case."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import ref_probe
+        st = ref_probe.probe()
+        if not st["available"]:
+            return None, st["reason"]
+        return ref_probe.time_reference(CFG), None
+    except Exception as e:           # a half-working TF install must not take the bench line down
+        return None, f"reference probe failed: {type(e).__name__}: {e}"
+
+
 def cpu_baseline(budget_s=20.0):
-    """Oracle train step (fwd+bwd via autograd, clip, Adam) on the host cores; B=1, S=1280 sample."""
+    """The reference itself when it runs here (kind "reference"), else the oracle train step (fwd+bwd via autograd, clip,
+    Adam; kind "port") on the host cores; B=1, S=1280 sample."""
+    ref, why_not = reference_baseline()
+    if ref is not None:
+        return ref
     from oracle import dalle_oracle as do
     cores = min(os.cpu_count() or 1, 32)   # more threads than this only add contention on this op mix
     torch.set_num_threads(cores)
@@ -87,7 +105,8 @@ def cpu_baseline(budget_s=20.0):
     return {"value": S / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
             "sample": f"{n} train steps of B=1 x S={S} (dalle_example weights, fp32 PyTorch-CPU oracle, "
                       f"{torch.get_num_threads()} threads), {dt:.2f} s/step",
-            "note": "CPU restatement of the reference; the mesh-tensorflow reference itself cannot run here"}
+            "note": "CPU restatement of the reference; the mesh-tensorflow reference itself cannot run here "
+                    f"(tools/ref_probe.py: {why_not})"}
 
 
 def cpu_baseline_vae(p, grid, budget_s=15.0):

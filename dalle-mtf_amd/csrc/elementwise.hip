@@ -906,7 +906,7 @@ extern "C" int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, fl
 //                        reference's loss_batch);  rowscale[m] = dz_scale / S[m];  E[m,label] -= S[m]  (so that dlogits = rowscale * E);
 //                        Xs[m,:] = bf16(rowscale[m] * x[m,:])  (the weight-gradient GEMM's left operand: dW = Xs^T E)
 // No shift (the engine's choice): exp(logit) is exact to rounding for logits within +-87 -- floating point keeps its relative
-// precision, the row maximum is not needed.  A row whose sum overflows (some logit > 88) or vanishes (all < -69) is flagged and
+// precision, the row maximum is not needed.  A row whose sum leaves [1e-18, 1e18] (some logit > 41, or all < -41 - ln V) is flagged and
 // redone exactly by softmax_fixup_kernel with the row maximum as the shift.  With the label logit as shift (rowshift = zl) the
 // label entry is 1 and only a logit exceeding the label's by > 88 (a row loss > 88 nats) takes the fix-up path.
 // =====================================================================================
@@ -984,7 +984,11 @@ __global__ __launch_bounds__(256) void softmax_finish_kernel(SoftmaxFinishArgs a
       float S = 0.f;
 #pragma unroll
       for (int k = 0; k < SF_PARTS; ++k) S += sm[k][r];
-      const bool bad = !(S > 1.0e-30f && S < 3.0e38f);   // inf / nan (an exponent overflowed) or a vanished row
+      // accept window [1e-18, 1e18] (|logsumexp| <= 41): inf / nan (an exponent overflowed) and vanished rows fall outside, and
+      // so do rows that are merely LARGE -- for S ~ 1e33..3e38 rowscale = dz_scale / S would be an fp32/bf16 denormal (Xs and
+      // rowscale_bf16 flush to 0: a silently dropped row) and the E.W^T accumulators of the input gradient could overflow.
+      // Inside the window rowscale >= 1e-18 * dz_scale and E <= 1e18 keep > 60 binades of headroom; outside, the exact fix-up.
+      const bool bad = !(S > 1.0e-18f && S < 1.0e18f);
       if (bad) a.flag[0] = 1;
       // loss = logsumexp - label logit = log S + shift - zl   (models.py:348-359: the reference's loss_batch)
       a.loss_rows[mr] = bad ? INFINITY : __logf(S) + (a.rowshift ? a.rowshift[mr] : 0.f) - a.zl[mr];

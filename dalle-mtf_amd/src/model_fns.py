@@ -76,18 +76,26 @@ def _build(params, mode_str):
     state = {"world": world, "rank": rank}
     if params.get("synthetic_image_tokens"):
         image_seq_len = int(params["synthetic_image_tokens"])
-        state["vae"] = None
     else:
-        vae, ckpt = load_vae_model(params, mode_str)
-        initialize_vae_weights(vae, ckpt)
-        # reference model_fns.py:68
-        image_seq_len = (vae.H // (2 ** len(vae.convblocks))) ** 2 // (vae.stack_factor ** 2)
-        state["vae"] = vae
+        vp = params["vae_params"]
+        cb = vp.get("convblocks") or [(3, 64), (3, 128), (3, 256)]
+        # reference model_fns.py:68 (from the VAE's configuration: the micro-batch count below sizes the tokenizer)
+        image_seq_len = (params["dataset"]["image_size"] // (2 ** len(cb))) ** 2 // ((vp.get("stack_factor") or 1) ** 2)
     nmb = 1
     if mode_str == "train":
         nmb = serialize_num_microbatches(local_bs, params["text_seq_len"] + image_seq_len,
                                          params.get("tokens_per_mb_per_replica"))
         assert local_bs % nmb == 0, f"per-replica batch {local_bs} does not split into {nmb} micro-batches"
+    if params.get("synthetic_image_tokens"):
+        state["vae"] = None
+    else:
+        # the tokenizer is sized for ONE ENGINE batch (a micro-batch in training): dalle_model_fn feeds it engine-sized
+        # chunks, so any row count the engine accepts (train: nmb x engine batch; eval: any multiple) also tokenizes
+        params["_tokenizer_batch"] = local_bs // nmb
+        vae, ckpt = load_vae_model(params, mode_str)
+        initialize_vae_weights(vae, ckpt)
+        assert image_seq_len == (vae.H // (2 ** len(vae.convblocks))) ** 2 // (vae.stack_factor ** 2)
+        state["vae"] = vae
     model = DALLE(n_embd=params["n_embd"], text_vocab_size=params["text_vocab_size"],
                   image_vocab_size=params["image_vocab_size"], text_seq_len=params["text_seq_len"],
                   image_seq_len=image_seq_len, n_layers=params["n_layers"], n_heads=params["n_heads"],

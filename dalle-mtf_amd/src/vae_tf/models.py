@@ -534,6 +534,42 @@ class DiscreteVAE:
         dh.im2col(dy, self.col, self.B, c.H, c.W, c.cout, c.H, c.W, 1, TAPS3_REV, Kp)
         dh.gemm_nt(self.col, Kp, self.wd[c.name], Kp, out, c.cin, self.B * c.H * c.W, c.cin, Kp, flags, residual=residual, relu_src=relu_src)
 
+    def _up_backward(self, c: _Conv, x_in, dz, out):
+        """backward of the transposed conv z = conv2d_transpose(y) (vae_tf/models.py:133-137): a stride-2 4x4 SAME conv of dz.
+        dW[kh,kw,Cout,Cin] and dbias into g, dy [B*H*W, cin] into `out`."""
+        B = self.B
+        Mi = B * c.H * c.W
+        Kz = 16 * c.cout
+        Kzp = _ru(Kz, 64)
+        p2 = lambda v: v > 0 and (v & (v - 1)) == 0
+        if c.cout % 64 == 0 and p2(c.H) and p2(c.W):
+            # both GEMMs gather dz implicitly
+            dh.conv_wgrad_tn(dz, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, x_in, c.cin, c.cin,
+                             self._gv(c.name + "/kernel"), self.ws)
+            dh.colsum(dz, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+            dh.conv_gemm_nt(dz, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, self.wd[c.name], Kzp, out, c.cin, c.cin)
+        else:
+            dh.im2col(dz, self.col, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, Kzp)     # stride-2 conv view of dz
+            dh.gemm_tn(self.col, Kzp, x_in, c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, self.ws)
+            dh.colsum(dz, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+            dh.gemm_nt(self.col, Kzp, self.wd[c.name], Kzp, out, c.cin, Mi, c.cin, Kzp)
+
+    def _dgrad_down(self, c: _Conv, dy, out):
+        """input gradient of the 4x4 stride-2 SAME conv (vae_tf/models.py:90-92) = its transposed conv: 4 output-parity GEMMs
+        over the 2x2 contributing taps + a pixel interleave; dy [B*Ho*Wo, cout] -> out [B*H*W, cin]."""
+        B = self.B
+        Mo = B * c.Ho * c.Wo
+        Kp = _ru(4 * c.cout, 64)
+        for p in range(4):
+            taps = [(t[1], t[2]) for t in _parity(p)]
+            if c.cout % 64 == 0:
+                dh.conv_gemm_nt(dy, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, self.wp[c.name][p], Kp,
+                                self.par[p * Mo * c.cin:], c.cin, c.cin)
+                continue
+            dh.im2col(dy, self.col, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, Kp)
+            dh.gemm_nt(self.col, Kp, self.wp[c.name][p], Kp, self.par[p * Mo * c.cin:], c.cin, Mo, c.cin, Kp)
+        dh.pixel_interleave(self.par, out, B, c.Ho, c.Wo, c.cin)
+
     def backward(self):
         """Gradients of the last forward(return_recon_loss=True) into the flat fp32 buffer `g`."""
         B, convs = self.B, self.convs
@@ -570,39 +606,15 @@ class DiscreteVAE:
                 spare[1], d = d, nd
                 i -= 2
             elif c.kind == "up":
-                Mi = B * c.H * c.W
-                Kz = 16 * c.cout
-                Kzp = _ru(Kz, 64)
-                p2 = lambda v: v > 0 and (v & (v - 1)) == 0
                 nd = spare[0]
-                if c.cout % 64 == 0 and p2(c.H) and p2(c.W):
-                    # the transposed conv's backward is a stride-2 4x4 conv of dz: both GEMMs gather dz implicitly
-                    dh.conv_wgrad_tn(d, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, self.act_in[i], c.cin, c.cin,
-                                     self._gv(c.name + "/kernel"), self.ws)
-                    dh.colsum(d, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
-                    dh.conv_gemm_nt(d, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, self.wd[c.name], Kzp, nd, c.cin, c.cin)
-                else:
-                    dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, Kzp)     # stride-2 conv view of dz
-                    dh.gemm_tn(self.col, Kzp, self.act_in[i], c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, self.ws)
-                    dh.colsum(d, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
-                    dh.gemm_nt(self.col, Kzp, self.wd[c.name], Kzp, nd, c.cin, Mi, c.cin, Kzp)
+                self._up_backward(c, self.act_in[i], d, nd)
                 spare[0], d = d, nd
                 i -= 1
             else:  # down
                 self._wgrad(c, self.act_in[i], d)
                 if i > 0:
-                    Mo = B * c.Ho * c.Wo
-                    Kp = _ru(4 * c.cout, 64)
-                    for p in range(4):
-                        taps = [(t[1], t[2]) for t in _parity(p)]
-                        if c.cout % 64 == 0:
-                            dh.conv_gemm_nt(d, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, self.wp[c.name][p], Kp,
-                                            self.par[p * Mo * c.cin:], c.cin, c.cin)
-                            continue
-                        dh.im2col(d, self.col, B, c.Ho, c.Wo, c.cout, c.Ho, c.Wo, 1, taps, Kp)
-                        dh.gemm_nt(self.col, Kp, self.wp[c.name][p], Kp, self.par[p * Mo * c.cin:], c.cin, Mo, c.cin, Kp)
                     nd = spare[0]
-                    dh.pixel_interleave(self.par, nd, B, c.Ho, c.Wo, c.cin)
+                    self._dgrad_down(c, d, nd)
                     spare[0], d = d, nd
                 i -= 1
             ready_down_to(self.offset[lowest.name + "/kernel"])

@@ -63,7 +63,10 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
         if bf16_oracle:
             loss_o16, g16 = do.loss_and_grads(Po, tokens, cfg, bf16=True)
             rec["loss_oracle_bf16"] = loss_o16
-            rec["worst_grad_rel_l2_vs_bf16_oracle"] = max(((rel_l2(gh[k], g16[k]), k) for k in g16), key=lambda t: t[0])
+            table16 = {k: rel_l2(gh[k], g16[k]) for k in g16}
+            rec["worst_grad_rel_l2_vs_bf16_oracle"] = max(((e, k) for k, e in table16.items()), key=lambda t: t[0])
+            if per_tensor:
+                rec["grad_rel_l2_vs_bf16_oracle"] = table16
         gn_h = math.sqrt(sum(float((gh[k].astype(np.float64) ** 2).sum()) for k in gh))
         gn_o = math.sqrt(sum(float((g32[k].astype(np.float64) ** 2).sum()) for k in g32))
         eng.global_step = step + 1  # past step 0 (lr(0) = 0 under warm-up)
@@ -78,7 +81,7 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
             rec["grad_rel_l2"] = table32
         report["steps"].append(rec)
         if verbose:
-            print({k: v for k, v in rec.items() if k != "grad_rel_l2"}, flush=True)
+            print({k: v for k, v in rec.items() if not k.startswith("grad_rel_l2")}, flush=True)
             if per_tensor:
                 for k, e in sorted(table32.items(), key=lambda t: -t[1])[:12]:
                     print(f"    rel-L2 {e:.4f}  {k}", flush=True)

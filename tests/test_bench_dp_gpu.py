@@ -138,3 +138,78 @@ print("DP_SETUP_OK")
 '''
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ROOT=ROOT), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "DP_SETUP_OK" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def _rccl_worker(rank, world, port, q):
+    """one rank per GPU, the product path: src/dp.init_process_group + dist_setup (C-ABI communicator over RCCL, strict)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    os.environ.pop("DALLE_BENCH_SHARE_GPU", None)
+    os.environ.pop("DALLE_DP_TRANSPORT", None)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "dalle-mtf_amd")]
+    import torch.distributed as dist
+    from oracle import dalle_oracle as do
+    from src import dp
+    from src.dalle_mtf.engine import DalleEngine
+    torch.cuda.set_device(rank if world > 1 else 0)
+    pg = comm = None
+    if world > 1:
+        dp.init_process_group(rank)
+        _, _, pg, comm = dp.dist_setup()
+        assert comm, "RCCL communicator must exist when every rank owns a GPU"
+    cfg = do.DalleConfig(256, 300, 64, 16, 112, 2, 2)
+    P0 = do.init_params(cfg, seed=5, perturb=0.05)
+    tokens = do.assemble_tokens(do.synthetic_captions(4, 16, 300, seed=1), do.synthetic_image_tokens(4, 112, 64, seed=2), 300)
+    hp = dict(lr=1e-3, train_steps=100, warmup_steps=1, gradient_clipping=1.0)
+    eng = DalleEngine(256, 2, 2, 300, 64, 16, 112, batch_size=4 // world, global_batch_size=4, hparams=hp,
+                      process_group=pg, world_size=world, comm=comm)
+    assert world == 1 or eng.reducer.transport == "rccl"
+    eng.load_reference_params(P0)
+    if world > 1:      # the start-up broadcast of weights over the same communicator
+        if rank != 0:
+            eng.p.zero_()
+        eng.reducer.broadcast(eng.p, root=0)
+        eng.refresh_compute_copies(cast=True)
+    shard = torch.from_numpy(tokens[rank * (4 // world):(rank + 1) * (4 // world)]).cuda()
+    eng.global_step = 1
+    eng.forward(shard, need_grad=True)
+    eng.backward()
+    eng.wait_grads()
+    torch.cuda.synchronize()
+    g = eng.g.detach().cpu().numpy().copy()
+    eng.optimizer_step()
+    q.put((rank, g, eng.p.detach().cpu().numpy().copy(), eng.grad_norm(), list(eng.reducer.last_log)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs: the RCCL exchange with one GPU per rank "
+                    "(auto-activates on the first multi-GPU box; no such box was available to the build)")
+def test_rccl_two_gpus_dp2_equals_single_process():
+    """reference src/model_fns.py:81-82,189 (layout batch_dim:data): 2 real ranks through dmi_comm_init /
+    dmi_allreduce_bucket / dmi_comm_broadcast_f32 over xGMI; gradients after the exchange are IDENTICAL on both ranks and
+    equal the single-process gradients of the concatenated batch to bf16 reduction-order noise; both ranks apply the same
+    clipped Adam update (global norm)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world, port in ((1, 29601), (2, 29603)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0
+        res[world] = got
+    (_, g1, p1, n1, _), = res[1]
+    (_, ga, pa, na, log_a), (_, gb, pb_, nb, log_b) = res[2]
+    assert np.array_equal(ga, gb) and np.array_equal(pa, pb_) and na == nb, "ranks diverged after the all-reduce"
+    assert log_a == log_b and sum(b - a for a, b in log_a) == ga.size      # every gradient element reduced exactly once
+    rel = np.linalg.norm(g1 - ga) / np.linalg.norm(g1)
+    assert rel < 2e-2, rel
+    assert abs(n1 - na) <= 1e-2 * n1
+    assert np.abs(p1 - pa).max() <= 6.5 * 1e-3

@@ -55,6 +55,49 @@ def test_oracle_reproduces_vae_golden():
     np.testing.assert_allclose(out, GV["recon_hard"], rtol=1e-4, atol=1e-5)
 
 
+REF_DUMP = os.path.join(HERE, "golden", "ref_dalle_small.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DUMP), reason="parity unpinned: tests/golden/ref_dalle_small.npz is written by "
+                    "tools/ref_probe.py dump on a machine where tensorflow==2.4 + mesh_tensorflow==0.1.18 run (none available)")
+def test_oracle_vs_reference_dump():
+    """The pin itself: the oracle against activations and gradients dumped from the UNMODIFIED reference model class
+    (src/dalle_mtf/models.py:141-416) with the oracle's weights (tools/ref_probe.py).  fp32 on both sides."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import ref_probe
+    R = np.load(REF_DUMP)
+    cfg = do.DalleConfig(**{k: ref_probe.SMALL[k] for k in ("n_embd", "text_vocab_size", "image_vocab_size", "text_seq_len",
+                                                            "image_seq_len", "n_layers", "n_heads")})
+    P = do.init_params(cfg, seed=1234, perturb=0.05)
+    loss, grads = do.loss_and_grads(P, R["tokens"], cfg)
+    assert abs(loss - float(R["loss"])) <= 1e-4 * abs(float(R["loss"]))
+    Pt = OrderedDict((k, torch.tensor(v)) for k, v in P.items())
+    _, lb, logits = do.forward(Pt, R["tokens"], cfg, return_logits=True)
+    np.testing.assert_allclose(logits.numpy(), R["logits"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lb.numpy(), R["loss_batch"], rtol=1e-4, atol=1e-5)
+    for k in R.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(grads[k[5:]], R[k].reshape(grads[k[5:]].shape), rtol=1e-3, atol=1e-6)
+
+
+def test_reference_probe_reports_unavailable_without_tensorflow():
+    """the skip path of tools/ref_probe.py and of bench.py's cpu_baseline: no TensorFlow -> {"available": false, reason},
+    exit status 0, nothing under the reference tree is touched, bench falls back to the oracle port."""
+    import json
+    import subprocess
+    tool = os.path.join(os.path.dirname(HERE), "tools", "ref_probe.py")
+    for cmd in ("check", "dump", "time"):
+        r = subprocess.run([sys.executable, tool, cmd], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, DALLE_REFERENCE_ROOT="/nonexistent"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        st = json.loads(r.stdout.strip().splitlines()[-1])
+        assert st["available"] is False and st["reason"]
+    sys.path.insert(0, os.path.dirname(HERE))
+    import bench
+    ref, why = bench.reference_baseline()
+    assert ref is None and why
+
+
 @pytest.mark.gpu
 def test_hip_matches_dalle_golden():
     from src.dalle_mtf.engine import DalleEngine

@@ -12,6 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+BF16_ORACLE_GRAD_TOL = 0.034     # measured 0.0272 (profiles/r03_parity_dalle_example.json) + 25 %
 DALLE_EXAMPLE = dict(n_embd=512, n_heads=4, n_layers=6, text_vocab=50258, image_vocab=512, T=256, P=1024)
 
 
@@ -19,7 +20,7 @@ def test_dalle_example_shape_step_vs_fp32_oracle():
     """loss, every gradient tensor and one clip + Adam update at the headline shape (B = 2: 2560 rows -> the 256x128 NT
     tiling of the vocabulary projection, the row-split weight-gradient tail and the fused softmax head all engage)."""
     from parity import check_report, compare_step, save_report
-    rep = compare_step(B=2, seed=21, steps=1, perturb=0.02, bf16_oracle=False, per_tensor=True, **DALLE_EXAMPLE)
+    rep = compare_step(B=2, seed=21, steps=1, perturb=0.02, bf16_oracle=True, per_tensor=True, **DALLE_EXAMPLE)
     save_report("parity_dalle_example.json", rep)
     # measured on MI355X (profiles/r02_parity_dalle_example.json): loss 9e-6 relative, grad norm 1.4e-4, worst tensor 0.033
     # (layer_5/mlp/mlp_linear_1/kernel).  The 3 % floor is the ReLU: a pre-activation within bf16 noise of 0 flips its mask
@@ -27,6 +28,16 @@ def test_dalle_example_shape_step_vs_fp32_oracle():
     # tensors downstream of the last ReLU (mlp_linear_2, to_logits/*) sit at 0.3-0.6 %.
     check_report(rep, loss_rtol=2e-4, grad_tol=0.042, gn_rtol=2e-3)
     assert rep["steps"][0]["head_fixup_flag"] == 0
+    # [r03] the same gradients against the bf16-EMULATING oracle (dalle_oracle `bf16=True`: activations and weight copies
+    # rounded to bf16 wherever the reference's bf_16 policy rounds them, src/dalle_mtf/ops.py:76-82; fp32 math in between).
+    # Its forward agrees with the kernels' to fp32 summation order (loss 1.7e-6 relative vs 1.1e-5 against the fp32 oracle), so
+    # what remains is the BACKWARD: the engine rounds every gradient activation (dh, dqkv, d_o, dx) to bf16, the oracle's
+    # autograd keeps them in fp32.  Measured: worst tensor 0.0272 vs 0.0337 against the fp32 oracle (same tensor,
+    # layer_5/mlp/mlp_linear_1/kernel) -- i.e. ~80 % of the headline gradient error is bf16 rounding of backward activations
+    # (inherent to the bf_16 policy, not to a kernel) and ~20 % is forward dtype error incl. ReLU mask flips.
+    s0 = rep["steps"][0]
+    assert abs(s0["loss_hip"] - s0["loss_oracle_bf16"]) <= 2e-4 * abs(s0["loss_oracle_bf16"]), s0
+    assert s0["worst_grad_rel_l2_vs_bf16_oracle"][0] <= BF16_ORACLE_GRAD_TOL, s0["worst_grad_rel_l2_vs_bf16_oracle"]
 
 
 def test_dalle_example_shape_eval_logits_vs_fp32_oracle():

@@ -417,6 +417,30 @@ def test_fused_softmax_head_overflow_rows_are_redone_exactly(shift):
     close(Xs, X.float() * rsc.cpu()[:, None], 1.6e-2, 1e-12, "Xs")
 
 
+def test_fused_softmax_head_large_but_finite_rows_take_the_exact_path():
+    """a row whose largest logit is ~80 has a FINITE sum (e^80 = 5.5e34) but rowscale = dz_scale / S would be a
+    denormal: Xs and the bf16 rowscale flush to zero and the row silently drops out of dW / db.  Such rows must be flagged and
+    redone with the row maximum as the shift, like overflowing ones."""
+    M, K, V = 130, 128, 500
+    X, Wt, bias, labels, Vp = _head_case(M, K, V, seed=12)
+    lab = labels.long()
+    for r in (5, 77):
+        v_hi = (int(lab[r]) + 1) % V
+        Wt[v_hi] = (X[r].float() * (80.0 / float(X[r].float().pow(2).sum()))).to(torch.bfloat16)
+    dz_scale = 1.0 / (32 * 1280)
+    zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale, shift=False)
+    assert flag == 1
+    z = X.float() @ Wt.float()[:V].t() + bias.float()[:V]
+    assert 70 < float(z[5].max()) < 88
+    ref_loss = torch.logsumexp(z, -1) - z[torch.arange(M), lab]
+    close(loss, ref_loss, 1e-4, 2e-3, "loss rows")
+    dz_ref = (torch.softmax(z, -1) - F.one_hot(lab, V).float()) * dz_scale
+    dz = E.float().cpu()[:, :V] * rsc.cpu()[:, None]
+    close(dz, dz_ref, 1.6e-2, 1e-3 * dz_scale, "dlogits incl. redone rows")
+    assert float(rsb.float().cpu()[5]) > 0 and float(Xs.float().cpu()[5].abs().max()) > 0, "row 5 must not flush to zero"
+    close(Xs, X.float() * rsc.cpu()[:, None], 1.6e-2, 1e-12, "Xs")
+
+
 def test_colsum_and_transpose():
     M, N = 1000, 520
     Y = rnd(M, N, seed=1)
