@@ -16,6 +16,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define WAVE 64
 
+// s_setprio(1) around an MFMA cluster (cdna_hip_programming.md T5): with several blocks per CU in different phases the
+// scheduler then prefers the wave that is feeding the matrix pipe over co-resident waves issuing DMA / LDS traffic.
+// Measured in the dalle_example step (profiles/r03_ab_setprio_groupm.log, same-call A/B): NT GEMMs 16.84 -> 16.74 ms/step
+// (the BK = 64 kernel +3 % on the K >= 1536 shapes, the 256x128 kernel neutral); the same around the attention kernels'
+// S / PV clusters: neutral to -0.5 % (not applied).
+#define MFMA_PRIO(x) __builtin_amdgcn_s_setprio(x)
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // RNE (v_cvt_pk_bf16_f32 on gfx950)

@@ -1191,7 +1191,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v,
                                                    bf16_t* __restrict__ pb, int64_t n,
                                                    const float* __restrict__ gnorm_sq, float clip, float lr, float b1,
-                                                   float b2, float eps, float wd, float gscale) {
+                                                   float b2, float eps, float wd, float gscale,
+                                                   const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = lr_dev[0];   // graph replay: the scheduled learning rate lives in device memory
   float mult = gscale;
   if (gnorm_sq != nullptr && clip > 0.f) {
     const float gn = sqrtf(gnorm_sq[0]) * gscale;  // norm of the scaled gradient
@@ -1229,13 +1231,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 extern "C" int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
                              const float* gnorm_sq, float clip, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float grad_scale, void* stream) {
+                             float weight_decay, float grad_scale, const float* lr_dev, void* stream) {
   DMI_REQUIRE(p && g && m && v && n > 0, "adam_step: bad args");
   DMI_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0 && (((uintptr_t)p_bf16) & 7) == 0,
               "adam_step: buffers must be 16-byte aligned");
   int64_t blocks = cdiv64(n / 4 + 1, 256);
   if (blocks > 4096) blocks = 4096;
-  adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, weight_decay, grad_scale);
+  adam_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, weight_decay, grad_scale, lr_dev);
   DMI_CHECK_LAUNCH("adam_step");
   return DMI_OK;
 }

@@ -53,7 +53,9 @@ extern "C" int dmi_set_option(const char* name, int value) {
 #define BM 128
 #define BN 128
 #define BK 64
+#ifndef GROUP_M
 #define GROUP_M 8
+#endif
 
 struct GemmArgs {
   const bf16_t* A;
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
   };
   auto compute = [&](int st) {
     const char* cur = smem + st * 32768;
+    MFMA_PRIO(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[2], fb[2];
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
+    MFMA_PRIO(0);
   };
 
   stage(0, 0);
@@ -396,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   };
   auto compute = [&](int st) {
     const char* cur = smem + st * STG;
+    MFMA_PRIO(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fa[4], fb[2];
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
+    MFMA_PRIO(0);
   };
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -505,6 +511,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
   };
   auto compute = [&](int st) {
     const char* cur = smem + st * STG;
+    MFMA_PRIO(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[4], fb[2];
@@ -518,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
+    MFMA_PRIO(0);
   };
 
   stage(0, 0);
@@ -977,6 +985,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     // kk-outer order with two fragment sets in flight and counted waits (lgkmcnt is a 4-bit counter: <= 15 outstanding): the
     // MFMAs of substep kk run under the reads of kk+1 / kk+2.  The earlier form -- all four sets read up front, then four
     // back-to-back MFMAs per accumulator -- measured 0.1 ms/step slower in the same call (16.54 / 16.73 vs 16.44 / 16.61 ms).
+    MFMA_PRIO(1);
     tr_issue(f[0], base + ofx[0], base + ofx[1], base + ofy[0], base + ofy[1]);
     tr_issue(f[1], base + 4096 + ofx[0], base + 4096 + ofx[1], base + 4096 + ofy[0], base + 4096 + ofy[1]);
 #pragma unroll
@@ -1001,6 +1010,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
         else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f[kk].y1a, f[kk].y1b), bacc, 0, 0, 0);
       }
     }
+    MFMA_PRIO(0);
   };
 
   unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, rq0 = 0;
@@ -1527,6 +1537,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGe
   };
   auto compute = [&](int st) {
     const char* cur = smem + st * 32768;
+    MFMA_PRIO(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       bf16x8 fa[2], fb[2];
@@ -1541,6 +1552,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGe
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
     }
+    MFMA_PRIO(0);
   };
 
   stage(0, 0);

@@ -135,7 +135,9 @@ extern "C" int dmi_pad_channels(const float* in, uint16_t* out, int64_t N, int C
 template <int NC>  // NC = ceil(T/8/64) chunks per lane
 __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ u,
                                                          bf16_t* __restrict__ y, bf16_t* __restrict__ y_soft,
-                                                         int* __restrict__ index, int64_t M, int T, float inv_temp, int hard) {
+                                                         int* __restrict__ index, int64_t M, int T, float inv_temp, int hard,
+                                                         const float* __restrict__ temp_dev) {
+  if (temp_dev) inv_temp = 1.f / temp_dev[0];   // graph replay: the annealed temperature lives in device memory
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wid;
   if (row >= M) return;
@@ -198,22 +200,25 @@ __global__ __launch_bounds__(256) void gumbel_fwd_kernel(const float* __restrict
   if (lane == 0 && index) index[row] = mi;
 }
 extern "C" int dmi_gumbel_softmax_fwd(const float* logits, const float* u, uint16_t* y, uint16_t* y_soft, int32_t* index,
-                                      int64_t M, int T, float temperature, int hard, void* stream) {
-  DMI_REQUIRE(logits && u && y && y_soft && M > 0 && T % 8 == 0 && T <= 4096 && temperature > 0.f, "gumbel_fwd: bad args (T=%d)", T);
+                                      int64_t M, int T, float temperature, int hard, const float* temperature_dev, void* stream) {
+  DMI_REQUIRE(logits && u && y && y_soft && M > 0 && T % 8 == 0 && T <= 4096 && (temperature > 0.f || temperature_dev),
+              "gumbel_fwd: bad args (T=%d)", T);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)cdiv64(M, 4)), blk(256);
-  const float it = 1.f / temperature;
-  if (T <= 512) gumbel_fwd_kernel<1><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
-  else if (T <= 1024) gumbel_fwd_kernel<2><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
-  else if (T <= 2048) gumbel_fwd_kernel<4><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
-  else gumbel_fwd_kernel<8><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard);
+  const float it = temperature_dev ? 0.f : 1.f / temperature;
+  if (T <= 512) gumbel_fwd_kernel<1><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard, temperature_dev);
+  else if (T <= 1024) gumbel_fwd_kernel<2><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard, temperature_dev);
+  else if (T <= 2048) gumbel_fwd_kernel<4><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard, temperature_dev);
+  else gumbel_fwd_kernel<8><<<grid, blk, 0, st>>>(logits, u, y, y_soft, index, M, T, it, hard, temperature_dev);
   DMI_CHECK_LAUNCH("gumbel_fwd");
   return DMI_OK;
 }
 
 // dlogits = (1/T) * y_soft * (dy - sum_j dy_j y_soft_j)   (hard: straight-through => same formula on y_soft)
 __global__ __launch_bounds__(256) void gumbel_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y_soft,
-                                                         bf16_t* __restrict__ dlogits, int64_t M, int T, float inv_temp) {
+                                                         bf16_t* __restrict__ dlogits, int64_t M, int T, float inv_temp,
+                                                         const float* __restrict__ temp_dev) {
+  if (temp_dev) inv_temp = 1.f / temp_dev[0];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wid;
   if (row >= M) return;
@@ -237,9 +242,10 @@ __global__ __launch_bounds__(256) void gumbel_bwd_kernel(const bf16_t* __restric
   }
 }
 extern "C" int dmi_gumbel_softmax_bwd(const uint16_t* dy, const uint16_t* y_soft, uint16_t* dlogits, int64_t M, int T,
-                                      float temperature, void* stream) {
-  DMI_REQUIRE(dy && y_soft && dlogits && M > 0 && T % 8 == 0 && temperature > 0.f, "gumbel_bwd: bad args");
-  gumbel_bwd_kernel<<<dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream>>>(dy, y_soft, dlogits, M, T, 1.f / temperature);
+                                      float temperature, const float* temperature_dev, void* stream) {
+  DMI_REQUIRE(dy && y_soft && dlogits && M > 0 && T % 8 == 0 && (temperature > 0.f || temperature_dev), "gumbel_bwd: bad args");
+  gumbel_bwd_kernel<<<dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream>>>(
+      dy, y_soft, dlogits, M, T, temperature_dev ? 0.f : 1.f / temperature, temperature_dev);
   DMI_CHECK_LAUNCH("gumbel_bwd");
   return DMI_OK;
 }

@@ -85,7 +85,7 @@ def _declare(L):
         "dmi_assemble_tokens": (I, [P, P, P, I, I, I, I, I, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
         "dmi_sumsq": (I, [P, L64, P, P, P]),
-        "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P]),
+        "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P, P]),
         "dmi_cast_f32_bf16": (I, [P, P, L64, P]),
         "dmi_transpose_bf16_padded": (I, [P, P, I, I, I, P]),
         "dmi_transpose_bf16_batch": (I, [P, P, P, I, L64, P]),
@@ -97,8 +97,8 @@ def _declare(L):
         "dmi_pixel_interleave": (I, [P, P, I, I, I, I, P]),
         "dmi_pad_channels": (I, [P, P, L64, I, I, P]),
         "dmi_unpad_channels": (I, [P, P, L64, I, I, P]),
-        "dmi_gumbel_softmax_fwd": (I, [P, P, P, P, P, L64, I, F, I, P]),
-        "dmi_gumbel_softmax_bwd": (I, [P, P, P, L64, I, F, P]),
+        "dmi_gumbel_softmax_fwd": (I, [P, P, P, P, P, L64, I, F, I, P, P]),
+        "dmi_gumbel_softmax_bwd": (I, [P, P, P, L64, I, F, P, P]),
         "dmi_mse_workspace_bytes": (L64, []),
         "dmi_mse_loss": (I, [P, P, P, P, L64, I, I, F, P, P]),
         "dmi_add_f32": (I, [P, P, L64, P]),
@@ -337,10 +337,11 @@ def sumsq(g, n, out, ws):
     _check(lib().dmi_sumsq(_p(g), n, _p(out), _p(ws), _stream()), "sumsq")
 
 
-def adam_step(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, wd, grad_scale=1.0):
+def adam_step(p, g, m, v, p_bf16, n, gnorm_sq, clip, lr, beta1, beta2, eps, wd, grad_scale=1.0, lr_dev=None):
+    """lr_dev: optional 1-element fp32 DEVICE tensor the kernel reads the learning rate from (HIP-graph replay)"""
     _dev(p, g, m, v)
     _check(lib().dmi_adam_step(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(gnorm_sq), clip, lr, beta1, beta2, eps,
-                               wd, grad_scale, _stream()), "adam_step")
+                               wd, grad_scale, _p(lr_dev), _stream()), "adam_step")
 
 
 def cast_f32_bf16(inp, out, n):
@@ -409,15 +410,16 @@ def unpad_channels(inp, out, N, Cin, Cp):
     _check(lib().dmi_unpad_channels(_p(inp), _p(out), N, Cin, Cp, _stream()), "unpad_channels")
 
 
-def gumbel_softmax_fwd(logits, u, y, y_soft, index, M, T, temperature, hard):
+def gumbel_softmax_fwd(logits, u, y, y_soft, index, M, T, temperature, hard, temperature_dev=None):
     _dev(logits, u, y, y_soft, index)
     _check(lib().dmi_gumbel_softmax_fwd(_p(logits), _p(u), _p(y), _p(y_soft), _p(index), M, T, float(temperature), int(bool(hard)),
-                                        _stream()), "gumbel_softmax_fwd")
+                                        _p(temperature_dev), _stream()), "gumbel_softmax_fwd")
 
 
-def gumbel_softmax_bwd(dy, y_soft, dlogits, M, T, temperature):
+def gumbel_softmax_bwd(dy, y_soft, dlogits, M, T, temperature, temperature_dev=None):
     _dev(dy, y_soft, dlogits)
-    _check(lib().dmi_gumbel_softmax_bwd(_p(dy), _p(y_soft), _p(dlogits), M, T, float(temperature), _stream()), "gumbel_softmax_bwd")
+    _check(lib().dmi_gumbel_softmax_bwd(_p(dy), _p(y_soft), _p(dlogits), M, T, float(temperature), _p(temperature_dev), _stream()),
+           "gumbel_softmax_bwd")
 
 
 def mse_workspace_bytes():

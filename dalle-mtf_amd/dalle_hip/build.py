@@ -64,5 +64,32 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(tag, defines, verbose=False):
+    """an experiment build of the same sources with extra -D switches: tools/_build/libdalle_hip_<tag>.so (travels with the
+    gpurun snapshot, never loaded by the product; select with DALLE_HIP_LIB for same-call A/B runs, tools/ab.sh)"""
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools", "_build")
+    objdir = os.path.join(out_dir, "obj_" + tag)
+    os.makedirs(objdir, exist_ok=True)
+    lib = os.path.join(out_dir, f"libdalle_hip_{tag}.so")
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [_hipcc()] + FLAGS + ["-D" + d for d in defines] + ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out)
+            raise RuntimeError(f"hipcc failed for {src} ({tag})")
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
+    if verbose:
+        print("[dalle_hip.build] variant", lib)
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # python build.py --variant <tag> DEFINE [DEFINE ...]
+        print(build_variant(sys.argv[2], sys.argv[3:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv))

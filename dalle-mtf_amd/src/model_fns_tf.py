@@ -92,26 +92,26 @@ def vae_model_fn(features, labels, mode, params):
     eval_gumbel = True if eval_gumbel is None else eval_gumbel
     gumbel = train_gumbel if mode == ModeKeys.TRAIN else eval_gumbel
     temp = temperature_schedule(model.global_step, params)
-    loss, reconstruction = model.forward(features, return_recon_loss=True, temperature=temp, hard_gumbel=gumbel,
-                                         need_grad=(mode == ModeKeys.TRAIN))
     denormalize = lambda x: (x + 1) / 2          # reference model_fns_tf.py:71,83
     imgs = features["inputs"] if isinstance(features, dict) else features
     if mode == ModeKeys.EVAL:
+        loss, reconstruction = model.forward(features, return_recon_loss=True, temperature=temp, hard_gumbel=gumbel, need_grad=False)
         if st["writer"] is not None and float(loss) < 1e-9:      # the reference's record_if(loss < 1e-9) gate (:88)
             st["writer"].images(model.global_step, "eval/input_image", denormalize(imgs))
             st["writer"].images(model.global_step, "eval/reconstruction_image", denormalize(reconstruction))
         return EstimatorSpec(mode=mode, loss=loss, eval_metrics={"_loss": loss})
 
+    # TRAIN: forward + backward + optimizer run inside train_op as ONE step (DiscreteVAE.train_step: a replayed HIP graph on a
+    # single GPU); spec.loss is the device scalar that step fills in -- the loss of this batch before the update, as upstream.
     def train_op():
-        model.backward()
-        model.optimizer_step(params["lr"])
+        model.train_step(features, params["lr"], hard_gumbel=gumbel, temperature=temp)
         return model.global_step
 
     host_call = None
     if st["writer"] is not None:      # rank 0 only: loss (+ temperature), input and reconstruction images (reference :68-78)
-        def host_call_fn(step, loss, temperature, input, reconstruction):
+        def host_call_fn(step, loss, temperature, input):
             st["writer"].scalars(step, loss=loss, temperature=temperature)
             st["writer"].images(step, "input_image", denormalize(input))
-            st["writer"].images(step, "reconstruction_image", denormalize(reconstruction))
-        host_call = (host_call_fn, {"loss": loss, "temperature": temp, "input": imgs, "reconstruction": reconstruction})
-    return EstimatorSpec(mode=mode, loss=loss, train_op=train_op, host_call=host_call, training_hooks=[st["saver"]])
+            st["writer"].images(step, "reconstruction_image", denormalize(model.reconstruction()))   # of the step just run
+        host_call = (host_call_fn, {"loss": model.loss[0], "temperature": temp, "input": imgs})
+    return EstimatorSpec(mode=mode, loss=model.loss[0], train_op=train_op, host_call=host_call, training_hooks=[st["saver"]])

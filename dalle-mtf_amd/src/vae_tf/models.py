@@ -16,6 +16,7 @@ translate to the TF variable names and shapes of SURVEY.md Appendix B.
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional
 
@@ -97,8 +98,10 @@ class DiscreteVAE:
         self.n_hid = self.convblocks[-1][1]
         self.grid = self.Hs // (2 ** len(self.convblocks))
         self.global_step = 0
+        self._graphs, self._graph_warm, self._dyn_on, self._img_static = {}, False, False, None
         self._build_graph()
         self._alloc()
+        self._dyn = torch.zeros(2, dtype=torch.float32, device=self.dev)   # [lr_t, temperature] read by graph-replayed kernels
         # gradient exchange (mean over replicas = SUM here x grad_scale 1/world in the Adam kernel), overlapped with backward
         self.reducer = GradReducer(self.g, world_size, comm=comm, pg=process_group)
 
@@ -404,10 +407,11 @@ class DiscreteVAE:
             return self.logits.view(B, self.grid, self.grid, self.num_tokens)
         if noise is None:
             self.u.uniform_(1e-9, 1.0)
-        else:
+        elif not (isinstance(noise, str) and noise == "preset"):   # "preset": self.u was filled by the caller (graph replay)
             self.u.copy_(noise.to(self.dev).reshape(self.Mg, self.num_tokens))
         self.temperature = float(temperature)
-        dh.gumbel_softmax_fwd(self.logits, self.u, self.y, self.y_soft, self.index, self.Mg, self.num_tokens, self.temperature, hard_gumbel)
+        dh.gumbel_softmax_fwd(self.logits, self.u, self.y, self.y_soft, self.index, self.Mg, self.num_tokens, self.temperature,
+                              hard_gumbel, temperature_dev=self._temp_dev())
         x = self._decoder_from_y()
         if not return_recon_loss:
             return self.reconstruction()
@@ -623,7 +627,7 @@ class DiscreteVAE:
                 T, nh, Mg = self.num_tokens, self.n_hid, self.Mg
                 dh.gemm_tn(d, nh, self.y, T, self.gc2, Mg, nh, T, self.ws)                               # dC from x_dec = y C^T
                 dh.gemm_nt(d, nh, self.codebook_t, nh, self.dy, T, Mg, T, nh)                            # dy = dxdec . C
-                dh.gumbel_softmax_bwd(self.dy, self.y_soft, self.dlogits, Mg, T, self.temperature)
+                dh.gumbel_softmax_bwd(self.dy, self.y_soft, self.dlogits, Mg, T, self.temperature, temperature_dev=self._temp_dev())
                 dh.gemm_tn(self.x_enc, nh, self.dlogits, T, self._gv("codebook/codebook"), Mg, nh, T, self.ws)  # dC from logits = x C
                 dh.add_f32(self._gv("codebook/codebook"), self.gc2, nh * T)
                 nd = spare[0]
@@ -637,11 +641,75 @@ class DiscreteVAE:
         """tf.train.AdamOptimizer (src/model_fns_tf.py:58-60; Appendix A.8): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
         p -= lr_t*m/(sqrt(v)+eps).  grad_scale 1/world = CrossShardOptimizer's mean over replicas (:61)."""
         self.reducer.finish()
-        t = self.global_step + 1
-        lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
-        dh.adam_step(self.p, self.g, self.m, self.v, self.pb, self.total, None, 0.0, lr_t, beta1, beta2, eps, 0.0, 1.0 / self.world)
+        lr_t = self.lr_t(lr, beta1, beta2)
+        dh.adam_step(self.p, self.g, self.m, self.v, self.pb, self.total, None, 0.0, lr_t, beta1, beta2, eps, 0.0, 1.0 / self.world,
+                     lr_dev=self._dyn[0:1] if self._dyn_on else None)
         self.refresh_compute_copies(cast=False)
         self.global_step += 1
+
+    def lr_t(self, lr, beta1=0.9, beta2=0.999):
+        t = self.global_step + 1
+        return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+    # ------------------------------------------------------------------ whole step as one HIP graph
+    def _temp_dev(self):
+        return self._dyn[1:2] if self._dyn_on else None
+
+    def train_step(self, features, lr, hard_gumbel=True, temperature=1.0, noise=None, graph=None):
+        """forward + backward + optimizer_step.  The small configurations are launch-bound (vae_example: ~170 launches of a
+        few microseconds each; 3.2 ms per step from Python against ~1 ms of kernel time, profiles/r02_bench_vae_example.json),
+        so the step is captured ONCE as a HIP graph and replayed: per step the host then issues the image copy, the Gumbel
+        uniforms (drawn eagerly), two scalar fills and one graph launch.  The learning rate lr_t
+        (tf.train.AdamOptimizer's bias-corrected rate, src/model_fns_tf.py:58) and the annealed temperature (:40-45) live in
+        a 2-float device buffer the kernels read (dmi_adam_step lr_dev / dmi_gumbel_softmax_* temperature_dev), so one graph
+        serves the whole schedule.  Eager when: data-parallel (the exchange runs on its own stream and communicator), a
+        bench event hook is set, DALLE_VAE_GRAPH=0, or graph=False.  Same kernels, same order: results are bit-identical to
+        the eager step (tested).  Returns the device scalar loss."""
+        want = (os.environ.get("DALLE_VAE_GRAPH", "1") != "0") if graph is None else bool(graph)
+        img = features["inputs"] if isinstance(features, dict) else features
+        if not want or self.world > 1 or getattr(self, "event_hook", None) is not None:
+            self.forward(img, return_recon_loss=True, hard_gumbel=hard_gumbel, temperature=temperature, noise=noise, need_grad=True)
+            self.backward()
+            self.optimizer_step(lr)
+            return self.loss[0]
+        if self._img_static is None:
+            self._img_static = torch.empty(self.B, self.H, self.W, self.num_ch, dtype=torch.float32, device=self.dev)
+        self._img_static.copy_(img.to(dtype=torch.float32), non_blocking=True)
+        if noise is None:
+            self.u.uniform_(1e-9, 1.0)
+        else:
+            self.u.copy_(noise.to(self.dev).reshape(self.Mg, self.num_tokens))
+        self._dyn[0:1].fill_(self.lr_t(lr))          # by-value kernel arguments: no host buffer whose lifetime could race a replay
+        self._dyn[1:2].fill_(float(temperature))
+        self.temperature = float(temperature)
+        key = bool(hard_gumbel)
+        g = self._graphs.get(key)
+        if g is None:
+            self._dyn_on = True
+            try:
+                if not self._graph_warm:
+                    # first step eager (on the kernels' device-scalar path): lazily allocated buffers come into being
+                    # outside the capture
+                    self._step_body(key)
+                    self._graph_warm = True
+                    return self.loss[0]
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                step0 = self.global_step
+                with torch.cuda.graph(g):
+                    self._step_body(key)
+                self.global_step = step0          # capture records, it does not execute: the replay below is the step
+                self._graphs[key] = g
+            finally:
+                self._dyn_on = False
+        g.replay()
+        self.global_step += 1
+        return self.loss[0]
+
+    def _step_body(self, hard_gumbel):
+        self.forward(self._img_static, return_recon_loss=True, hard_gumbel=hard_gumbel, temperature=1.0, noise="preset", need_grad=True)
+        self.backward()
+        self.optimizer_step(1.0)      # lr / temperature arguments are ignored on the device-scalar path
 
     def state_dict(self):
         # reference-named variables as plain tensors in a plain dict: loadable with torch.load(weights_only=True)

@@ -160,12 +160,14 @@ int dmi_assemble_tokens(const int32_t* text, const float* vae_logits, int32_t* t
  * adam: mult = clip>0 ? clip/max(sqrt(*gnorm_sq),clip) : 1;  g*=mult; m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;
  *       p -= lr*(m/(sqrt(v)+eps) + wd*p)   (NO bias correction); p_bf16 (optional) = bf16(p).
  * tf_adam=1 switches to tf.train.AdamOptimizer semantics (bias-corrected lr_t passed as lr, eps as given,
- * grad_scale multiplies g first: CrossShardOptimizer mean) -- src/model_fns_tf.py:58-61. */
+ * grad_scale multiplies g first: CrossShardOptimizer mean) -- src/model_fns_tf.py:58-61.
+ * lr_dev (nullable): when given, the kernel reads the learning rate from lr_dev[0] (DEVICE memory) and ignores `lr` -- the
+ * per-step schedule value (src/optimizers.py:46-76) can then change between replays of a captured HIP graph. */
 int64_t dmi_sumsq_workspace_bytes(int64_t n);
 int dmi_sumsq(const float* g, int64_t n, float* out, void* workspace, void* stream);
 int dmi_adam_step(float* p, const float* g, float* m, float* v, uint16_t* p_bf16, int64_t n,
                   const float* gnorm_sq, float clip, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, float grad_scale, void* stream);
+                  float weight_decay, float grad_scale, const float* lr_dev, void* stream);
 
 /* ---- data-parallel exchange: the all-reduce mtf inserts for `layout: batch_dim:data`   src/model_fns.py:81-82,189,
  * VAE src/model_fns_tf.py:61 (CrossShardOptimizer).  One process per GPU, RCCL over xGMI, bound at run time
@@ -242,11 +244,13 @@ int dmi_conv2d_f32(const float* x, int B, int H, int W, int C, int Ho, int Wo, i
 int dmi_space_to_depth_f32(const float* img, float* stacked, int B, int Hs, int Ws, int C, int s, int Cp, void* stream);
 int dmi_depth_to_space_f32(const float* stacked, float* img, int B, int Hs, int Ws, int C, int s, int Cp, void* stream);
 /* K13 gumbel_softmax (layers.py:4-21) with INJECTED uniforms u in [1e-9, 1): y = softmax((logits - log(-log u))/T);
- * hard: y = one_hot(argmax) (first max), gradient straight-through.  y, y_soft bf16 [M,T]; index int32 [M] (nullable). */
+ * hard: y = one_hot(argmax) (first max), gradient straight-through.  y, y_soft bf16 [M,T]; index int32 [M] (nullable).
+ * temperature_dev (nullable): read T from temperature_dev[0] (DEVICE memory) instead of the argument, so the annealed
+ * schedule (src/model_fns_tf.py:40-45) can advance between replays of a captured HIP graph. */
 int dmi_gumbel_softmax_fwd(const float* logits, const float* u, uint16_t* y, uint16_t* y_soft, int32_t* index,
-                           int64_t M, int T, float temperature, int hard, void* stream);
+                           int64_t M, int T, float temperature, int hard, const float* temperature_dev, void* stream);
 int dmi_gumbel_softmax_bwd(const uint16_t* dy, const uint16_t* y_soft, uint16_t* dlogits, int64_t M, int T,
-                           float temperature, void* stream);
+                           float temperature, const float* temperature_dev, void* stream);
 /* K14 mse_loss (layers.py:24-25): loss[0] = mean((img - out)^2) over N*Cin; dout (nullable) = 2(out-img)*grad_scale/(N*Cin) */
 int64_t dmi_mse_workspace_bytes(void);
 int dmi_mse_loss(const float* img, const uint16_t* outp, uint16_t* dout, float* loss, int64_t N, int Cin, int Cp,

@@ -24,10 +24,10 @@ def test_vae_model_fn_trains_and_tf_adam_semantics():
     spec = vae_model_fn(img, img, ModeKeys.TRAIN, p)
     model = p["_vae_state_train"]["model"]
     before = model.export_reference()
-    loss0 = float(spec.loss)
-    assert np.isfinite(loss0)
-    step = spec.train_op()
+    step = spec.train_op()          # forward + backward + update run as one step inside train_op (spec.loss is filled by it)
     assert step == 1
+    loss0 = float(spec.loss)
+    assert np.isfinite(loss0) and loss0 > 0
     grads = model.export_reference(model.g)
     after = model.export_reference()
     # tf.train.AdamOptimizer step 1 on the HIP gradients must reproduce the HIP update (update-rule parity)
@@ -46,6 +46,35 @@ def test_vae_model_fn_trains_and_tf_adam_semantics():
     assert np.isfinite(float(ev.loss))
     with pytest.raises(NotImplementedError):
         vae_model_fn(img, img, ModeKeys.PREDICT, p)
+
+
+def test_vae_graph_replayed_step_is_bit_identical_to_the_eager_step():
+    """DiscreteVAE.train_step captures forward + backward + TF-Adam as ONE HIP graph (launch-bound small configurations) with
+    the scheduled scalars -- bias-corrected lr_t and the annealed Gumbel temperature -- in device memory.  Same kernels in the
+    same order: after 6 steps with a CHANGING temperature and identical noise, weights, Adam state and losses must equal the
+    eager run bit for bit."""
+    from oracle import vae_oracle as vo
+    from src.vae_tf import DiscreteVAE
+    c = dict(num_tokens=128, dimensions=16, convblocks=[[2, 64], [2, 64]])
+    P = vo.init_params(vo.VaeConfig(**c), seed=3, bias_perturb=0.02)
+    runs = {}
+    for mode in ("eager", "graph"):
+        vae = DiscreteVAE(batch_size=4, use_bf16=True, **c)
+        vae.load_reference_params(P)
+        losses = []
+        for t in range(6):
+            img = torch.from_numpy(vo.synthetic_images(4, 16, seed=10 + t))
+            u = torch.from_numpy(vo.synthetic_uniforms((4, vae.grid, vae.grid, 128), seed=20 + t))
+            loss = vae.train_step(img, 1e-3, hard_gumbel=(t % 2 == 0), temperature=1.0 - 0.1 * t, noise=u, graph=(mode == "graph"))
+            losses.append(float(loss))
+        assert vae.global_step == 6
+        if mode == "graph":
+            assert len(vae._graphs) == 2          # one graph per Gumbel mode, each serving several temperatures / lr_t values
+        runs[mode] = (losses, vae.p.clone(), vae.m.clone(), vae.v.clone())
+        del vae
+    assert runs["eager"][0] == runs["graph"][0], (runs["eager"][0], runs["graph"][0])
+    for a, b in zip(runs["eager"][1:], runs["graph"][1:]):
+        assert torch.equal(a, b)
 
 
 def test_dalle_model_fn_with_vae_tokenisation():

@@ -1,4 +1,10 @@
 #!/bin/bash
-# A/B an engine-level environment toggle on the step benchmark: tools/ab_env.sh VAR [rounds]
-V=${1:-DALLE_GROUPED_WGRAD}; R=${2:-2}
-for i in $(seq 1 $R); do for g in 0 1; do env $V=$g python bench.py --steps 30 --warmup 8 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$V=$g', round(d['ms_per_step'],3))"; done; done
+# A/B of engine switches inside ONE gpurun call (boxes differ by +-4 %): alternates the arms, prints ms/step per run.
+# usage: tools/ab_env.sh "<ENV=val ...>" "<ENV=val ...>" [reps] [bench args...]
+A="$1"; B="$2"; REPS="${3:-2}"; shift 3 || true
+for r in $(seq 1 "$REPS"); do
+  for arm in "$A" "$B"; do
+    out=$(env $arm python bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" 2>/dev/null | tail -1)
+    echo "[$arm] $(echo "$out" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("ms_per_step=%.3f value=%.0f" % (d["ms_per_step"], d["value"]))')"
+  done
+done
