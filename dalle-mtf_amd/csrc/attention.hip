@@ -934,3 +934,90 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
 }
+
+// =====================================================================================
+// incremental decode: ONE query position against the key/value cache  
+// =====================================================================================
+// The reference scaffolds incremental inference (src/dalle_mtf/models.py:246-254: the new k, v replace row `position - 1`
+// of the stored states; :281-285: the mask row of that position selects keys <= position) but never finishes the predict
+// path.  Here the cache IS the forward pass's [B*S, 3d] projection buffer: the caller's QKV GEMM writes row `pos` of every
+// batch element in place (row pitch S*3d), then this kernel computes, per (batch, head),
+//     o = softmax(q_pos . K[0..pos]^T) V[0..pos]           (unscaled logits, as everywhere on this path)
+// HBM-bound (2 * (pos+1) * 256 B per head): one block per (b, h), a wave per 64-key chunk with key = lane for the scores
+// (no cross-lane reduction per key), online softmax per wave, P.V with lane = 2 output dims; the four waves merge through LDS.
+// P is rounded to bf16 before P.V and the row sum is taken over the unrounded fp32 values -- the same places where the tiled
+// forward kernel rounds -- so decode logits track full-forward logits to bf16 noise.
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, int H, int S, int pos) {
+  __shared__ float qs[HD];
+  __shared__ float ps[4][64];
+  __shared__ float red_m[4], red_l[4];
+  __shared__ float oacc[4][HD];
+  const int bh = blockIdx.x, b = bh / H, hh = bh % H;
+  const int d = H * HD;
+  const int64_t ld3 = 3 * (int64_t)d;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bf16_t* base = qkv + (int64_t)b * S * ld3 + hh * HD;
+  if (threadIdx.x < HD) qs[threadIdx.x] = bf2f(base[(int64_t)pos * ld3 + threadIdx.x]);
+  __syncthreads();
+  float m = -1e30f, l = 0.f, o0 = 0.f, o1 = 0.f;
+  for (int c = wid; c * 64 <= pos; c += 4) {
+    const int key = c * 64 + lane;
+    const bool valid = key <= pos;
+    float s = 0.f;
+    if (valid) {
+      const u32x4* kr = (const u32x4*)(base + d + (int64_t)key * ld3);
+#pragma unroll
+      for (int i = 0; i < HD / 8; ++i) {
+        float f[8];
+        unpack8(kr[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s = __builtin_fmaf(f[j], qs[8 * i + j], s);
+      }
+    }
+    s = valid ? s : -1e30f;
+    const float mn = fmaxf(m, wave_max(s));
+    const float alpha = __expf(m - mn);
+    const float p = valid ? __expf(s - mn) : 0.f;
+    l = l * alpha + wave_sum(p);
+    o0 *= alpha;
+    o1 *= alpha;
+    m = mn;
+    ps[wid][lane] = bf2f(f2bf(p));
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: in-order LDS, no block barrier needed
+    const int nk = (pos - c * 64 + 1 < 64) ? pos - c * 64 + 1 : 64;
+    const bf16_t* vr = base + 2 * d + (int64_t)(c * 64) * ld3 + 2 * lane;
+    for (int j = 0; j < nk; ++j) {
+      const unsigned vv = *(const unsigned*)(vr + (int64_t)j * ld3);
+      const float pj = ps[wid][j];
+      o0 = __builtin_fmaf(pj, __uint_as_float(vv << 16), o0);
+      o1 = __builtin_fmaf(pj, __uint_as_float(vv & 0xffff0000u), o1);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) { red_m[wid] = m; red_l[wid] = l; }
+  oacc[wid][2 * lane] = o0;
+  oacc[wid][2 * lane + 1] = o1;
+  __syncthreads();
+  if (wid == 0) {
+    const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float L = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {      // fixed order: deterministic
+      const float sc = __expf(red_m[w] - M);
+      L += red_l[w] * sc;
+      a0 += oacc[w][2 * lane] * sc;
+      a1 += oacc[w][2 * lane + 1] * sc;
+    }
+    const float inv = 1.f / L;
+    *(unsigned*)(o + (int64_t)b * d + hh * HD + 2 * lane) = pack2bf(a0 * inv, a1 * inv);
+  }
+}
+
+extern "C" int dmi_attention_decode(const uint16_t* qkv, uint16_t* o, int B, int H, int S, int pos, void* stream) {
+  DMI_REQUIRE(qkv && o, "attention_decode: null pointer");
+  DMI_REQUIRE(B > 0 && H > 0 && S > 0 && pos >= 0 && pos < S, "attention_decode: need 0 <= pos < S (pos=%d, S=%d)", pos, S);
+  attn_decode_kernel<<<dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream>>>(qkv, o, H, S, pos);
+  DMI_CHECK_LAUNCH("attention_decode");
+  return DMI_OK;
+}

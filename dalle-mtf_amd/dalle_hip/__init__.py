@@ -75,6 +75,7 @@ def _declare(L):
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
         "dmi_attention_fwd": (I, [P, P, P, I, I, I, P]),
         "dmi_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
+        "dmi_attention_decode": (I, [P, P, I, I, I, I, P]),
         "dmi_label_logit": (I, [P, I, P, I, P, P, P, P, L64, I, I, P]),
         "dmi_gemm_nt_softmax_partials": (L64, [I]),
         "dmi_gemm_nt_softmax": (I, [P, I, P, I, P, P, P, I, P, I, I, I, P]),
@@ -197,6 +198,12 @@ def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None,
     _dev(A, Bt, C)
     _check(lib().dmi_gemm_nt(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _p(residual),
                              _p(relu_src), _p(rowscale), _stream()), "gemm_nt")
+
+
+def attention_decode(qkv, o, B, H, S, pos):
+    """one query position against the K/V cache held in the [B*S, 3d] projection buffer (row pos already written)"""
+    _dev(qkv, o)
+    _check(lib().dmi_attention_decode(_p(qkv), _p(o), B, H, S, int(pos), _stream()), "attention_decode")
 
 
 def gemm_nt_splitk_workspace_bytes(M, N, nsplit):

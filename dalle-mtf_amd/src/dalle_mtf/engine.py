@@ -363,31 +363,81 @@ class DalleEngine:
         return self.z.view(self.B, self.S, self.Vp)[:, :, :self.V].float()
 
     # ------------------------------------------------------------------ sampling
-    def sample_image_tokens(self, text: torch.Tensor, temperature: float = 1.0, top_k: int = 0, seed: int = 0) -> torch.Tensor:
+    def sample_image_tokens(self, text: torch.Tensor, temperature: float = 1.0, top_k: int = 0, seed: int = 0,
+                            kv_cache: bool = True) -> torch.Tensor:
         """Autoregressive image-token sampling: text int32 [B, T] -> image-token ids [B, P] in [0, image_vocab_size).
         The reference scaffolds this (is_incremental_inference, models.py:246-254,281-285) but its predict path raises
-        NotImplementedError (model_fns.py:135-136); here the plain form: one full evaluation forward per generated position (the
-        causal mask makes the not-yet-generated tail irrelevant), logits restricted to the image vocabulary, temperature /
-        top-k / greedy (temperature 0).  No KV cache: 1024 forwards of the dalle_example shape take a few seconds."""
+        NotImplementedError (model_fns.py:135-136).  Logits are restricted to the image vocabulary; temperature / top-k /
+        greedy (temperature 0).
+
+        kv_cache=True (default): ONE full forward over the text prefix fills the per-layer key/value cache (the [B*S, 3d]
+        projection buffers of the forward pass), then every further token is one incremental step over B rows --
+        decode_step(): QKV GEMM writing row `pos` of the cache in place, dmi_attention_decode (one query against keys
+        0..pos), out-projection, MLP -- ~45 launches of a few microseconds instead of a 1280-position forward.
+        kv_cache=False: the plain form, one full evaluation forward per generated position (the causal mask makes the
+        not-yet-generated tail irrelevant); kept as the cross-check the cached path is tested against."""
         B, T, S, P = self.B, self.T, self.S, self.S - self.T
         assert text.shape == (B, T)
         lo, hi = self.text_vocab_size, self.text_vocab_size + self.image_vocab_size
         toks = torch.full((B, S), lo, dtype=torch.int32, device=self.dev)
         toks[:, :T] = text.to(device=self.dev, dtype=torch.int32)
         gen = torch.Generator(device=self.dev).manual_seed(seed)
-        for pos in range(P):
-            self.forward(toks, need_grad=False)
-            z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi].float()       # the position before predicts token T + pos
+        if kv_cache and self.recompute:
+            raise dh.DalleHipError("kv_cache sampling needs the per-layer projection buffers (recompute_grad shares one set)")
+
+        def pick(z):
             if temperature <= 0:
-                nxt = z.argmax(-1)
+                return z.argmax(-1)
+            z = z / temperature
+            if top_k:
+                kth = z.topk(min(top_k, z.shape[-1]), dim=-1).values[:, -1:]
+                z = z.masked_fill(z < kth, float("-inf"))
+            return torch.multinomial(torch.softmax(z, -1), 1, generator=gen).squeeze(-1)
+
+        for pos in range(P):
+            if not kv_cache or pos == 0:      # (prefill: the full forward also leaves k, v of positions < T in the cache)
+                self.forward(toks, need_grad=False)
+                z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi].float()   # the position before predicts token T + pos
             else:
-                z = z / temperature
-                if top_k:
-                    kth = z.topk(min(top_k, z.shape[-1]), dim=-1).values[:, -1:]
-                    z = z.masked_fill(z < kth, float("-inf"))
-                nxt = torch.multinomial(torch.softmax(z, -1), 1, generator=gen).squeeze(-1)
-            toks[:, T + pos] = (nxt + lo).to(torch.int32)
+                z = self.decode_step(toks[:, T + pos - 1].contiguous(), T + pos - 1)
+            toks[:, T + pos] = (pick(z) + lo).to(torch.int32)
         return (toks[:, T:] - lo).contiguous()
+
+    def decode_step(self, tokens_at_pos: torch.Tensor, pos: int) -> torch.Tensor:
+        """Incremental inference (reference hooks src/dalle_mtf/models.py:246-254,281-285): the hidden state of sequence
+        position `pos` alone, given the tokens int32 [B] at that position and the key/value cache of positions < pos left by
+        forward() / earlier decode steps in self.qkv[l].  Returns fp32 logits over the IMAGE vocabulary [B, image_vocab_size]
+        (what predicts the token at pos + 1)."""
+        B, d, L, H, S = self.B, self.d, self.L, self.H, self.S
+        assert tokens_at_pos.shape == (B,) and tokens_at_pos.dtype == torch.int32 and 0 <= pos < S
+        if getattr(self, "_dec", None) is None:
+            b16 = dict(dtype=torch.bfloat16, device=self.dev)
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            self._dec = dict(x=[torch.empty(B, d, **b16) for _ in range(2)], xn=torch.empty(B, d, **b16), o=torch.empty(B, d, **b16),
+                             h=torch.empty(B, 4 * d, **b16), st=[torch.empty(B, **f32) for _ in range(2)],
+                             z=torch.empty(B, self.image_vocab_size, **b16))
+        D = self._dec
+        x, x1, xn, o, h, st, z = D["x"][0], D["x"][1], D["xn"], D["o"], D["h"], D["st"], D["z"]
+        wpe = self._w("positional_embedding/wpe")
+        dh.embed_fwd(tokens_at_pos, self._w("embedding/wte"), wpe[pos:pos + 1], x, 1, d, self.V)   # every row takes wpe[pos]
+        for l in range(L):
+            p = f"layer_{l}/"
+            cache = self.qkv[l]                                        # [B*S, 3d]; row b*S + pos <- q | k | v of this step
+            dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), xn, st[0], st[1], B, d)
+            dh.gemm_nt(xn, d, self.tview(p + "attn/qkv"), d, cache[pos:], S * 3 * d, B, 3 * d, d)
+            dh.attention_decode(cache, o, B, H, S, pos)
+            dh.gemm_nt(o, d, self.tview(p + "attn/o"), d, x1, d, B, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
+                       bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
+            dh.layernorm_fwd(x1, self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), xn, st[0], st[1], B, d)
+            dh.gemm_nt(xn, d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, h, 4 * d, B, 4 * d, d, dh.GEMM_BIAS | dh.GEMM_RELU,
+                       bias=self._w(p + "mlp/mlp_linear_1/bias"))
+            dh.gemm_nt(h, 4 * d, self.tview(p + "mlp/mlp_linear_2/kernel"), 4 * d, x, d, B, d, 4 * d,
+                       dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=x1)
+        dh.layernorm_fwd(x, self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), xn, st[0], st[1], B, d)
+        lo, nv = self.text_vocab_size, self.image_vocab_size
+        Wt = self.tview("to_logits/linear_out/kernel")                 # [Vp, d]: rows lo .. lo + nv are the image vocabulary
+        dh.gemm_nt(xn, d, Wt[lo:lo + nv], d, z, nv, B, nv, d)
+        return z.float() + self._w("to_logits/linear_out/bias")[lo:lo + nv].float()
 
     # ------------------------------------------------------------------ backward
     def _gv(self, name):

@@ -117,6 +117,12 @@ int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int H
 int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* scratch,
                       uint16_t* dqkv, int B, int H, int S, void* stream);
 
+/* Incremental decode (the reference's unfinished is_incremental_inference path, src/dalle_mtf/models.py:246-254,281-285):
+ * one query position `pos` against the key/value cache.  qkv = the forward pass's projection buffer [B*S, 3*H*128] used as the
+ * cache; row b*S + pos must already hold q | k | v of the new position (the caller's QKV GEMM writes it in place with row
+ * pitch S*3d).  o[b, h*128 ..] = softmax(q . K[0..pos]^T) V[0..pos], bf16 [B, H*128].  Unscaled logits, keys <= pos only. */
+int dmi_attention_decode(const uint16_t* qkv, uint16_t* o, int B, int H, int S, int pos, void* stream);
+
 /* ---- K7/K8  to_logits + cross entropy, labels = shift(tokens)   models.py:391-395,348-359,407-410
  * labels[t] = tokens[t+1], last = eos (bit-exact int path). */
 int dmi_shift_labels(const int32_t* tokens, int32_t* labels, int B, int S, int eos, void* stream);

@@ -233,3 +233,67 @@ def test_greedy_sampling_matches_oracle_and_decodes():
     onehot = torch.nn.functional.one_hot(toks.cpu().long().view(2, 4, 4), 64).float()
     want = vo.decoder({k: torch.tensor(v) for k, v in VP.items()}, onehot, vcfg).numpy()
     assert float(np.abs(img.cpu().numpy() - want).max()) <= 5e-2 * max(1.0, float(np.abs(want).max()))
+
+
+@pytest.mark.parametrize("B,H,S", [(2, 1, 72), (3, 2, 320)])
+def test_attention_decode_kernel_vs_fp32_math(B, H, S):
+    """dmi_attention_decode: one query position against the cache, for positions at the start, at 64-key chunk boundaries and at
+    the end; vs fp32 softmax(q K^T) V on the same bf16 inputs (unscaled logits, keys <= pos)."""
+    import dalle_hip as dh
+    d = H * 128
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(B * S, 3 * d, generator=g) * 0.3).to(torch.bfloat16)
+    qd = qkv.cuda()
+    o = torch.empty(B, d, dtype=torch.bfloat16, device="cuda")
+    f = qkv.float().view(B, S, 3, H, 128)
+    for pos in sorted({0, 1, 63, 64, 65, 127, 128, S // 2, S - 2, S - 1} & set(range(S))):
+        dh.attention_decode(qd, o, B, H, S, pos)
+        q, k, v = f[:, pos, 0], f[:, :pos + 1, 1], f[:, :pos + 1, 2]           # [B,H,128], [B,p+1,H,128]
+        w = torch.softmax(torch.einsum("bhd,bkhd->bhk", q, k), -1)
+        ref = torch.einsum("bhk,bkhd->bhd", w, v).reshape(B, d)
+        err = float((o.float().cpu() - ref).abs().max())
+        assert err <= 1.6e-2 * float(ref.abs().max()) + 2e-3, (pos, err)
+
+
+def test_kv_cached_decode_equals_full_forward():
+    """Incremental inference (reference hooks src/dalle_mtf/models.py:246-254,281-285): with the key/value cache, the logits of
+    position p computed from ONE new row equal the full forward's logits at p (teacher forcing over a 320-position sequence:
+    every 64-key chunk count, batch 3), and the cached greedy sampler emits the same tokens as the one-forward-per-token
+    sampler wherever the top-2 logit gap exceeds twice the measured logit difference."""
+    from oracle import dalle_oracle as do
+    from src.dalle_mtf.engine import DalleEngine
+    T, P, tv, iv, B = 16, 304, 60, 64, 3
+    cfg = do.DalleConfig(128, tv, iv, T, P, 2, 1)
+    eng = DalleEngine(128, 2, 1, tv, iv, T, P, batch_size=B, hparams=dict(lr=1e-3, train_steps=10))
+    eng.load_reference_params(do.init_params(cfg, seed=9, perturb=0.05))
+    S = T + P
+    toks = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(B, T, tv, seed=1),
+                                               do.synthetic_image_tokens(B, P, iv, seed=2), tv)).cuda()
+    eng.forward(toks, need_grad=False)                      # also the prefill: k, v of every position are in the cache
+    full = eng.z.view(B, S, eng.Vp)[:, :, tv:tv + iv].float().clone()
+    worst = 0.0
+    for p in list(range(T - 1, T + 70)) + [127, 128, 129, 255, 256, S - 2, S - 1]:
+        z = eng.decode_step(toks[:, p].contiguous(), p)     # rewrites row p of the cache with the same values
+        worst = max(worst, float((z - full[:, p]).abs().max()))
+    scale = float(full.abs().max())
+    print("decode vs full forward: max |dlogit|", worst, "of", scale)
+    assert worst <= 2.5e-2 * scale, (worst, scale)
+    text = toks[:, :T].contiguous()
+    a = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True)
+    b = eng.sample_image_tokens(text, temperature=0.0, kv_cache=False)
+    agree = (a == b)
+    # positions after a first disagreement see different prefixes; compare up to and including it
+    first_bad = [int((~agree[i]).nonzero()[0]) if not bool(agree[i].all()) else P for i in range(B)]
+    for i in range(B):
+        if first_bad[i] < P:      # a disagreement must be a near-tie of the full-forward logits at that position
+            seq = torch.cat([text[i], b[i, :first_bad[i]].to(torch.int32) + tv, torch.full((S - T - first_bad[i],), tv, dtype=torch.int32, device="cuda")])
+            eng.forward(seq.repeat(B, 1), need_grad=False)
+            zz = eng.z.view(B, S, eng.Vp)[0, T + first_bad[i] - 1, tv:tv + iv].float()
+            top2 = zz.topk(2).values
+            assert float(top2[0] - top2[1]) <= 2 * worst + 1e-3, (i, first_bad[i], float(top2[0] - top2[1]), worst)
+    # (a random-initialised model has nearly flat logits, so near-ties -- and with them a first divergence -- are common; on
+    # MI355X: decode-vs-full logit difference 0.0043 of a 0.85 logit range, first divergences at positions 304 (none), 95, 50)
+    # seeded stochastic sampling runs on the cached path and is reproducible
+    c1 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
+    c2 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
+    assert torch.equal(c1, c2) and int(c1.max()) < iv and int(c1.min()) >= 0
