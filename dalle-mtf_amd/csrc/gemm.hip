@@ -24,7 +24,6 @@
 #include <type_traits>
 
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
-static int g_opt_nt9 = 0;        // ping-pong form of the 256x256 NT tile: 0 never, 1 wherever nt8 would run, 2 always (tests)
 static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (long K, whole residencies), 2 always (tests)
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn8 = 1;        // 256x256 weight-gradient tile (8 waves): 0 never, 1 auto (few tiles, many row splits), 2 always (tests)
@@ -35,7 +34,6 @@ extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt8")) return g_opt_nt8;
-  if (!strcmp(name, "nt9")) return g_opt_nt9;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
   if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
@@ -45,7 +43,6 @@ extern "C" int dmi_get_option(const char* name) {
 extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
-  if (!strcmp(name, "nt9")) { g_opt_nt9 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
   if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
@@ -570,173 +567,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
   }
 }
 
-// =====================================================================================
-// NT kernel v9: the 256x256 tile of v8 with the two waves of every SIMD in PING-PONG and REGISTER-STAGED operand tiles
-// (cdna_hip_programming.md: the 8-phase template's wave role diversity + s_setprio, T14 issue-early / write-late).
-// What bounds v2 / v4 / v8 is not L2 bandwidth but the ISSUE cost of the LDS-DMA instruction: one `buffer_load ... lds` piece
-// (1 KiB) blocks its wave for 100-185 cycles when the wave also carries fragment reads and MFMAs (MI355X_MICROARCH.md
-// cycle table; r03 ping-pong experiment with DMA staging: L phase ~800 cycles against a 512-cycle MFMA phase, +2 % only).
-// A plain buffer_load into registers issues in a few cycles and a ds_write_b128 in ~13, at the price of 16 staging VGPRs
-// per wave -- affordable here because a wave holds only ONE 32-wide slab of fragments (48 VGPRs) at a time.
-//   K is cut into 32-wide slabs; the waves form two groups (group = wave >> 2 = the M half; waves w and w + 4 share a SIMD)
-//   running the SAME stream one tick apart:
-//     L(p): 12 ds_read_b128 (all fragments of slab p) | ds_write_b128 x4 of the staged pieces of slab p+3 | buffer_load x4 of
-//           slab p+4 into the staging registers          -- ~300 cycles, no MFMA
-//     M(p): 16 MFMAs from registers under s_setprio 1    -- 512 cycles
-//   so each SIMD always has exactly one wave feeding the matrix pipe while the other does the LDS / memory work of its next
-//   slab.  One s_barrier per tick.  The LDS ring is 4 slabs x 32 KiB (A 256x32 | B 256x32, 64-B rows, chunk ^= (row>>2)&3
-//   applied on the global address so the LDS writes are lane-linear and the ds_read_b128 fragment reads conflict-free).
-//   Hazards: slab p+3 is written into the buffer of slab p-1 during L(p); its last readers were the L(p-1) phases of both
-//   groups, each retired by lgkmcnt(0) in front of a barrier every wave has passed since.  It is first read in L(p+3), three
-//   barriers after the writers' lgkmcnt(0).  Same k order as v2 / v4 / v8 -> bit-identical results.
-// =====================================================================================
-#define STG9 32768
-template <int FLAGS>
-__global__ __launch_bounds__(512, 2) void gemm_nt9_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slabs][A 16K | B 16K]
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wid >> 2;          // ping-pong group (= M half of the tile)
-  const int wm = g, wn = wid & 3;
-  const int r = lane & 31, h = lane >> 5;
-
-  int tm, tn;
-  tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
-  const int m0 = tm * BM8, n0 = tn * BN8;
-  const int kb = blockIdx.y * a.k_per_split;
-  const int ke = (kb + a.k_per_split < a.K) ? kb + a.k_per_split : a.K;
-  const int NP = (ke - kb) / 32;   // slabs; even and >= 2 (K % 64 == 0)
-
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda + kb), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)n0 * a.ldb + kb), 0, 0x7fffffff, 0x00020000);
-  int voa[2], vob[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 512 * i, row = c >> 2, pc = c & 3;
-    const int src_ch = pc ^ ((row >> 2) & 3);
-    const int ra_ = m0 + row < a.M ? row : a.M - 1 - m0;   // clamp inside the matrix (results discarded)
-    const int rb_ = n0 + row < a.N ? row : a.N - 1 - n0;
-    voa[i] = (ra_ * a.lda + 8 * src_ch) * 2;
-    vob[i] = (rb_ * a.ldb + 8 * src_ch) * 2;
-  }
-  // fragment offsets for slabs 0/1 (immediate offsets reach 64 KiB) and for slabs 2/3 (+ 64 KiB in the address register)
-  int offa[2][2], offb[2][2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    offa[0][kk] = lds4_off(wm * 128 + r, kk * 2 + h);
-    offb[0][kk] = 16384 + lds4_off(wn * 64 + r, kk * 2 + h);
-    offa[1][kk] = offa[0][kk] + 65536;
-    offb[1][kk] = offb[0][kk] + 65536;
-  }
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  bf16x8 fa[2][4], fb[2][2];
-  u32x4 sA[2], sB[2];                  // the staged pieces (2 x 16 B of A, 2 x 16 B of B per lane) of one slab
-
-  auto gload = [&](int slab) {         // issue-early: 4 buffer loads into the staging registers
-    const int soff = slab * 64;
-    sA[0] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa[0], soff, 0);
-    sA[1] = __builtin_amdgcn_raw_buffer_load_b128(ra, voa[1], soff, 0);
-    sB[0] = __builtin_amdgcn_raw_buffer_load_b128(rb, vob[0], soff, 0);
-    sB[1] = __builtin_amdgcn_raw_buffer_load_b128(rb, vob[1], soff, 0);
-  };
-  auto lwrite = [&](auto stc) {        // write-late: lane-linear 16-B stores (the swizzle sits in the global address)
-    constexpr int st = decltype(stc)::value;
-    char* base = smem + st * STG9 + tid * 16;
-    *(u32x4*)(base) = sA[0];
-    *(u32x4*)(base + 8192) = sA[1];
-    *(u32x4*)(base + 16384) = sB[0];
-    *(u32x4*)(base + 16384 + 8192) = sB[1];
-  };
-  auto load_frags = [&](auto stc) {    // every fragment of one slab into registers
-    constexpr int st = decltype(stc)::value;
-    constexpr int hi = st >> 1, so = (st & 1) * STG9;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[kk][i] = *(const bf16x8*)(smem + offa[hi][kk] + so + i * 2048);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) fb[kk][j] = *(const bf16x8*)(smem + offb[hi][kk] + so + j * 2048);
-    }
-  };
-  auto mfmas = [&]() {                 // M phase: 16 MFMAs from registers
-    MFMA_PRIO(1);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);  // D[n][m]
-    MFMA_PRIO(0);
-  };
-  // tick boundary: this wave's LDS reads and writes have completed (lgkmcnt) before anyone passes the barrier
-  auto boundary = [&]() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  };
-  auto slab = [&](int p, auto stc) {   // slab p lives in ring slot stc = p & 3; slab p + 3 goes to slot (stc + 3) & 3
-    constexpr int st = decltype(stc)::value;
-    boundary();
-    load_frags(stc);
-    if (p + 3 < NP) lwrite(std::integral_constant<int, (st + 3) & 3>{});   // staged since L(p-1) (or the prologue)
-    if (p + 4 < NP) gload(p + 4);
-    boundary();
-    mfmas();
-  };
-
-  // prologue: slabs 0, 1, 2 into the ring, slab 3 staged in registers
-  gload(0);
-  lwrite(std::integral_constant<int, 0>{});
-  gload(1);
-  lwrite(std::integral_constant<int, 1>{});
-  if (NP > 2) {
-    gload(2);
-    lwrite(std::integral_constant<int, 2>{});
-  }
-  if (NP > 3) gload(3);
-  if (g == 1) boundary();                       // the stagger: group 1 runs one tick behind group 0
-  int p = 0;
-  for (; p + 4 <= NP; p += 4) {
-    slab(p, std::integral_constant<int, 0>{});
-    slab(p + 1, std::integral_constant<int, 1>{});
-    slab(p + 2, std::integral_constant<int, 2>{});
-    slab(p + 3, std::integral_constant<int, 3>{});
-  }
-  if (p < NP) {   // NP % 4 == 2
-    slab(p, std::integral_constant<int, 0>{});
-    slab(p + 1, std::integral_constant<int, 1>{});
-  }
-  if (g == 0) boundary();                       // barrier counts match again
-  __syncthreads();                              // the epilogue stages through the (now idle) ring
-
-  if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 128 + i * 32 + r;
-      if (m >= a.M) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
-          if (n >= a.N) continue;
-          float* cp = (float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n;
-          *(f32x4*)cp = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        }
-    }
-  } else {
-    epilogue_bf16<FLAGS, 4>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 128, n0 + wn * 64);
-  }
-}
-
 // out[i] = sum_s slabs[s*stride + i]   (float4 lanes, deterministic order)
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                            int nsplit, int64_t n4, int64_t stride4) {
@@ -757,15 +587,6 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
     // 256x256 tiles (one 8-wave block per CU): main-loop-bound shapes only -- long K and whole residencies of 256 blocks
     const bool auto8 = g_opt_nt8 == 1 && a.k_per_split >= 4096 && (t8m * t8n * nsplit) % 256 == 0;
-    if ((auto8 && g_opt_nt9 == 1) || g_opt_nt9 == 2) {
-      static bool attr9 = false;
-      if (!attr9) { (void)hipFuncSetAttribute((const void*)gemm_nt9_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr9 = true; }
-      GemmArgs b = a;
-      b.tiles_m = t8m; b.tiles_n = t8n;
-      gemm_nt9_kernel<FLAGS><<<dim3(t8m * t8n, nsplit), dim3(512), 131072, st>>>(b);
-      DMI_CHECK_LAUNCH("gemm_nt9");
-      return DMI_OK;
-    }
     if (auto8 || g_opt_nt8 == 2) {
       static bool attr8 = false;
       if (!attr8) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8 = true; }

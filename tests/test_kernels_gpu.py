@@ -239,57 +239,6 @@ def test_gemm_nt8_tile_256x256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "256x256 and 128x128 tile kernels must be bit-identical"
 
 
-@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (2100, 520, 320, 5), (512, 512, 1024, 3),
-                                         (515, 136, 64, 8), (700, 264, 128, 32), (256, 256, 64, 16), (768, 512, 2112, 0)])
-def test_gemm_nt9_pingpong_tile_256x256(M, N, K, flags):
-    """the ping-pong form of the 256x256 tile (forced): 4-slab DMA ring with counted vmcnt, two staggered wave groups; K from
-    one 64-step (2 slabs: the whole ring protocol degenerates to its tail) to 66 slabs (NP % 4 == 2), M / N tails, every
-    epilogue: bit-identical to the 128x128x64 kernel (identical k order).  Run twice: a race in the ring would not repeat."""
-    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
-    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
-    hsrc = torch.relu(rnd(M, N, seed=5))
-    rs = torch.rand(M, generator=torch.Generator().manual_seed(6)) + 0.5
-    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None,
-              relu_src=hsrc.to(DEV) if flags & 8 else None, rowscale=rs.to(DEV) if flags & 32 else None)
-    outs = []
-    dh.set_option("nt4", 0)
-    try:
-        for nt9 in (2, 2, 0):
-            dh.set_option("nt9", nt9)
-            dh.set_option("nt8", 0)
-            C = torch.zeros(M, N, dtype=torch.float32 if flags & 16 else torch.bfloat16, device=DEV)
-            dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, flags, **kw)
-            outs.append(C.cpu())
-    finally:
-        dh.set_option("nt9", 0)
-        dh.set_option("nt8", 1)
-        dh.set_option("nt4", 1)
-    assert float(outs[2].float().abs().max()) > 0
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2]), "ping-pong 256x256 and 128x128 kernels must be bit-identical"
-
-
-def test_gemm_nt9_long_k_and_splitk():
-    """long K (the head input-gradient form): 6400-wide K unsplit and split in 4 with the row scale in the reduce"""
-    M, N, K = 1024, 512, 6400
-    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2)
-    rs = torch.rand(M, generator=torch.Generator().manual_seed(3)) + 0.5
-    outs = []
-    try:
-        for nt9 in (2, 0):
-            dh.set_option("nt9", nt9)
-            dh.set_option("nt8", 0)
-            C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-            dh.gemm_nt(A.to(DEV), K, Bt.to(DEV), K, C, N, M, N, K, dh.GEMM_ROWSCALE, rowscale=rs.to(DEV))
-            C2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-            dh.gemm_nt_splitk(A.to(DEV), K, Bt.to(DEV), K, C2, M, N, K, 4, ws(dh.gemm_nt_splitk_workspace_bytes(M, N, 4)), rowscale=rs.to(DEV))
-            outs.append((C.cpu(), C2.cpu()))
-    finally:
-        dh.set_option("nt9", 0)
-        dh.set_option("nt8", 1)
-    close(outs[0][0], _gemm_ref(A, Bt) * rs[:, None], 1.6e-2, 2e-2 * math.sqrt(K / 64) * 0.05, "nt9 long K")
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-
-
 def test_gemm_nt8_splitk_rowscale():
     """the head input-gradient form: long K split in 4, 256x256 tiles (auto: 4 x 64 tiles = 256 blocks), row scale in the reduce"""
     M, N, K = 2048, 2048, 4096 * 4

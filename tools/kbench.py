@@ -49,12 +49,10 @@ def bench_gemm_nt(M, N, K, flags=0, tag="", variants=(("auto", 1),)):
     for name, nt4 in variants:
         dh.set_option("nt4", nt4 if nt4 < 8 else 0)
         dh.set_option("nt8", 2 if nt4 == 8 else 0)
-        dh.set_option("nt9", 2 if nt4 == 9 else 0)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res, rowscale=rs))
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     dh.set_option("nt4", 1)
     dh.set_option("nt8", 1)
-    dh.set_option("nt9", 0)
 
 
 def bench_splitk(M, N, K, ns, nt8):
@@ -161,17 +159,6 @@ if __name__ == "__main__":
         bench_gemm_nt(M, 512, 50816, 32, " head-dgrad", (("nt2", 0), ("nt8", 8)))
         for ns, nt8 in ((2, 0), (4, 0), (4, 2), (8, 2)):
             bench_splitk(M, 512, 50816, ns, nt8)
-    if "pp" in what:     # ping-pong 256x256 (nt9) vs lock-step 256x256 (nt8) vs the 2-blocks-per-CU kernels
-        four = (("nt2", 0), ("nt4", 2), ("nt8", 8), ("nt9", 9), ("nt8", 8), ("nt9", 9))
-        bench_gemm_nt(M, 2048, 2048, 0, " big", four)
-        bench_gemm_nt(M, 4096, 4096, 0, " big", four)
-        bench_gemm_nt(M, 512, 50816, 32, " head-dgrad", four[2:])
-        bench_gemm_nt(M, 50816, 512, 1, " logits", four)
-        bench_gemm_nt(M, 2048, 512, 3, " ffn1", four)
-        bench_gemm_nt(M, 1536, 512, 0, " qkv", four)
-        bench_gemm_nt(M, 2048, 512, 8, " ffn2-dgrad", four)
-        bench_gemm_nt(M, 512, 2048, 5, " ffn2", four)
-        bench_gemm_nt(M, 512, 2048, 0, " ffn1-dgrad", four)
     if "tn" in what:
         for I, J in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d), (d, 50816)):
             bench_gemm_tn(M, I, J, weighted=(J == 50816))
