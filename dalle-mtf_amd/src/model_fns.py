@@ -31,6 +31,9 @@ def load_vae_model(params, mode_str):
     assert vae_params is not None, "vae model config must be supplied"
     if vae_checkpoint_path is None:
         vae_checkpoint_path = latest_checkpoint(vae_params["model_path"])
+    if vae_checkpoint_path is None and vae_params.get("model_path"):      # a run directory written by the reference's tf.train.Saver
+        from .data.tf_checkpoint import latest_tf_checkpoint
+        vae_checkpoint_path = latest_tf_checkpoint(vae_params["model_path"])
     if vae_checkpoint_path is None and not params.get("allow_random_vae"):
         raise AssertionError("pretrained vae needed for training")
     D = params["dataset"]["image_size"]
@@ -53,6 +56,13 @@ def initialize_vae_weights(vae, checkpoint_path):
     """reference model_fns.py:11-32: restore every variable under scope 'vae' by name."""
     if checkpoint_path is None:
         vae.init_params()
+        return
+    if os.path.exists(str(checkpoint_path) + ".index"):
+        # a TensorFlow checkpoint written by the reference itself (tf.train.Saver, variables under scope "vae/"): restore by
+        # name exactly as reference model_fns.py:11-32 does -- read without TensorFlow by src/data/tf_checkpoint.py
+        from .data.tf_checkpoint import load_model_variables
+        P = load_model_variables(str(checkpoint_path), scope="vae/") or load_model_variables(str(checkpoint_path))
+        vae.load_reference_params(P)
         return
     sd = torch.load(checkpoint_path, map_location="cpu")
     vae.load_reference_params({k: (v.numpy() if torch.is_tensor(v) else v) for k, v in sd["vae_variables"].items()})
@@ -108,6 +118,11 @@ def _build(params, mode_str):
     ck = latest_checkpoint(params["model_path"]) if params.get("model_path") else None
     if ck is not None:
         eng.load_state_dict(torch.load(ck, map_location="cpu")["dalle"])
+    elif params.get("tf_checkpoint"):
+        # warm start from a checkpoint of the reference (`<prefix>.index` + `.data-*`, variable names of SURVEY Appendix B)
+        from .data.tf_checkpoint import global_step_of, load_model_variables
+        eng.load_reference_params(load_model_variables(params["tf_checkpoint"]))
+        eng.global_step = global_step_of(params["tf_checkpoint"])
     else:
         eng.init_params(seed=params.get("seed") or 1234)
     if world > 1:

@@ -120,31 +120,67 @@ def scalar_summary(name, x):
 
 
 class SummaryWriter:
-    """Writes scalars as JSON lines under model_dir (TensorBoard event files need TensorFlow, absent here)."""
+    """tf2.summary.create_file_writer stand-in (reference src/utils/utils.py:103-161, src/model_fns_tf.py:68-96): scalars and
+    images go to a TensorBoard event file `events.out.tfevents.<time>.<host>` under model_dir -- TFRecord framing of
+    tensorflow.Event protos, written without TensorFlow (src/data/tfrecord.py supplies the framing, CRCs and the proto wire
+    helpers) -- and, for people without TensorBoard, to `summaries.jsonl` + `images/*.png`.
+    Event {1: wall_time (double), 2: step (int64), 3: file_version (string) | 5: Summary};
+    Summary {1: repeated Value {1: tag, 2: simple_value (float) | 4: Image {1: height, 2: width, 3: colorspace, 4: PNG bytes}}}."""
 
     def __init__(self, model_dir):
+        import socket
+        import time
         os.makedirs(model_dir, exist_ok=True)
         self.path = os.path.join(model_dir, "summaries.jsonl")
+        self.events_path = os.path.join(model_dir, f"events.out.tfevents.{int(time.time())}.{socket.gethostname()}")
+        self._write_event(0, file_version=b"brain.Event:2")
+
+    def _write_event(self, step, file_version=None, summary=None):
+        import struct
+        import time
+        from ..data.tfrecord import _ld, _varint, masked_crc32c
+        ev = bytes([(1 << 3) | 1]) + struct.pack("<d", time.time()) + bytes([(2 << 3) | 0]) + _varint(int(step))
+        if file_version is not None:
+            ev += _ld(3, file_version)
+        if summary is not None:
+            ev += _ld(5, summary)
+        hdr = struct.pack("<Q", len(ev))
+        with open(self.events_path, "ab") as f:
+            f.write(hdr + struct.pack("<I", masked_crc32c(hdr)) + ev + struct.pack("<I", masked_crc32c(ev)))
 
     def scalars(self, step, **kv):
+        import struct
+        from ..data.tfrecord import _ld
         rec = {"step": int(step)}
+        summary = b""
         for k, v in kv.items():
             rec[k] = float(v.item() if hasattr(v, "item") else v)
+            summary += _ld(1, _ld(1, k.encode()) + bytes([(2 << 3) | 5]) + struct.pack("<f", rec[k]))
         with open(self.path, "a") as f:
             f.write(json.dumps(rec) + "\n")
+        self._write_event(step, summary=summary)
 
     def images(self, step, name, x, max_images=3):
-        """tf2.summary.image stand-in (reference src/model_fns_tf.py:74-75,89-90; TF writes max_outputs = 3 images):
-        x NHWC in [0, 1] -> model_dir/images/<name>_<step>_<i>.png"""
+        """tf2.summary.image (reference src/model_fns_tf.py:74-75,89-90; TF writes max_outputs = 3 images):
+        x NHWC in [0, 1] -> event-file Image values tagged <name>/image/<i> and model_dir/images/<name>_<step>_<i>.png"""
+        import io
         import numpy as np
         from PIL import Image
+        from ..data.tfrecord import _ld, _varint
         d = os.path.join(os.path.dirname(self.path), "images")
         os.makedirs(d, exist_ok=True)
         a = x[:max_images].detach().float().cpu().numpy() if hasattr(x, "detach") else np.asarray(x[:max_images], np.float32)
         a = (np.clip(a, 0.0, 1.0) * 255.0 + 0.5).astype(np.uint8)
+        summary = b""
         for i, im in enumerate(a):
-            Image.fromarray(im[..., 0] if im.shape[-1] == 1 else im[..., :3]).save(
-                os.path.join(d, f"{name.replace('/', '_')}_{int(step)}_{i}.png"))
+            pil = Image.fromarray(im[..., 0] if im.shape[-1] == 1 else im[..., :3])
+            pil.save(os.path.join(d, f"{name.replace('/', '_')}_{int(step)}_{i}.png"))
+            buf = io.BytesIO()
+            pil.save(buf, format="PNG")
+            img = (bytes([(1 << 3) | 0]) + _varint(im.shape[0]) + bytes([(2 << 3) | 0]) + _varint(im.shape[1]) +
+                   bytes([(3 << 3) | 0]) + _varint(1 if im.shape[-1] == 1 else 3) + _ld(4, buf.getvalue()))
+            summary += _ld(1, _ld(1, f"{name}/image/{i}".encode()) + _ld(4, img))
+        self._write_event(step, summary=summary)
 
 
 def create_host_call(model_dir):

@@ -6,6 +6,7 @@ import json
 import os
 
 import pytest
+import numpy as np
 import torch
 
 from src import utils
@@ -157,3 +158,83 @@ def test_tokenizer_contract_offline():
     assert len(tok) == 50258 and tok.encode(tok.pad_token)[0] == 50257     # train_dalle.py:47-49 contract
     with pytest.raises(NotImplementedError):
         get_tokenizer("some_other_tokenizer")
+
+
+def test_summary_writer_emits_tensorboard_event_file(tmp_path):
+    """the event file is TFRecord-framed tensorflow.Event protos: version record first, then scalars (simple_value) and
+    PNG-encoded images -- read back here with the repo's own TFRecord reader (CRC-checked) and wire decoder"""
+    import glob
+    import io
+    import struct
+    from PIL import Image
+    from src.data import tfrecord as tfr
+    from src.utils.utils import SummaryWriter
+    w = SummaryWriter(str(tmp_path))
+    w.scalars(7, loss=1.5, lr=1e-3)
+    w.images(7, "input_image", np.random.default_rng(0).random((2, 8, 8, 3), dtype=np.float32))
+    (path,) = glob.glob(str(tmp_path / "events.out.tfevents.*"))
+    recs = list(tfr.read_records(path, verify_crc=True))
+    assert len(recs) == 3
+    ev0 = {f: v for f, _, v in tfr._fields(recs[0])}
+    assert ev0[3] == b"brain.Event:2"
+    ev1 = {f: v for f, _, v in tfr._fields(recs[1])}
+    assert ev1[2] == 7 and abs(struct.unpack("<d", ev1[1])[0] - __import__("time").time()) < 60
+    vals = {}
+    for f, _, value in tfr._fields(ev1[5]):
+        fields = {ff: vv for ff, _, vv in tfr._fields(value)}
+        vals[fields[1].decode()] = struct.unpack("<f", fields[2])[0]
+    assert vals == {"loss": 1.5, "lr": np.float32(1e-3)}
+    ev2 = {f: v for f, _, v in tfr._fields(recs[2])}
+    tags = []
+    for f, _, value in tfr._fields(ev2[5]):
+        fields = {ff: vv for ff, _, vv in tfr._fields(value)}
+        img = {ff: vv for ff, _, vv in tfr._fields(fields[4])}
+        assert (img[1], img[2], img[3]) == (8, 8, 3)
+        assert Image.open(io.BytesIO(img[4])).size == (8, 8)
+        tags.append(fields[1].decode())
+    assert tags == ["input_image/image/0", "input_image/image/1"]
+
+
+def test_tf_checkpoint_bundle_roundtrip_and_known_constants(tmp_path):
+    """TensorFlow V2 checkpoint reader / writer (src/data/tf_checkpoint.py): a multi-block index (many variables), every dtype,
+    scalars and empty shapes; CRC failures and a wrong magic are loud; variable selection by scope drops optimizer slots."""
+    import struct
+    from src.data import tf_checkpoint as tfc
+    rng = np.random.default_rng(0)
+    V = {f"layer_{i}/attn/q": rng.standard_normal((16, 8)).astype(np.float32) for i in range(120)}
+    V.update({"global_step": np.asarray(1234, np.int64), "vae/codebook/codebook": rng.standard_normal((4, 6)).astype(np.float32),
+              "vae/codebook/codebook/adam_m": np.zeros((4, 6), np.float32), "half": rng.standard_normal(5).astype(np.float16),
+              "ids": np.arange(7, dtype=np.int32), "wide": rng.standard_normal((3, 1, 2)).astype(np.float64)})
+    prefix = str(tmp_path / "model.ckpt-1234")
+    tfc.save_checkpoint(prefix, V)
+    raw = open(prefix + ".index", "rb").read()
+    assert struct.unpack("<Q", raw[-8:])[0] == 0xDB4775248B80FB57 and len(raw) > 4096      # more than one data block
+    got = tfc.load_checkpoint(prefix)
+    assert sorted(got) == sorted(V)
+    for k in V:
+        assert got[k].dtype == V[k].dtype and got[k].shape == V[k].shape and np.array_equal(got[k], V[k]), k
+    assert tfc.list_variables(prefix)["wide"] == ("float64", (3, 1, 2))
+    assert tfc.global_step_of(prefix) == 1234
+    assert list(tfc.load_model_variables(prefix, scope="vae/")) == ["codebook/codebook"]
+    assert "global_step" not in tfc.load_model_variables(prefix)
+    open(str(tmp_path / "checkpoint"), "w").write('model_checkpoint_path: "model.ckpt-1234"\n')
+    assert tfc.latest_tf_checkpoint(str(tmp_path)) == prefix
+    # bfloat16 tensors (the reference's master dtype under bf_16): dtype enum 14, high halves of float32
+    bf = (np.asarray([1.0, -2.5, 3.140625], np.float32).view(np.uint32) >> 16).astype("<u2")
+    tab = tfc.read_table(prefix + ".index")
+    tab[b"bf"] = (tfc._varint(8) + tfc._varint(14) + tfc._ld(2, tfc._shape_proto((3,))) + tfc._varint(32) + tfc._varint(0) +
+                  tfc._varint(40) + tfc._varint(6) + tfc._varint(53) + struct.pack("<I", tfc.masked_crc32c(bf.tobytes())))
+    open(str(tmp_path / "b.data-00000-of-00001"), "wb").write(bf.tobytes())
+    tfc.write_table(str(tmp_path / "b.index"), {b"": tab[b""], b"bf": tab[b"bf"]})
+    assert np.array_equal(tfc.load_checkpoint(str(tmp_path / "b"))["bf"], np.asarray([1.0, -2.5, 3.140625], np.float32))
+    # corruption is loud
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    data[10] ^= 1
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(IOError):
+        tfc.load_checkpoint(prefix)
+    bad = bytearray(raw)
+    bad[100] ^= 1
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(IOError):
+        tfc.read_table(prefix + ".index")

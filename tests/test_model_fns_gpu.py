@@ -297,3 +297,35 @@ def test_kv_cached_decode_equals_full_forward():
     c1 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
     c2 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
     assert torch.equal(c1, c2) and int(c1.max()) < iv and int(c1.min()) >= 0
+
+
+def test_reference_tf_checkpoints_load_by_variable_name(tmp_path):
+    """(f)2: a checkpoint in the reference's own format (tf.train.Saver bundle, variable names of SURVEY Appendix B, optimizer
+    slots and global_step alongside) warm-starts the DALL-E engine (`tf_checkpoint`) and restores the VAE's variables from scope
+    `vae/` exactly as reference src/model_fns.py:11-32 does -- read without TensorFlow."""
+    from oracle import dalle_oracle as do
+    from oracle import vae_oracle as vo
+    from src.data import tf_checkpoint as tfc
+    from src.dalle_mtf.engine import DalleEngine
+    from src.model_fns import initialize_vae_weights
+    from src.vae_tf import DiscreteVAE
+    cfg = do.DalleConfig(128, 60, 64, 8, 16, 2, 1)
+    P = do.init_params(cfg, seed=4, perturb=0.05)
+    bundle = {k: v for k, v in P.items()}
+    bundle.update({k + "/adam_m": np.zeros_like(v) for k, v in P.items()})
+    bundle["global_step"] = np.asarray(321, np.int64)
+    prefix = str(tmp_path / "model.ckpt-321")
+    tfc.save_checkpoint(prefix, bundle)
+    eng = DalleEngine(128, 2, 1, 60, 64, 8, 16, batch_size=2, hparams=dict(lr=1e-3, train_steps=10))
+    eng.load_reference_params(tfc.load_model_variables(prefix))
+    back = eng.export_reference()
+    assert sorted(back) == sorted(P) and all(np.array_equal(back[k], P[k]) for k in P)
+    assert tfc.global_step_of(prefix) == 321
+    vc = dict(num_tokens=64, dimensions=16, convblocks=[[2, 64], [2, 64]])
+    VP = vo.init_params(vo.VaeConfig(**vc), seed=5, bias_perturb=0.02)
+    vprefix = str(tmp_path / "vae" / "model.ckpt-9")
+    tfc.save_checkpoint(vprefix, {"vae/" + k: v for k, v in VP.items()})
+    vae = DiscreteVAE(batch_size=2, mode="eval", **vc)
+    initialize_vae_weights(vae, vprefix)
+    vb = vae.export_reference()
+    assert all(np.allclose(vb[k], VP[k]) for k in VP)
