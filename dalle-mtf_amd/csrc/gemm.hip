@@ -1643,8 +1643,9 @@ static int ilog2_exact(int v) {
 extern "C" int64_t dmi_conv_wgrad_tn_workspace_bytes(int M, int K, int N) { return dmi_gemm_tn_workspace_bytes(M, K, N); }
 extern "C" int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps,
                                  const int* dy, const int* dx, const uint16_t* dY, int ldy, int N, float* dW, float* dbias,
-                                 void* workspace, void* stream) {
+                                 void* workspace, dmi_reduce_item* deferred, int* n_deferred, void* stream) {
   DMI_REQUIRE(x && dY && dW && dy && dx && workspace, "conv_wgrad_tn: null pointer");
+  if (n_deferred) *n_deferred = 0;
   DMI_REQUIRE(C % 64 == 0 && ntaps >= 1 && ntaps <= CONV_MAX_TAPS && N % 8 == 0 && ldy % 8 == 0 && ldy >= N,
               "conv_wgrad_tn: need C%%64==0, 1..16 taps, N/ldy multiples of 8 (C=%d ntaps=%d N=%d)", C, ntaps, N);
   const int lw = ilog2_exact(Wo), lh = ilog2_exact(Ho);
@@ -1675,11 +1676,18 @@ extern "C" int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, 
   conv_wgrad_tn_kernel<<<dim3(a.tiles_i * a.tiles_j * nsplit), dim3(256), TN_LDS_BYTES, st>>>(a, g);
   DMI_CHECK_LAUNCH("conv_wgrad_tn");
   if (nsplit > 1) {
+    const int64_t n4 = (int64_t)I * J / 4;
+    if (deferred && n_deferred) {   // the caller reduces later (dmi_reduce_slabs_batch); the workspace must stay untouched until then
+      int k = 0;
+      if (dbias) { deferred[k].slabs = bpart; deferred[k].out = dbias; deferred[k].nsplit = nsplit; deferred[k].n4 = J / 4; ++k; }
+      deferred[k].slabs = slabs; deferred[k].out = dW; deferred[k].nsplit = nsplit; deferred[k].n4 = n4; ++k;
+      *n_deferred = k;
+      return DMI_OK;
+    }
     if (dbias) {
       reduce_slabs_kernel<<<dim3((unsigned)cdiv64(J / 4, 256)), dim3(256), 0, st>>>(bpart, dbias, nsplit, J / 4, J / 4);
       DMI_CHECK_LAUNCH("conv_wgrad_tn_bias_reduce");
     }
-    const int64_t n4 = (int64_t)I * J / 4;
     int64_t blocks = cdiv64(n4, 256);
     if (blocks > 2048) blocks = 2048;
     reduce_slabs_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(slabs, dW, nsplit, n4, n4);

@@ -84,6 +84,39 @@ extern "C" int dmi_weight_gather(const uint16_t* in, uint16_t* out, int A, int B
   return DMI_OK;
 }
 
+// Every per-step weight re-layout of a model in ONE launch (the small VAE configurations spent 50 launches of ~3 us on them):
+// table[i] = {in_off, out_off, A, Bn, nsel, ldo, first_block, idx[16]} (int64; offsets in elements of in_base / out_base,
+// first_block ascending); a block covers 2048 consecutive output elements of its item.
+#define WG_ROW 23
+__global__ __launch_bounds__(256) void weight_gather_batch_kernel(const bf16_t* __restrict__ in_base, bf16_t* __restrict__ out_base,
+                                                                  const int64_t* __restrict__ table, int n) {
+  const int64_t blk = blockIdx.x;
+  int i = 0;
+  while (i + 1 < n && table[(i + 1) * WG_ROW + 6] <= blk) ++i;
+  const int64_t* row = table + (int64_t)i * WG_ROW;
+  const bf16_t* in = in_base + row[0];
+  bf16_t* out = out_base + row[1];
+  const int A = (int)row[2], Bn = (int)row[3], nsel = (int)row[4], ldo = (int)row[5];
+  const int64_t total = (int64_t)A * ldo;
+  const int64_t base = (blk - row[6]) * 2048;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int64_t e = base + k * 256 + threadIdx.x;
+    if (e >= total) break;
+    const int j = (int)(e % ldo);
+    const int a = (int)(e / ldo);
+    const int t = j / Bn, b = j % Bn;
+    out[e] = (t < nsel) ? in[((int64_t)row[7 + t] * A + a) * Bn + b] : (bf16_t)0;
+  }
+}
+extern "C" int dmi_weight_gather_batch(const uint16_t* in_base, uint16_t* out_base, const int64_t* table, int n, int64_t total_blocks,
+                                       void* stream) {
+  DMI_REQUIRE(in_base && out_base && table && n > 0 && total_blocks > 0, "weight_gather_batch: bad args");
+  weight_gather_batch_kernel<<<dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream>>>(in_base, out_base, table, n);
+  DMI_CHECK_LAUNCH("weight_gather_batch");
+  return DMI_OK;
+}
+
 // out[b, 2t+py, 2u+px, :] = in[p = py*2+px][b, t, u, :]
 __global__ __launch_bounds__(256) void pixel_interleave_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B,
                                                                int Ht, int Wt, int C) {

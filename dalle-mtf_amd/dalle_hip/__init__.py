@@ -93,8 +93,9 @@ def _declare(L):
         "dmi_im2col": (I, [P, P, I, I, I, I, I, I, I, I, P, P, I, P]),
         "dmi_conv_gemm_nt": (I, [P, I, I, I, I, I, I, I, I, P, P, P, I, P, I, I, I, P, P, P, P]),
         "dmi_conv_wgrad_tn_workspace_bytes": (L64, [I, I, I]),
-        "dmi_conv_wgrad_tn": (I, [P, I, I, I, I, I, I, I, I, P, P, P, I, I, P, P, P, P]),
+        "dmi_conv_wgrad_tn": (I, [P, I, I, I, I, I, I, I, I, P, P, P, I, I, P, P, P, P, P, P]),
         "dmi_weight_gather": (I, [P, P, I, I, I, P, I, P]),
+        "dmi_weight_gather_batch": (I, [P, P, P, I, L64, P]),
         "dmi_pixel_interleave": (I, [P, P, I, I, I, I, P]),
         "dmi_pad_channels": (I, [P, P, L64, I, I, P]),
         "dmi_unpad_channels": (I, [P, P, L64, I, I, P]),
@@ -380,12 +381,23 @@ def conv_wgrad_tn_workspace_bytes(M, K, N):
     return int(lib().dmi_conv_wgrad_tn_workspace_bytes(M, K, N))
 
 
-def conv_wgrad_tn(x, B, H, W, C, Ho, Wo, stride, taps, dY, ldy, N, dW, ws, dbias=None):
-    """implicit-im2col weight gradient (include/dalle_hip.h: dmi_conv_wgrad_tn); Ho, Wo powers of two, C % 64 == 0."""
+def conv_wgrad_tn(x, B, H, W, C, Ho, Wo, stride, taps, dY, ldy, N, dW, ws, dbias=None, deferred: "DeferredReduces" = None):
+    """implicit-im2col weight gradient (include/dalle_hip.h: dmi_conv_wgrad_tn); Ho, Wo powers of two, C % 64 == 0.
+    deferred: as gemm_tn (ws must then be exclusive to this call until deferred.run())."""
     _dev(x, dY, dW, ws)
     dy, dx = _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps])
+    if deferred is None:
+        _check(lib().dmi_conv_wgrad_tn(_p(x), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p),
+                                       ctypes.cast(dx, c_void_p), _p(dY), ldy, N, _p(dW), _p(dbias), _p(ws), None, None, _stream()),
+               "conv_wgrad_tn")
+        return
+    assert deferred.n + 2 <= deferred.capacity
+    cnt = c_int(0)
+    slot = ctypes.byref(deferred.items, deferred.n * ctypes.sizeof(ReduceItem))
     _check(lib().dmi_conv_wgrad_tn(_p(x), B, H, W, C, Ho, Wo, stride, len(taps), ctypes.cast(dy, c_void_p),
-                                   ctypes.cast(dx, c_void_p), _p(dY), ldy, N, _p(dW), _p(dbias), _p(ws), _stream()), "conv_wgrad_tn")
+                                   ctypes.cast(dx, c_void_p), _p(dY), ldy, N, _p(dW), _p(dbias), _p(ws), slot, ctypes.byref(cnt),
+                                   _stream()), "conv_wgrad_tn")
+    deferred.n += cnt.value
 
 
 def im2col(x, out, B, H, W, C, Ho, Wo, stride, taps, ldo):
@@ -415,6 +427,11 @@ def pad_channels(inp, out, N, Cin, Cp):
 def unpad_channels(inp, out, N, Cin, Cp):
     _dev(inp, out)
     _check(lib().dmi_unpad_channels(_p(inp), _p(out), N, Cin, Cp, _stream()), "unpad_channels")
+
+
+def weight_gather_batch(in_base, out_base, table, n, total_blocks):
+    _dev(in_base, out_base, table)
+    _check(lib().dmi_weight_gather_batch(_p(in_base), _p(out_base), _p(table), n, total_blocks, _stream()), "weight_gather_batch")
 
 
 def gumbel_softmax_fwd(logits, u, y, y_soft, index, M, T, temperature, hard, temperature_dev=None):

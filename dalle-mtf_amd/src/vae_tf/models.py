@@ -29,6 +29,7 @@ from ..dp import GradReducer
 IMG_CP = 8     # padded image channels
 OUT_CP = 64    # padded reconstruction channels
 ALIGN = 128
+WS_POOL = 7    # weight gradients in flight before their slab reduces are flushed (2 reduce items each, 16 per batched launch)
 
 
 def _ru(x, m):
@@ -159,27 +160,47 @@ class DiscreteVAE:
         self.m, self.v = torch.zeros(n, **f32), torch.zeros(n, **f32)
         self.pb = torch.zeros(n, **b16)
         self.gc2 = torch.zeros(self.n_hid * self.num_tokens, **f32)  # second contribution to the tied codebook gradient
-        # derived weight copies
+        # derived weight copies: views of ONE flat buffer, so that the per-step refresh is two batched launches
+        # (dmi_transpose_bf16_batch + dmi_weight_gather_batch) instead of one launch per copy
         self.wf, self.wd, self.wp = {}, {}, {}
+        plan = []                                   # (dict, key, index or None, rows, cols)
         max_col = 0
         for c in self.convs:
             K = c.kk * c.cin
             Kp = _ru(K, 64)
             M_out = B * c.Ho * c.Wo
             if c.kind in ("down", "res", "final"):
-                self.wf[c.name] = torch.zeros(c.cout, Kp, **b16)                         # [co][(k,ci)] fwd
+                plan.append(("wf", c.name, None, c.cout, Kp))                             # [co][(k,ci)] fwd
                 max_col = max(max_col, M_out * Kp)
             if c.kind == "res":
-                self.wd[c.name] = torch.zeros(c.cin, _ru(9 * c.cout, 64), **b16)         # [ci][(k,co)] dgrad
+                plan.append(("wd", c.name, None, c.cin, _ru(9 * c.cout, 64)))             # [ci][(k,co)] dgrad
                 max_col = max(max_col, M_out * _ru(9 * c.cout, 64))
             if c.kind == "down":
-                self.wp[c.name] = [torch.zeros(c.cin, _ru(4 * c.cout, 64), **b16) for _ in range(4)]  # dgrad parity
+                for q in range(4):
+                    plan.append(("wp", c.name, q, c.cin, _ru(4 * c.cout, 64)))            # dgrad parity
                 max_col = max(max_col, M_out * _ru(4 * c.cout, 64))
             if c.kind == "up":
-                self.wp[c.name] = [torch.zeros(c.cout, _ru(4 * c.cin, 64), **b16) for _ in range(4)]  # fwd parity [cz][(a,b,cy)]
-                self.wd[c.name] = torch.zeros(c.cin, _ru(16 * c.cout, 64), **b16)        # [cy][(k,cz)] for dy
+                for q in range(4):
+                    plan.append(("wp", c.name, q, c.cout, _ru(4 * c.cin, 64)))            # fwd parity [cz][(a,b,cy)]
+                plan.append(("wd", c.name, None, c.cin, _ru(16 * c.cout, 64)))            # [cy][(k,cz)] for dy
                 max_col = max(max_col, B * c.H * c.W * _ru(4 * c.cin, 64), B * c.H * c.W * _ru(16 * c.cout, 64))
-        self.codebook_t = torch.zeros(self.num_tokens, self.n_hid, **b16)
+        plan.append(("cb", "codebook_t", None, self.num_tokens, self.n_hid))
+        off = 0
+        self._wc_off = {}
+        for kind, name, q, rows, cols in plan:
+            self._wc_off[(kind, name, q)] = off
+            off += _ru(rows * cols, ALIGN)
+        self.wcopies = torch.zeros(off, **b16)
+        for kind, name, q, rows, cols in plan:
+            o = self._wc_off[(kind, name, q)]
+            v = self.wcopies[o:o + rows * cols].view(rows, cols)
+            if kind == "wp":
+                self.wp.setdefault(name, [None] * 4)[q] = v
+            elif kind == "cb":
+                self.codebook_t = v
+            else:
+                getattr(self, kind)[name] = v
+        self._refresh_tables = None
         self.col = torch.empty(max_col, **b16)
         # im2col matrices of the forward convolutions kept for their weight gradients (288 GB HBM: ~8 GB for vae_coco at 16
         # images) -- the backward pass then gathers only dy; allocated on first use in train mode
@@ -226,6 +247,14 @@ class DiscreteVAE:
                       dh.colsum_workspace_bytes(max(M_out, M_in), max(c.cout, c.cin)))
         wsz = max(wsz, dh.gemm_tn_workspace_bytes(Mg, self.n_hid, self.num_tokens), dh.mse_workspace_bytes())
         self.ws = torch.empty(int(wsz) + 1024, dtype=torch.uint8, device=dev)
+        # backward(): the split-m slab reduces of the weight gradients are DEFERRED and run a few layers at a time in one launch
+        # (the small configurations spent a fifth of their step in ~60 reduce launches of a few microseconds); every pending
+        # weight gradient owns one workspace of this pool until the flush
+        self.ws_cs = torch.empty(int(max(dh.colsum_workspace_bytes(max(B * c.Ho * c.Wo, B * c.H * c.W), max(c.cout, c.cin))
+                                         for c in self.convs)) + 1024, dtype=torch.uint8, device=dev)   # column sums reduce at once
+        self.ws_pool = [torch.empty_like(self.ws) for _ in range(WS_POOL)]     # (self.ws stays free for the immediate calls)
+        self._ws_next = 0
+        self.deferred = dh.DeferredReduces()
 
     # ------------------------------------------------------------------ parameters
     def view(self, buf, name):
@@ -290,25 +319,52 @@ class DiscreteVAE:
         return out
 
     def refresh_compute_copies(self, cast=False):
+        """bf16 master copy (cast) + every derived weight layout of the step, in two batched launches: the [in,out] -> [out,in]
+        transposes (forward kernels, transposed-conv dy kernels, codebook) and the tap gathers (dgrad / output-parity kernels).
+        A transpose whose row count needs zero padding to the 64-multiple K pitch (none in the shipped configurations) keeps its
+        own launch."""
         if cast:
             dh.cast_f32_bf16(self.p, self.pb, self.total)
-        for c in self.convs:
-            wn = self.view(self.pb, c.name + "/kernel")            # [kk][A][Bn] bf16
-            K = c.kk * c.cin
-            if c.kind in ("down", "res", "final"):
-                dh.transpose_padded(wn, self.wf[c.name], K, _ru(K, 64), c.cout)          # [(k,ci)][co] -> [co][(k,ci)]
-            if c.kind == "res":
-                dh.weight_gather(wn, self.wd[c.name], c.cin, c.cout, list(range(9)), _ru(9 * c.cout, 64))
-            if c.kind == "down":
-                for p in range(4):
-                    dh.weight_gather(wn, self.wp[c.name][p], c.cin, c.cout, [t[0] for t in _parity(p)], _ru(4 * c.cout, 64))
-            if c.kind == "up":
-                for p in range(4):
-                    dh.weight_gather(wn, self.wp[c.name][p], c.cout, c.cin, [t[0] for t in _parity(p)], _ru(4 * c.cin, 64))
-                Kz = 16 * c.cout
-                dh.transpose_padded(wn, self.wd[c.name], Kz, _ru(Kz, 64), c.cin)         # [(k,cz)][cy] -> [cy][(k,cz)]
-        cb = self.view(self.pb, "codebook/codebook")
-        dh.transpose(cb, self.codebook_t, 1, self.n_hid, self.num_tokens)
+        if self._refresh_tables is None:
+            tr, tile, ga, blk, padded = [], 0, [], 0, []
+            for c in self.convs:
+                src = self.offset[c.name + "/kernel"]
+                K = c.kk * c.cin
+                if c.kind in ("down", "res", "final"):
+                    if _ru(K, 64) == K:
+                        tr.append([src, self._wc_off[("wf", c.name, None)], K, c.cout, tile])
+                        tile += ((K + 63) // 64) * ((c.cout + 63) // 64)
+                    else:
+                        padded.append((c.name, "wf", K, _ru(K, 64), c.cout))
+                if c.kind == "res":
+                    ga.append((src, self._wc_off[("wd", c.name, None)], c.cin, c.cout, list(range(9)), _ru(9 * c.cout, 64)))
+                if c.kind == "down":
+                    for q in range(4):
+                        ga.append((src, self._wc_off[("wp", c.name, q)], c.cin, c.cout, [t[0] for t in _parity(q)], _ru(4 * c.cout, 64)))
+                if c.kind == "up":
+                    for q in range(4):
+                        ga.append((src, self._wc_off[("wp", c.name, q)], c.cout, c.cin, [t[0] for t in _parity(q)], _ru(4 * c.cin, 64)))
+                    Kz = 16 * c.cout
+                    if _ru(Kz, 64) == Kz:
+                        tr.append([src, self._wc_off[("wd", c.name, None)], Kz, c.cin, tile])
+                        tile += ((Kz + 63) // 64) * ((c.cin + 63) // 64)
+                    else:
+                        padded.append((c.name, "wd", Kz, _ru(Kz, 64), c.cin))
+            tr.append([self.offset["codebook/codebook"], self._wc_off[("cb", "codebook_t", None)], self.n_hid, self.num_tokens, tile])
+            tile += ((self.n_hid + 63) // 64) * ((self.num_tokens + 63) // 64)
+            rows = []
+            for src, dst, A, Bn, idx, ldo in ga:
+                rows.append([src, dst, A, Bn, len(idx), ldo, blk] + idx + [0] * (16 - len(idx)))
+                blk += (A * ldo + 2047) // 2048
+            self._refresh_tables = dict(tr=torch.tensor(tr, dtype=torch.int64, device=self.dev), tiles=tile,
+                                        ga=torch.tensor(rows, dtype=torch.int64, device=self.dev) if rows else None, blocks=blk,
+                                        padded=padded)
+        T = self._refresh_tables
+        dh.transpose_batch(self.pb, self.wcopies, T["tr"], T["tr"].shape[0], T["tiles"])
+        if T["ga"] is not None:
+            dh.weight_gather_batch(self.pb, self.wcopies, T["ga"], T["ga"].shape[0], T["blocks"])
+        for name, kind, R, Rp, C in T["padded"]:
+            dh.transpose_padded(self.view(self.pb, name + "/kernel"), getattr(self, kind)[name], R, Rp, C)
 
     # ------------------------------------------------------------------ conv building blocks
     def _w(self, name):
@@ -507,27 +563,43 @@ class DiscreteVAE:
     def _gv(self, name):
         return self.view(self.g, name)
 
-    def _wgrad(self, c: _Conv, x_in, dy):
+    def _defer_ws(self, defer):
+        """(workspace, deferred list or None) of the next weight gradient: immediate reduce on the shared workspace, or a pool
+        slot whose reduces run at the next _flush_reduces()"""
+        if not defer:
+            return self.ws, None
+        if self._ws_next >= WS_POOL:
+            self._flush_reduces()
+        w = self.ws_pool[self._ws_next]
+        self._ws_next += 1
+        return w, self.deferred
+
+    def _flush_reduces(self):
+        self.deferred.run()
+        self._ws_next = 0
+
+    def _wgrad(self, c: _Conv, x_in, dy, defer=False):
         """dW[(k,ci)][co] = col(x)^T . dy (+ bias gradient fused) -- lands directly in the TF kernel layout."""
         B = self.B
+        ws, dfr = self._defer_ws(defer)
         if c.kind == "final":
-            dh.gemm_tn(x_in, c.cin, dy, c.cout, self._gv(c.name + "/kernel"), B * c.H * c.W, c.cin, c.cout, self.ws,
-                       dbias=self._gv(c.name + "/bias"))
+            dh.gemm_tn(x_in, c.cin, dy, c.cout, self._gv(c.name + "/kernel"), B * c.H * c.W, c.cin, c.cout, ws,
+                       dbias=self._gv(c.name + "/bias"), deferred=dfr)
             return
         K = c.kk * c.cin
         Kp = _ru(K, 64)
         taps, s = (TAPS4, 2) if c.kind == "down" else (TAPS3, 1)
         if self._implicit_ok(c):
             dh.conv_wgrad_tn(x_in, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, dy, c.cout, c.cout, self._gv(c.name + "/kernel"),
-                             self.ws, dbias=self._gv(c.name + "/bias"))
+                             ws, dbias=self._gv(c.name + "/bias"), deferred=dfr)
             return
         col = self.col
         if c.name in self._col_valid:        # the forward pass of this step left col(x_in) in its kept buffer
             col = self.col_keep[c.name]
         else:
             dh.im2col(x_in, col, B, c.H, c.W, c.cin, c.Ho, c.Wo, s, taps, Kp)
-        dh.gemm_tn(col, Kp, dy, c.cout, self._gv(c.name + "/kernel"), B * c.Ho * c.Wo, K, c.cout, self.ws,
-                   dbias=self._gv(c.name + "/bias"))
+        dh.gemm_tn(col, Kp, dy, c.cout, self._gv(c.name + "/kernel"), B * c.Ho * c.Wo, K, c.cout, ws,
+                   dbias=self._gv(c.name + "/bias"), deferred=dfr)
 
     def _dgrad3(self, c: _Conv, dy, out, flags=0, residual=None, relu_src=None):
         Kp = _ru(9 * c.cout, 64)
@@ -538,7 +610,7 @@ class DiscreteVAE:
         dh.im2col(dy, self.col, self.B, c.H, c.W, c.cout, c.H, c.W, 1, TAPS3_REV, Kp)
         dh.gemm_nt(self.col, Kp, self.wd[c.name], Kp, out, c.cin, self.B * c.H * c.W, c.cin, Kp, flags, residual=residual, relu_src=relu_src)
 
-    def _up_backward(self, c: _Conv, x_in, dz, out):
+    def _up_backward(self, c: _Conv, x_in, dz, out, defer=False):
         """backward of the transposed conv z = conv2d_transpose(y) (vae_tf/models.py:133-137): a stride-2 4x4 SAME conv of dz.
         dW[kh,kw,Cout,Cin] and dbias into g, dy [B*H*W, cin] into `out`."""
         B = self.B
@@ -546,16 +618,17 @@ class DiscreteVAE:
         Kz = 16 * c.cout
         Kzp = _ru(Kz, 64)
         p2 = lambda v: v > 0 and (v & (v - 1)) == 0
+        ws, dfr = self._defer_ws(defer)
         if c.cout % 64 == 0 and p2(c.H) and p2(c.W):
             # both GEMMs gather dz implicitly
+            dh.colsum(dz, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws_cs)
             dh.conv_wgrad_tn(dz, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, x_in, c.cin, c.cin,
-                             self._gv(c.name + "/kernel"), self.ws)
-            dh.colsum(dz, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+                             self._gv(c.name + "/kernel"), ws, deferred=dfr)
             dh.conv_gemm_nt(dz, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, self.wd[c.name], Kzp, out, c.cin, c.cin)
         else:
             dh.im2col(dz, self.col, B, c.Ho, c.Wo, c.cout, c.H, c.W, 2, TAPS4, Kzp)     # stride-2 conv view of dz
-            dh.gemm_tn(self.col, Kzp, x_in, c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, self.ws)
-            dh.colsum(dz, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws)
+            dh.colsum(dz, c.cout, self._gv(c.name + "/bias"), B * c.Ho * c.Wo, c.cout, self.ws_cs)
+            dh.gemm_tn(self.col, Kzp, x_in, c.cin, self._gv(c.name + "/kernel"), Mi, Kz, c.cin, ws, deferred=dfr)
             dh.gemm_nt(self.col, Kzp, self.wd[c.name], Kzp, out, c.cin, Mi, c.cin, Kzp)
 
     def _dgrad_down(self, c: _Conv, dy, out):
@@ -584,6 +657,8 @@ class DiscreteVAE:
 
         def ready_down_to(off):           # the layout follows the forward order, backward finishes it from the end
             if off < mark[0]:
+                if self.world > 1:
+                    self._flush_reduces()  # the exchange takes g[off, mark): its pending slab reduces must have landed
                 self.reducer.ready(off, mark[0])
                 mark[0] = off
         while i >= 0:
@@ -591,7 +666,7 @@ class DiscreteVAE:
             lowest = convs[i - 1] if c.kind == "res" else c     # a residual pair is processed as one unit
             if c.kind == "final":
                 M = B * c.H * c.W
-                self._wgrad(c, self.act_in[i], d)
+                self._wgrad(c, self.act_in[i], d, defer=True)
                 nd = spare[0]
                 dh.gemm_nt(d, c.cout, self._w(c.name + "/kernel"), c.cout, nd, c.cin, M, c.cin, c.cout)   # K = 64 padded channels
                 spare[0], d = d, nd
@@ -601,21 +676,21 @@ class DiscreteVAE:
                 x_in, r = self.act_in[i - 1], self.act_in[i]
                 if self.recompute_grad:      # re-run the branch's first conv into the shared buffer (bit-identical to the forward)
                     self._conv_fwd(cin_conv, x_in, r, flags=dh.GEMM_RELU)
-                self._wgrad(c, r, d)
+                self._wgrad(c, r, d, defer=True)
                 da = spare[0]
                 self._dgrad3(c, d, da, flags=dh.GEMM_RELU_MASK, relu_src=r)
-                self._wgrad(cin_conv, x_in, da)
+                self._wgrad(cin_conv, x_in, da, defer=True)
                 nd = spare[1]
                 self._dgrad3(cin_conv, da, nd, flags=dh.GEMM_RESIDUAL, residual=d)
                 spare[1], d = d, nd
                 i -= 2
             elif c.kind == "up":
                 nd = spare[0]
-                self._up_backward(c, self.act_in[i], d, nd)
+                self._up_backward(c, self.act_in[i], d, nd, defer=True)
                 spare[0], d = d, nd
                 i -= 1
             else:  # down
-                self._wgrad(c, self.act_in[i], d)
+                self._wgrad(c, self.act_in[i], d, defer=True)
                 if i > 0:
                     nd = spare[0]
                     self._dgrad_down(c, d, nd)
@@ -635,6 +710,7 @@ class DiscreteVAE:
                 spare[0], d = d, nd
                 ready_down_to(self.offset["codebook/codebook"])
         ready_down_to(0)
+        self._flush_reduces()
 
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr, beta1=0.9, beta2=0.999, eps=1e-8):

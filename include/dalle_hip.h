@@ -218,11 +218,12 @@ int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, int Ho, int 
 /* Implicit-im2col weight gradient: dW[(t*C + c)][n] = sum_{b,oy,ox} x[b, oy*stride+dy[t], ox*stride+dx[t], c] * dY[(b,oy,ox)][n]
  * (+ dbias[n] = column sums of dY, nullable) = dmi_im2col + dmi_gemm_tn without the column matrix; lands in the TF kernel
  * layout [kh*kw*Cin, Cout] of tf.layers.conv2d (src/vae_tf/models.py:67).  C % 64 == 0, Ho and Wo powers of two.
- * workspace >= dmi_conv_wgrad_tn_workspace_bytes(B*Ho*Wo, ntaps*C, N). */
+ * workspace >= dmi_conv_wgrad_tn_workspace_bytes(B*Ho*Wo, ntaps*C, N).  deferred / n_deferred as dmi_gemm_tn: the final slab
+ * reduces are handed back for one dmi_reduce_slabs_batch launch (the workspace then belongs to this call until that launch). */
 int64_t dmi_conv_wgrad_tn_workspace_bytes(int M, int K, int N);
 int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, int Ho, int Wo, int stride, int ntaps,
                       const int* dy, const int* dx, const uint16_t* dY, int ldy, int N, float* dW, float* dbias,
-                      void* workspace, void* stream);
+                      void* workspace, dmi_reduce_item* deferred, int* n_deferred, void* stream);
 
 /* out[(b,oy,ox)][t*C + c] = x[b, oy*stride + dy[t], ox*stride + dx[t], c] (0 outside); row pitch ldo, tail zero-filled.
  * dy/dx are HOST arrays (ntaps <= 16). */
@@ -231,6 +232,11 @@ int dmi_im2col(const uint16_t* x, uint16_t* out, int B, int H, int W, int C, int
 /* out[a][t*Bn + b] = in[idx[t]][a][b], row pitch ldo (tail zero)  (conv kernel [k][ci][co] -> [ci][(k',co)] for the
  * dgrad / output-parity GEMMs); idx on HOST */
 int dmi_weight_gather(const uint16_t* in, uint16_t* out, int A, int Bn, int nsel, const int* idx, int ldo, void* stream);
+/* n independent weight gathers between two buffers in ONE launch (the per-step refresh of every dgrad / output-parity weight
+ * copy of a model): table[i] = {in_off, out_off, A, Bn, nsel, ldo, first_block, idx[16]} (23 int64 per row, DEVICE memory;
+ * offsets in elements, first_block ascending, an item spans ceil(A*ldo / 2048) blocks); total_blocks = their sum. */
+int dmi_weight_gather_batch(const uint16_t* in_base, uint16_t* out_base, const int64_t* table, int n, int64_t total_blocks,
+                            void* stream);
 /* out[b, 2t+py, 2u+px, :] = in4[py*2+px][b, t, u, :]  (assembles a stride-2 transposed convolution) */
 int dmi_pixel_interleave(const uint16_t* in4, uint16_t* out, int B, int Ht, int Wt, int C, void* stream);
 /* fp32 [N, Cin] <-> bf16 [N, Cp] (zero-padded channels): image in, reconstruction out */
