@@ -383,7 +383,7 @@ class DalleEngine:
         toks[:, :T] = text.to(device=self.dev, dtype=torch.int32)
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         if kv_cache and self.recompute:
-            raise dh.DalleHipError("kv_cache sampling needs the per-layer projection buffers (recompute_grad shares one set)")
+            kv_cache = False     # recompute_grad keeps ONE shared set of projection buffers: there is no per-layer cache to decode from
 
         def pick(z):
             if temperature <= 0:
