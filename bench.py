@@ -221,8 +221,11 @@ def bench_vae(args, world, rank, pg, comm):
     dt = time.perf_counter() - t0
     if graphed and heavy is not None:
         vae.event_hook = (heavy.name, evs)
-        for i in range(20):
+        for i in range(22):
             step(i)
+            if i == 1:
+                sync()
+                evs.clear()      # the first eager steps after the replays pay one-time costs (a 15 ms outlier was measured)
         sync()
         vae.event_hook = None
     loss = float(vae.loss.item())
@@ -241,6 +244,8 @@ def bench_vae(args, world, rank, pg, comm):
     fl_img += 2 * 2 * g2 * vae.n_hid * vae.num_tokens
     train_fl = 3 * fl_img * B
     k_ms = [a.elapsed_time(b) for a, b in evs]
+    if os.environ.get("BENCH_DEBUG_EVENTS"):
+        print("event ms:", [round(x, 3) for x in k_ms], file=sys.stderr)
     k_avg = sum(k_ms) / max(len(k_ms), 1) if k_ms else float("nan")
     roof = None
     if heavy is not None and k_ms:
