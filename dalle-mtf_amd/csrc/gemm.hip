@@ -110,9 +110,30 @@ __device__ __forceinline__ int lds_chunk_off(int row, int ch) { return (row * 8 
 // (Measured and dropped: replacing the bf16 relu_src read of the FFN-2 input gradient by 1 sign bit per element -- 8 ballots in
 // the FFN-1 epilogue, 8 broadcast 64-bit loads + shifts in the mask epilogue -- saves 158 MB of reads per layer but ran the two
 // kernels 125 / 149 us instead of 110 / 134 us: the epilogue is issue-bound, not bandwidth-bound.)
-template <int FLAGS, int MI>
-__device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[MI][2], float* stg, int lane, int mrow0, int ncol0) {
+// accumulators -> wave-private fp32 staging block of 32 rows x 64 columns (pitch 68 floats), for the two MFMA shapes:
+//   32x32x16: acc[MI][2] (f32x16): lane (r = lane & 31, h = lane >> 5) holds row r, columns j*32 + 8q + 4h + {0..3}
+//   16x16x32: acc[2 MI][4] (f32x4): lane (c = lane & 15, g = lane >> 4) holds row ii*16 + c, columns j*16 + 4g + {0..3}
+template <int MI>
+__device__ __forceinline__ void stage_rows32(const f32x16 (&acc)[MI][2], int i, float* stg, int lane) {
   const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
+          f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+}
+template <int MI>
+__device__ __forceinline__ void stage_rows32(const f32x4 (&acc)[2 * MI][4], int i, float* stg, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(f32x4*)(stg + (ii * 16 + c) * 68 + j * 16 + 4 * g) = acc[2 * i + ii][j];
+}
+
+template <int FLAGS, int MI, class ACC>
+__device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, ACC& acc, float* stg, int lane, int mrow0, int ncol0) {
   const int orow = lane >> 3, ocol = (lane & 7) * 8;
   const int n = ncol0 + ocol;
   const bool nok = n < a.N;
@@ -143,12 +164,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, f32x16 (&acc)[M
       if constexpr (FLAGS & DMI_GEMM_ROWSCALE) rsc[it] = (m < a.M) ? a.rowscale[m] : 0.f;
       if constexpr (FLAGS & GEMM_SOFTMAX) rsc[it] = (shifted && m < a.M) ? a.rowshift[m] * LOG2E : 0.f;
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *(f32x4*)(stg + r * 68 + j * 32 + 8 * q + 4 * h) =
-            f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+    stage_rows32<MI>(acc, i, stg, lane);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private region: in-order LDS, no barrier needed
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -255,20 +271,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
     }
   }
   // hoisted fragment byte offsets: chunk (2kk+h) ^ ((row>>1)&7); (row>>1)&7 == (r>>1)&7 for every tile row used
-  int offa[4], offb[4];
+  const int c16 = lane & 15, g16 = lane >> 4;
+  int offa[2], offb[2];    // per 32-wide k-substep: chunk 4 ks + g of row (tile base + c); 16-row tiles are 2048 B apart
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    offa[kk] = lds_chunk_off(wm * 64 + r, kk * 2 + h);
-    offb[kk] = 16384 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
+  for (int ks = 0; ks < 2; ++ks) {
+    offa[ks] = lds_chunk_off(wm * 64 + c16, ks * 4 + g16);
+    offb[ks] = 16384 + lds_chunk_off(wn * 64 + c16, ks * 4 + g16);
   }
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int st, int soff) {
     char* base = smem + st * 32768 + wid * 1024;
@@ -282,18 +297,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
     const char* cur = smem + st * 32768;
     MFMA_PRIO(1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
-        fb[i] = *(const bf16x8*)(cur + offb[kk] + i * 4096);
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *(const bf16x8*)(cur + offa[ks] + i * 2048);
+        fb[i] = *(const bf16x8*)(cur + offb[ks] + i * 2048);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
     }
     MFMA_PRIO(0);
   };
@@ -319,18 +334,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
 
   if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + wm * 64 + i * 32 + r;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + c16;
       if (m >= a.M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
-          if (n >= a.N) continue;
-          float* cp = (float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n;
-          *(f32x4*)cp = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * g16;
+        if (n >= a.N) continue;
+        *(f32x4*)((float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n) = acc[i][j];
+      }
     }
   } else {
     epilogue_bf16<FLAGS, 2>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 64, n0 + wn * 64);
@@ -347,7 +359,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
 // =====================================================================================
 #define BM4 256
 #define BK4 32
-__device__ __forceinline__ int lds4_off(int row, int ch) { return row * 64 + ((ch ^ ((row >> 2) & 3)) << 4); }
+// 64-B LDS rows (4 chunks of 16 B): chunk ^= (-(row >> 2)) & 3.  A ds_read_b128 of the 16x16x32 fragments is served in lane groups
+// {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): rows 0-3 and 12-15 with chunk g, rows 4-11 with chunk g + 1 -- the row-quad map
+// 0, 3, 2, 1 puts those four (row quad, chunk) pairs on four different 64-B columns of the 256-B bank row: conflict-free.
+__device__ __forceinline__ int lds4_swz(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ int lds4_off(int row, int ch) { return row * 64 + ((ch ^ lds4_swz(row)) << 4); }
 
 template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
@@ -370,26 +386,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   for (int i = 0; i < 4; ++i) {
     const int c = tid + 256 * i, row = c >> 2, pc = c & 3;
     const int rr = m0 + row < a.M ? row : a.M - 1 - m0;
-    voa[i] = (rr * a.lda + 8 * (pc ^ ((row >> 2) & 3))) * 2;
+    voa[i] = (rr * a.lda + 8 * (pc ^ lds4_swz(row))) * 2;
     if (i < 2) {
       const int rn = n0 + row < a.N ? row : a.N - 1 - n0;
-      vob[i] = (rn * a.ldb + 8 * (pc ^ ((row >> 2) & 3))) * 2;
+      vob[i] = (rn * a.ldb + 8 * (pc ^ lds4_swz(row))) * 2;
     }
   }
-  int offa[2], offb[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    offa[kk] = lds4_off(wm * 128 + r, kk * 2 + h);
-    offb[kk] = 16384 + lds4_off(wn * 64 + r, kk * 2 + h);
-  }
+  const int c16 = lane & 15, g16 = lane >> 4;
+  // one 32-wide k-step per stage: chunk g of row (tile base + c); 16-row tiles are 1024 B apart (the swizzle term repeats every 16 rows)
+  const int offa = lds4_off(wm * 128 + c16, g16);
+  const int offb = 16384 + lds4_off(wn * 64 + c16, g16);
 
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int st, int soff) {
     char* base = smem + st * STG + wid * 1024;
@@ -401,18 +413,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   auto compute = [&](int st) {
     const char* cur = smem + st * STG;
     MFMA_PRIO(1);
+    {
+      bf16x8 fa[8], fb[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[2];
+      for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8*)(cur + offa + i * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 2048);
+      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(cur + offb + j * 1024);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *(const bf16x8*)(cur + offb[kk] + j * 2048);
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
     }
     MFMA_PRIO(0);
   };
@@ -486,20 +497,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
       vob[i] = (rb_ * a.ldb + 8 * src_ch) * 2;
     }
   }
-  int offa[4], offb[4];
+  const int c16 = lane & 15, g16 = lane >> 4;
+  int offa[2], offb[2];    // per 32-wide k-substep: chunk 4 ks + g of row (tile base + c); tiles are 16 rows = 2048 B apart
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    offa[kk] = lds_chunk_off(wm * 128 + r, kk * 2 + h);
-    offb[kk] = 32768 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
+  for (int ks = 0; ks < 2; ++ks) {
+    offa[ks] = lds_chunk_off(wm * 128 + c16, ks * 4 + g16);
+    offb[ks] = 32768 + lds_chunk_off(wn * 64 + c16, ks * 4 + g16);
   }
-
-  f32x16 acc[4][2];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int st, int soff) {
     char* base = smem + st * STG + wid * 1024;
@@ -513,17 +522,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
     const char* cur = smem + st * STG;
     MFMA_PRIO(1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[4], fb[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[8], fb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
+      for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8*)(cur + offa[ks] + i * 2048);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = *(const bf16x8*)(cur + offb[kk] + j * 4096);
+      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(cur + offb[ks] + j * 2048);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
     }
     MFMA_PRIO(0);
   };
@@ -549,18 +558,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
 
   if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 128 + i * 32 + r;
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + c16;
       if (m >= a.M) continue;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * h;
-          if (n >= a.N) continue;
-          float* cp = (float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n;
-          *(f32x4*)cp = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        }
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * g16;
+        if (n >= a.N) continue;
+        *(f32x4*)((float*)a.C + (int64_t)blockIdx.y * a.slab_stride + (int64_t)m * a.ldc + n) = acc[i][j];
+      }
     }
   } else {
     epilogue_bf16<FLAGS, 4>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 128, n0 + wn * 64);
@@ -1508,20 +1514,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGe
       vob[i] = (rb_ * a.ldb + 8 * src_ch) * 2;
     }
   }
-  int offa[4], offb[4];
+  const int c16 = lane & 15, g16 = lane >> 4;
+  int offa[2], offb[2];    // per 32-wide k-substep: chunk 4 ks + g of row (tile base + c); 16-row tiles are 2048 B apart
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    offa[kk] = lds_chunk_off(wm * 64 + r, kk * 2 + h);
-    offb[kk] = 16384 + lds_chunk_off(wn * 64 + r, kk * 2 + h);
+  for (int ks = 0; ks < 2; ++ks) {
+    offa[ks] = lds_chunk_off(wm * 64 + c16, ks * 4 + g16);
+    offb[ks] = 16384 + lds_chunk_off(wn * 64 + c16, ks * 4 + g16);
   }
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto stage = [&](int st, int t) {   // k-step t: tap = t*64 / C, channel offset (t*64) % C  (wave-uniform scalars)
     char* base = smem + st * 32768 + wid * 1024;
@@ -1539,18 +1544,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGe
     const char* cur = smem + st * 32768;
     MFMA_PRIO(1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      bf16x8 fa[2], fb[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *(const bf16x8*)(cur + offa[kk] + i * 4096);
-        fb[i] = *(const bf16x8*)(cur + offb[kk] + i * 4096);
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = *(const bf16x8*)(cur + offa[ks] + i * 2048);
+        fb[i] = *(const bf16x8*)(cur + offb[ks] + i * 2048);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
     }
     MFMA_PRIO(0);
   };
