@@ -872,6 +872,53 @@ __device__ __forceinline__ void w_wait_nodrain(WFrag& f) {   // the weight reads
 __device__ __forceinline__ void w_wait(WFrag& f) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]) : : "memory");
 }
+// ---- 16x16x32 fragments of the 128x128 weight-gradient tile: per 32-row k-substep a wave reads 4 x-tiles and 4 y-tiles of 16
+// columns; each fragment is two transposing 8-byte reads (rows +0..3 | +4..7 of the lane group's 8 rows).  Issued in halves of
+// 8 reads so that counted waits stay inside the 4-bit lgkmcnt.
+struct TrHalf16 {
+  u32x2 t[4][2];   // tile {0..3}{rows +0..3 | +4..7}
+};
+template <int OFF>
+__device__ __forceinline__ void tr16_issue(TrHalf16& f, const unsigned (&ad)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13"
+      : "=&v"(f.t[0][0]), "=&v"(f.t[0][1]), "=&v"(f.t[1][0]), "=&v"(f.t[1][1]), "=&v"(f.t[2][0]), "=&v"(f.t[2][1]),
+        "=&v"(f.t[3][0]), "=&v"(f.t[3][1])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "i"(OFF), "i"(OFF + 1024)
+      : "memory");
+}
+// wait until at most N LDS operations are outstanding; names both halves so that no consumer is scheduled above it
+template <int N>
+__device__ __forceinline__ void tr16_wait(TrHalf16& x, TrHalf16& y) {
+  asm volatile("s_waitcnt lgkmcnt(%16)"
+               : "+v"(x.t[0][0]), "+v"(x.t[0][1]), "+v"(x.t[1][0]), "+v"(x.t[1][1]), "+v"(x.t[2][0]), "+v"(x.t[2][1]),
+                 "+v"(x.t[3][0]), "+v"(x.t[3][1]), "+v"(y.t[0][0]), "+v"(y.t[0][1]), "+v"(y.t[1][0]), "+v"(y.t[1][1]),
+                 "+v"(y.t[2][0]), "+v"(y.t[2][1]), "+v"(y.t[3][0]), "+v"(y.t[3][1])
+               : "n"(N)
+               : "memory");
+}
+// bias-gradient weights of one stage for the 16x16x32 form: 8 consecutive bf16 per 32-row substep at byte 64 s + 16 g
+struct WFrag16 {
+  u32x4 w[2];
+};
+__device__ __forceinline__ void w16_issue(WFrag16& f, unsigned addr) {
+  asm volatile(
+      "ds_read_b128 %0, %2\n\t"
+      "ds_read_b128 %1, %2 offset:64"
+      : "=&v"(f.w[0]), "=&v"(f.w[1])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void w16_keep(WFrag16& f) {   // the weight reads are older than every fragment read: already in
+  asm volatile("" : "+v"(f.w[0]), "+v"(f.w[1]) : : "memory");
+}
 #define TN_LDS_BYTES (65536 + 512)   // two 32-KiB operand stages + two 256-B bias-weight strips
 
 // v3: LDS-DMA staging (buffer_load_dwordx4 ... lds; rows past the split / matrix end read as 0 through the
@@ -902,22 +949,22 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
   const __amdgpu_buffer_rsrc_t rx = CONV ? __builtin_amdgcn_make_buffer_rsrc((void*)a.X, 0, a.ldx, 0x00020000)
                                          : __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)mb * a.ldx + i0), 0, (int)(nbx > 0x7fffffff ? 0x7fffffff : nbx), 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (int64_t)mb * a.ldy + j0), 0, (int)(nby > 0x7fffffff ? 0x7fffffff : nby), 0x00020000);
-  // DMA: linear LDS chunk c = tid + 256 i -> row c>>4, physical chunk c&15 holds source chunk (c&15) ^ 4*(row&3)
+  // DMA: linear LDS chunk c = tid + 256 i -> row c>>4, physical chunk c&15 holds source chunk (c&15) ^ 4*(row&3) ^ 2*((row>>3)&1)
   int vox[4], voy[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = (tid >> 4) + 16 * i;
-    const int sch = (tid & 15) ^ (4 * (row & 3));
+    const int sch = (tid & 15) ^ (4 * (row & 3)) ^ (2 * ((row >> 3) & 1));
     vox[i] = (8 * sch < wx) ? (row * a.ldx + 8 * sch) * 2 : 0x7ffffff0;  // columns past the width read as 0
     voy[i] = (8 * sch < wy) ? (row * a.ldy + 8 * sch) * 2 : 0x7ffffff0;
   }
   const int stepx = TN_BKM * a.ldx * 2, stepy = TN_BKM * a.ldy * 2;
-  // CONV: per-lane constants (the source chunk, hence the tap and channel, do not depend on i: 16 i keeps row & 3)
+  // CONV: per-lane constants (the source chunk, hence the tap and channel, do not depend on i: 16 i keeps row & 3 and row bit 3)
   int cv_dy = 0, cv_dx = 0, cv_coff = 0, cv_m = 0;
   bool cv_colok = false;
   if constexpr (CONV) {
     const int row0 = tid >> 4;
-    const int sch = (tid & 15) ^ (4 * (row0 & 3));
+    const int sch = (tid & 15) ^ (4 * (row0 & 3)) ^ (2 * ((row0 >> 3) & 1));
     const int kcol = i0 + 8 * sch;
     cv_colok = 8 * sch < wx;
     const int tap = cv_colok ? kcol / cg->C : 0;
@@ -926,29 +973,28 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     cv_coff = (kcol - tap * cg->C) * 2;
     cv_m = mb + row0;   // output pixel of this lane's first row in the next stage
   }
-  // fragment read offsets (bytes): row 8h + (l16>>2) [+16kk, +4], byte in row = (w*128 + i*64 + 32*(g4&1) + 8*(l16&3)) ^ 64*(row&3)
+  // fragment read offsets (bytes) for v_mfma_f32_16x16x32_bf16: lane group g4 owns the substep's rows 8 g4 + (l16>>2) [+4]; byte in
+  // row = (wave base + tile*32 + 8*(l16&3)) ^ 64*(row&3) ^ 32*((row>>3)&1) -- the two lane groups of a 32-lane service group read
+  // rows 8 apart (same bank row), so the second XOR term sends them to different 32-B halves: all 64 banks once per service group
   const int rr = l16 >> 2;
-  const int rowb = (8 * h + rr) * 256;
-  const int cb = 32 * (g4 & 1) + 8 * (l16 & 3);
-  int ofx[2], ofy[2];
+  const int rowb = (8 * g4 + rr) * 256;
+  const int cb = 8 * (l16 & 3);
+  const int xm = (64 * rr) ^ (32 * (g4 & 1));
+  int ofx[4], ofy[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    ofx[i] = rowb + ((wi * 128 + i * 64 + cb) ^ (64 * rr));
-    ofy[i] = 16384 + rowb + ((wj * 128 + i * 64 + cb) ^ (64 * rr));
+  for (int t = 0; t < 4; ++t) {
+    ofx[t] = rowb + ((wi * 128 + t * 32 + cb) ^ xm);
+    ofy[t] = 16384 + rowb + ((wj * 128 + t * 32 + cb) ^ xm);
   }
 
-  f32x16 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  f32x16 bacc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) bacc[e] = 0.f;
-  // Bias gradient = (weighted) column sums of dY: blocks of the first row-tile issue one extra MFMA per k-substep whose A operand
-  // is all ones (plain sums) or, with a.bias_w, the per-row weights broadcast over the 32 output rows: D[i][j] = sum_m w[m] Y[m][j].
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  // Bias gradient = (weighted) column sums of dY: blocks of the first row-tile issue two extra MFMAs per k-substep whose A operand
+  // is all ones (plain sums) or, with a.bias_w, the per-row weights broadcast over the 16 output rows: D[i][j] = sum_m w[m] Y[m][j].
   // (Spreading that work over all row-tile blocks was measured: mixed, slower in the step.)
   const bool do_bias = (bias_out != nullptr) && (ti == 0);
   const bool use_w = do_bias && (a.bias_w != nullptr);
@@ -983,39 +1029,43 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
+  auto bf = [](const u32x2 (&p)[2]) { return tr_cat(p[0], p[1]); };
+  auto mfmas = [&](TrHalf16& X, TrHalf16& Y, const bf16x8 wa) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(X.t[i]), bf(Y.t[j]), acc[i][j], 0, 0, 0);   // D[i][j]: lane (c, g) holds rows 4g.., column c
+    if (do_bias) {  // wave (wi, wj) sums the columns of y tiles 2 wi, 2 wi + 1  (wave-uniform branches)
+      if (wi == 0) {
+        bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bf(Y.t[0]), bacc[0], 0, 0, 0);
+        bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bf(Y.t[1]), bacc[1], 0, 0, 0);
+      } else {
+        bacc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bf(Y.t[2]), bacc[0], 0, 0, 0);
+        bacc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bf(Y.t[3]), bacc[1], 0, 0, 0);
+      }
+    }
+  };
   auto compute = [&](int st) {
     const unsigned base = lds0 + st * 32768;
-    TrFrag f[4];
-    WFrag wf;
-    if (use_w) w_issue(wf, lds0 + 65536 + st * 256 + 16 * h);
-    // kk-outer order with two fragment sets in flight and counted waits (lgkmcnt is a 4-bit counter: <= 15 outstanding): the
-    // MFMAs of substep kk run under the reads of kk+1 / kk+2.  The earlier form -- all four sets read up front, then four
-    // back-to-back MFMAs per accumulator -- measured 0.1 ms/step slower in the same call (16.54 / 16.73 vs 16.44 / 16.61 ms).
+    unsigned ax[4], ay[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { ax[t] = base + ofx[t]; ay[t] = base + ofy[t]; }
+    WFrag16 wf;
+    if (use_w) w16_issue(wf, lds0 + 65536 + st * 256 + 16 * g4);
+    // two 32-row substeps; the second substep's fragments are read under the first substep's MFMAs (counted lgkmcnt: the reads
+    // return in order, at most 8 of the younger half may still be in flight when the older set is consumed)
+    TrHalf16 X0, Y0, X1, Y1;
     MFMA_PRIO(1);
-    tr_issue(f[0], base + ofx[0], base + ofx[1], base + ofy[0], base + ofy[1]);
-    tr_issue(f[1], base + 4096 + ofx[0], base + 4096 + ofx[1], base + 4096 + ofy[0], base + 4096 + ofy[1]);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 3) tr_wait8(f[kk]); else tr_wait(f[kk]);
-      if (kk == 0 && use_w) w_wait_nodrain(wf);
-      if (kk + 2 < 4) {
-        const unsigned b2 = base + (kk + 2) * 4096;
-        tr_issue(f[kk + 2], b2 + ofx[0], b2 + ofx[1], b2 + ofy[0], b2 + ofy[1]);
-      }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x0a, f[kk].x0b), tr_cat(f[kk].y0a, f[kk].y0b), acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x0a, f[kk].x0b), tr_cat(f[kk].y1a, f[kk].y1b), acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x1a, f[kk].x1b), tr_cat(f[kk].y0a, f[kk].y0b), acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_cat(f[kk].x1a, f[kk].x1b), tr_cat(f[kk].y1a, f[kk].y1b), acc[1][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (do_bias) {  // wave (wi,wj) sums columns wj*64 + wi*32 ..  (wave-uniform branches)
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const bf16x8 wa = use_w ? __builtin_bit_cast(bf16x8, wf.w[kk]) : ones;
-        if (wi == 0) bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f[kk].y0a, f[kk].y0b), bacc, 0, 0, 0);
-        else bacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, tr_cat(f[kk].y1a, f[kk].y1b), bacc, 0, 0, 0);
-      }
-    }
+    tr16_issue<0>(X0, ax);
+    tr16_issue<0>(Y0, ay);
+    tr16_issue<8192>(X1, ax);
+    tr16_wait<8>(X0, Y0);
+    if (use_w) w16_keep(wf);
+    tr16_issue<8192>(Y1, ay);
+    mfmas(X0, Y0, use_w ? __builtin_bit_cast(bf16x8, wf.w[0]) : ones);
+    tr16_wait<0>(X1, Y1);
+    mfmas(X1, Y1, use_w ? __builtin_bit_cast(bf16x8, wf.w[1]) : ones);
     MFMA_PRIO(0);
   };
 
@@ -1045,22 +1095,25 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     }
   }
   if (a.dbg) tq2 = __builtin_readcyclecounter();
-  // store: reg e -> row i = (e&3) + 8*(e>>2) + 4h ; col j = lane&31
+  // store: tile (i, j), reg e -> row 16 i + 4 g + e ; column 16 j + c
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = j0 + wj * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < 4; ++j) {
+      const int col = j0 + wj * 64 + j * 16 + l16;
       if (col >= a.J) continue;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = i0 + wi * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      for (int e = 0; e < 4; ++e) {
+        const int row = i0 + wi * 64 + i * 16 + 4 * g4 + e;
         if (row < a.I) C[(int64_t)row * ldc + col] = acc[i][j][e];
       }
     }
-  if (do_bias && h == 0) {  // row 0 of D (reg 0 of the lower half-wave) holds the column sums
-    const int col = j0 + wj * 64 + wi * 32 + (lane & 31);
-    if (col < a.J) bias_out[col] = bacc[0];
+  if (do_bias && g4 == 0) {  // row 0 of D (reg 0 of lane group 0) holds the column sums
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = j0 + wj * 64 + (2 * wi + q) * 16 + l16;
+      if (col < a.J) bias_out[col] = bacc[q][0];
+    }
   }
   if (a.dbg && tid == 0) {
     unsigned long long* dq = a.dbg + (size_t)blockIdx.x * 8;   // 100 MHz realtime stamps calibrate the cycle counter
