@@ -26,7 +26,8 @@
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
 static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (long K, whole residencies), 2 always (tests)
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
-static int g_opt_tn8 = 1;        // 256x256 weight-gradient tile (8 waves): 0 never, 1 auto (few tiles, many row splits), 2 always (tests)
+static int g_opt_tn8 = 0;        // 256x256 weight-gradient tile (8 waves, still on 32x32x16 MFMAs): 0 never (default since the 128x128 kernel
+                                 // moved to 16x16x32: 45 / 76 us vs 60 / 86 us on the 512x512 / 512x1536 gradients), 1 auto (few tiles), 2 always (tests)
 static int g_opt_tn8_max_tiles = 16;   // auto mode: use the 256x256 weight-gradient kernel below this many tiles (A/B hook)
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;

@@ -292,7 +292,7 @@ def test_gemm_tn(tail, tn8, M, I, J):
         close(db2, wv.float() @ dY.float(), 1e-4, 1e-3 * math.sqrt(M), f"gemm_tn weighted bias grad tail={tail}")
     finally:
         dh.set_option("tn_tail", 1)
-        dh.set_option("tn8", 1)
+        dh.set_option("tn8", 0)
 
 
 def test_gemm_tn_deferred_batch_reduce_is_bit_identical():

@@ -72,7 +72,7 @@ def bench_gemm_tn(M, I, J, weighted=False):
     for tn8 in (0, 2, 0, 2):    # 128x128 | 256x256 tiles (repeated: drift check)
         dh.set_option("tn8", tn8)
         _bench_gemm_tn(M, I, J, weighted, tn8)
-    dh.set_option("tn8", 1)
+    dh.set_option("tn8", 0)
 
 
 def _bench_gemm_tn(M, I, J, weighted, tn8):
