@@ -944,32 +944,51 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
 // batch element in place (row pitch S*3d), then this kernel computes, per (batch, head),
 //     o = softmax(q_pos . K[0..pos]^T) V[0..pos]           (unscaled logits, as everywhere on this path)
 // HBM-bound (2 * (pos+1) * 256 B per head): one block per (b, h), a wave per 64-key chunk with key = lane for the scores
-// (no cross-lane reduction per key), online softmax per wave, P.V with lane = 2 output dims; the four waves merge through LDS.
+// (no cross-lane reduction per key), online softmax per wave, P.V with lane = 2 output dims; the sixteen waves merge through LDS.
+// (With four waves and one value row in flight per wave the kernel was latency-bound: 46 us at B*H = 128, S = 1280.)
 // P is rounded to bf16 before P.V and the row sum is taken over the unrounded fp32 values -- the same places where the tiled
 // forward kernel rounds -- so decode logits track full-forward logits to bf16 noise.
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o, int H, int S, int pos) {
+//
+// Graph-replayable form (one captured HIP graph serves every position of the sampling loop): `pos_dev` -- the position read
+// from device memory -- and `fresh` -- a [B, 3d] staging buffer at a FIXED address that the step's QKV GEMM wrote (a kernel
+// argument baked into a graph cannot move along the cache).  With `fresh` the block takes q from it, stores the head's
+// q | k | v into cache row `pos` for the steps to come, and reads key / value `pos` from the staging row itself (no reliance
+// on the block seeing its own global stores).
+#define DEC_WAVES 16   // 1024 threads: a (batch, head) pair streams <= S keys through ONE block, so the block must itself hold the loads in flight
+__global__ __launch_bounds__(64 * DEC_WAVES) void attn_decode_kernel(bf16_t* qkv, const bf16_t* __restrict__ fresh, bf16_t* __restrict__ o,
+                                                                     int H, int S, int pos_arg, const int* __restrict__ pos_dev) {
   __shared__ float qs[HD];
-  __shared__ float ps[4][64];
-  __shared__ float red_m[4], red_l[4];
-  __shared__ float oacc[4][HD];
+  __shared__ float ps[DEC_WAVES][64];
+  __shared__ float red_m[DEC_WAVES], red_l[DEC_WAVES];
+  __shared__ float oacc[DEC_WAVES][HD];
   const int bh = blockIdx.x, b = bh / H, hh = bh % H;
   const int d = H * HD;
   const int64_t ld3 = 3 * (int64_t)d;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const bf16_t* base = qkv + (int64_t)b * S * ld3 + hh * HD;
-  if (threadIdx.x < HD) qs[threadIdx.x] = bf2f(base[(int64_t)pos * ld3 + threadIdx.x]);
+  const int pos = pos_dev ? *pos_dev : pos_arg;
+  if (pos < 0 || pos >= S) return;                     // (block-uniform; the host checks the by-value form)
+  bf16_t* base = qkv + (int64_t)b * S * ld3 + hh * HD;
+  const bf16_t* fr = fresh ? fresh + (int64_t)b * ld3 + hh * HD : nullptr;
+  if (threadIdx.x < HD) qs[threadIdx.x] = bf2f(fr ? fr[threadIdx.x] : base[(int64_t)pos * ld3 + threadIdx.x]);
+  if (fr && threadIdx.x >= HD && threadIdx.x < HD + 3 * HD / 8) {   // q | k | v of this head: 3 x 256 B -> cache row pos
+    const int t = threadIdx.x - HD, part = t / (HD / 8), ch = t % (HD / 8);
+    *(u32x4*)(base + (int64_t)pos * ld3 + part * d + ch * 8) = *(const u32x4*)(fr + part * d + ch * 8);
+  }
   __syncthreads();
   float m = -1e30f, l = 0.f, o0 = 0.f, o1 = 0.f;
-  for (int c = wid; c * 64 <= pos; c += 4) {
+  for (int c = wid; c * 64 <= pos; c += DEC_WAVES) {
     const int key = c * 64 + lane;
     const bool valid = key <= pos;
     float s = 0.f;
     if (valid) {
-      const u32x4* kr = (const u32x4*)(base + d + (int64_t)key * ld3);
+      const u32x4* kr = (const u32x4*)((fr && key == pos) ? fr + d : base + d + (int64_t)key * ld3);
+      u32x4 kv[HD / 8];
+#pragma unroll
+      for (int i = 0; i < HD / 8; ++i) kv[i] = kr[i];    // the whole 256-B row requested before the first use
 #pragma unroll
       for (int i = 0; i < HD / 8; ++i) {
         float f[8];
-        unpack8(kr[i], f);
+        unpack8(kv[i], f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s = __builtin_fmaf(f[j], qs[8 * i + j], s);
       }
@@ -987,11 +1006,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: in-order LDS, no block barrier needed
     const int nk = (pos - c * 64 + 1 < 64) ? pos - c * 64 + 1 : 64;
     const bf16_t* vr = base + 2 * d + (int64_t)(c * 64) * ld3 + 2 * lane;
-    for (int j = 0; j < nk; ++j) {
-      const unsigned vv = *(const unsigned*)(vr + (int64_t)j * ld3);
-      const float pj = ps[wid][j];
-      o0 = __builtin_fmaf(pj, __uint_as_float(vv << 16), o0);
-      o1 = __builtin_fmaf(pj, __uint_as_float(vv & 0xffff0000u), o1);
+    for (int j0 = 0; j0 < nk; j0 += 8) {                  // eight value rows in flight per wave; rows past nk: clamped, p = 0
+      unsigned vv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = (j0 + u < nk) ? j0 + u : nk - 1;
+        vv[u] = *(const unsigned*)((fr && c * 64 + j == pos) ? fr + 2 * d + 2 * lane : vr + (int64_t)j * ld3);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float pj = ps[wid][j0 + u];                 // (j0 + u <= 63; entries >= nk hold 0)
+        o0 = __builtin_fmaf(pj, __uint_as_float(vv[u] << 16), o0);
+        o1 = __builtin_fmaf(pj, __uint_as_float(vv[u] & 0xffff0000u), o1);
+      }
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1000,10 +1027,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   oacc[wid][2 * lane + 1] = o1;
   __syncthreads();
   if (wid == 0) {
-    const float M = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    float M = red_m[0];
+#pragma unroll
+    for (int w = 1; w < DEC_WAVES; ++w) M = fmaxf(M, red_m[w]);
     float L = 0.f, a0 = 0.f, a1 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {      // fixed order: deterministic
+    for (int w = 0; w < DEC_WAVES; ++w) {      // fixed order: deterministic
       const float sc = __expf(red_m[w] - M);
       L += red_l[w] * sc;
       a0 += oacc[w][2 * lane] * sc;
@@ -1014,10 +1043,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
   }
 }
 
-extern "C" int dmi_attention_decode(const uint16_t* qkv, uint16_t* o, int B, int H, int S, int pos, void* stream) {
+extern "C" int dmi_attention_decode(uint16_t* qkv, const uint16_t* fresh, uint16_t* o, int B, int H, int S, int pos, const int* pos_dev,
+                                    void* stream) {
   DMI_REQUIRE(qkv && o, "attention_decode: null pointer");
-  DMI_REQUIRE(B > 0 && H > 0 && S > 0 && pos >= 0 && pos < S, "attention_decode: need 0 <= pos < S (pos=%d, S=%d)", pos, S);
-  attn_decode_kernel<<<dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream>>>(qkv, o, H, S, pos);
+  DMI_REQUIRE(B > 0 && H > 0 && S > 0, "attention_decode: bad shape");
+  DMI_REQUIRE(pos_dev || (pos >= 0 && pos < S), "attention_decode: need 0 <= pos < S (pos=%d, S=%d)", pos, S);
+  attn_decode_kernel<<<dim3((unsigned)(B * H)), dim3(64 * DEC_WAVES), 0, (hipStream_t)stream>>>(qkv, fresh, o, H, S, pos, pos_dev);
   DMI_CHECK_LAUNCH("attention_decode");
   return DMI_OK;
 }

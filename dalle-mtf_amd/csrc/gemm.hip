@@ -29,6 +29,7 @@ int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1:
 static int g_opt_tn8 = 0;        // 256x256 weight-gradient tile (8 waves, still on 32x32x16 MFMAs): 0 never (default since the 128x128 kernel
                                  // moved to 16x16x32: 45 / 76 us vs 60 / 86 us on the 512x512 / 512x1536 gradients), 1 auto (few tiles), 2 always (tests)
 static int g_opt_tn8_max_tiles = 16;   // auto mode: use the 256x256 weight-gradient kernel below this many tiles (A/B hook)
+static int g_opt_skinny = 1;     // M <= 32 products (the decode step) on the weight-streaming kernel: 0 never, 1 auto
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;
 extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
@@ -36,6 +37,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt8")) return g_opt_nt8;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
+  if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
   if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
@@ -45,6 +47,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
+  if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
   if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
@@ -587,9 +590,73 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
   }
 }
 
+// =====================================================================================
+// skinny NT GEMM: M <= 32 rows (the incremental decode step: one new position per sequence)
+// =====================================================================================
+// C[M <= 32, N] = A[M, K] . Bt[N, K]^T with the bias / ReLU / residual epilogues of the decode step.  The 128-row tiles above
+// put such a product on N / 128 CUs (4 blocks for N = 512: 19 us at K = 2048, all of it latency); the work is a stream over
+// the WEIGHTS (N * K * 2 bytes, HBM / L2 bound), so here a block owns 16 output columns and its eight waves split K in
+// 64-element steps: every lane loads 32 contiguous bytes of one weight row and of two activation rows per step (whole 128-B
+// lines per 4 lanes), straight into v_mfma_f32_16x16x32_bf16 operands -- the contraction order inside a step is permuted the
+// same way for both operands, which a dot product does not see -- and the eight partial tiles are summed through LDS in a
+// fixed order.  No LDS staging of operands, no barriers in the K loop.
+#define SK_WAVES 8
+template <int FLAGS>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_nt_skinny_kernel(const GemmArgs a) {
+  __shared__ f32x4 red[SK_WAVES][2][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int r0 = c < a.M ? c : a.M - 1, r1 = 16 + c < a.M ? 16 + c : a.M - 1;   // rows past M: clamped, never stored
+  const bf16_t* pa0 = a.A + (int64_t)r0 * a.lda + 16 * g;
+  const bf16_t* pa1 = a.A + (int64_t)r1 * a.lda + 16 * g;
+  const bf16_t* pb = a.B + (int64_t)(n0 + c) * a.ldb + 16 * g;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k0 = 64 * wid; k0 < a.K; k0 += 64 * SK_WAVES) {
+    const bf16x8 b0 = *(const bf16x8*)(pb + k0), b1 = *(const bf16x8*)(pb + k0 + 8);
+    const bf16x8 x0 = *(const bf16x8*)(pa0 + k0), x1 = *(const bf16x8*)(pa0 + k0 + 8);
+    const bf16x8 y0 = *(const bf16x8*)(pa1 + k0), y1 = *(const bf16x8*)(pa1 + k0 + 8);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y0, b0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b1, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(y1, b1, acc1, 0, 0, 0);
+  }
+  red[wid][0][lane] = acc0;
+  red[wid][1][lane] = acc1;
+  __syncthreads();
+  if (wid >= 2) return;
+  // waves 0 / 1 finish rows 0..15 / 16..31: lane (c, g) holds column n0 + c of rows 4g + e
+  f32x4 v = red[0][wid][lane];
+#pragma unroll
+  for (int w = 1; w < SK_WAVES; ++w) {
+    const f32x4 t = red[w][wid][lane];
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  const int n = n0 + c;
+  float bias = 0.f;
+  if constexpr (FLAGS & DMI_GEMM_BIAS) bias = bf2f(a.bias[n]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = 16 * wid + 4 * g + e;
+    if (m >= a.M) continue;
+    float x = v[e] + bias;
+    if constexpr (FLAGS & DMI_GEMM_RELU) x = fmaxf(x, 0.f);
+    if constexpr (FLAGS & DMI_GEMM_RESIDUAL) x += bf2f(a.residual[(int64_t)m * a.ldc + n]);
+    ((bf16_t*)a.C)[(int64_t)m * a.ldc + n] = f2bf(x);
+  }
+}
+
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
+  if constexpr (FLAGS == 0 || FLAGS == DMI_GEMM_BIAS || FLAGS == (DMI_GEMM_BIAS | DMI_GEMM_RELU) || FLAGS == (DMI_GEMM_BIAS | DMI_GEMM_RESIDUAL)) {
+    if (g_opt_skinny && a.M <= 32 && nsplit == 1 && a.N % 16 == 0) {
+      gemm_nt_skinny_kernel<FLAGS><<<dim3(a.N / 16), dim3(64 * SK_WAVES), 0, st>>>(a);
+      DMI_CHECK_LAUNCH("gemm_nt_skinny");
+      return DMI_OK;
+    }
+  }
   {
     const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
     // 256x256 tiles (one 8-wave block per CU): main-loop-bound shapes only -- long K and whole residencies of 256 blocks

@@ -75,7 +75,7 @@ def _declare(L):
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
         "dmi_attention_fwd": (I, [P, P, P, I, I, I, P]),
         "dmi_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
-        "dmi_attention_decode": (I, [P, P, I, I, I, I, P]),
+        "dmi_attention_decode": (I, [P, P, P, I, I, I, I, P, P]),
         "dmi_label_logit": (I, [P, I, P, I, P, P, P, P, L64, I, I, P]),
         "dmi_gemm_nt_softmax_partials": (L64, [I]),
         "dmi_gemm_nt_softmax": (I, [P, I, P, I, P, P, P, I, P, I, I, I, P]),
@@ -201,10 +201,17 @@ def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None,
                              _p(relu_src), _p(rowscale), _stream()), "gemm_nt")
 
 
-def attention_decode(qkv, o, B, H, S, pos):
-    """one query position against the K/V cache held in the [B*S, 3d] projection buffer (row pos already written)"""
+def attention_decode(qkv, o, B, H, S, pos, fresh=None, pos_dev=None):
+    """one query position against the K/V cache held in the [B*S, 3d] projection buffer.  fresh=None: row pos already
+    written; fresh = [B, 3d] staging buffer: the kernel moves it into row pos.  pos_dev (int32 [1] on the device) overrides
+    pos -- the graph-replayable form."""
     _dev(qkv, o)
-    _check(lib().dmi_attention_decode(_p(qkv), _p(o), B, H, S, int(pos), _stream()), "attention_decode")
+    if fresh is not None:
+        _dev(fresh)
+    if pos_dev is not None:
+        _dev(pos_dev)
+        assert pos_dev.dtype == torch.int32
+    _check(lib().dmi_attention_decode(_p(qkv), _p(fresh), _p(o), B, H, S, int(pos), _p(pos_dev), _stream()), "attention_decode")
 
 
 def gemm_nt_splitk_workspace_bytes(M, N, nsplit):

@@ -364,7 +364,7 @@ class DalleEngine:
 
     # ------------------------------------------------------------------ sampling
     def sample_image_tokens(self, text: torch.Tensor, temperature: float = 1.0, top_k: int = 0, seed: int = 0,
-                            kv_cache: bool = True) -> torch.Tensor:
+                            kv_cache: bool = True, decode_graph: bool = True) -> torch.Tensor:
         """Autoregressive image-token sampling: text int32 [B, T] -> image-token ids [B, P] in [0, image_vocab_size).
         The reference scaffolds this (is_incremental_inference, models.py:246-254,281-285) but its predict path raises
         NotImplementedError (model_fns.py:135-136).  Logits are restricted to the image vocabulary; temperature / top-k /
@@ -373,7 +373,8 @@ class DalleEngine:
         kv_cache=True (default): ONE full forward over the text prefix fills the per-layer key/value cache (the [B*S, 3d]
         projection buffers of the forward pass), then every further token is one incremental step over B rows --
         decode_step(): QKV GEMM writing row `pos` of the cache in place, dmi_attention_decode (one query against keys
-        0..pos), out-projection, MLP -- ~45 launches of a few microseconds instead of a 1280-position forward.
+        0..pos), out-projection, MLP -- ~90 launches of a few microseconds instead of a 1280-position forward, replayed as
+        one HIP graph (decode_graph; see decode_step).
         kv_cache=False: the plain form, one full evaluation forward per generated position (the causal mask makes the
         not-yet-generated tail irrelevant); kept as the cross-check the cached path is tested against."""
         B, T, S, P = self.B, self.T, self.S, self.S - self.T
@@ -399,33 +400,67 @@ class DalleEngine:
                 self.forward(toks, need_grad=False)
                 z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi].float()   # the position before predicts token T + pos
             else:
-                z = self.decode_step(toks[:, T + pos - 1].contiguous(), T + pos - 1)
+                z = self.decode_step(toks[:, T + pos - 1].contiguous(), T + pos - 1, graph=decode_graph)
             toks[:, T + pos] = (pick(z) + lo).to(torch.int32)
         return (toks[:, T:] - lo).contiguous()
 
-    def decode_step(self, tokens_at_pos: torch.Tensor, pos: int) -> torch.Tensor:
+    def decode_step(self, tokens_at_pos: torch.Tensor, pos: int, graph: bool = True) -> torch.Tensor:
         """Incremental inference (reference hooks src/dalle_mtf/models.py:246-254,281-285): the hidden state of sequence
         position `pos` alone, given the tokens int32 [B] at that position and the key/value cache of positions < pos left by
         forward() / earlier decode steps in self.qkv[l].  Returns fp32 logits over the IMAGE vocabulary [B, image_vocab_size]
-        (what predicts the token at pos + 1)."""
+        (what predicts the token at pos + 1; the buffer is reused by the next call).
+
+        graph=True: the ~90 launches of a step are a few microseconds of GPU work each, so the step is launch-bound when
+        driven from the host; it is captured ONCE as a HIP graph and replayed for every position.  Nothing position-dependent
+        is a by-value kernel argument: the position lives in device memory (the positional-embedding row is gathered by it,
+        dmi_attention_decode reads it as pos_dev), and the QKV GEMM writes a fixed staging buffer that the attention kernel
+        moves into cache row pos.  graph=False runs the same launches eagerly (the cross-check)."""
         B, d, L, H, S = self.B, self.d, self.L, self.H, self.S
         assert tokens_at_pos.shape == (B,) and tokens_at_pos.dtype == torch.int32 and 0 <= pos < S
         if getattr(self, "_dec", None) is None:
             b16 = dict(dtype=torch.bfloat16, device=self.dev)
             f32 = dict(dtype=torch.float32, device=self.dev)
+            wpe = self._w("positional_embedding/wpe")
             self._dec = dict(x=[torch.empty(B, d, **b16) for _ in range(2)], xn=torch.empty(B, d, **b16), o=torch.empty(B, d, **b16),
                              h=torch.empty(B, 4 * d, **b16), st=[torch.empty(B, **f32) for _ in range(2)],
-                             z=torch.empty(B, self.image_vocab_size, **b16))
+                             z=torch.empty(B, self.image_vocab_size, **b16), fresh=torch.empty(B, 3 * d, **b16),
+                             tok=torch.empty(B, dtype=torch.int32, device=self.dev),
+                             pos_i=torch.zeros(1, dtype=torch.int32, device=self.dev),
+                             pos_l=torch.zeros(1, dtype=torch.int64, device=self.dev),
+                             wpe_row=torch.empty(1, d, dtype=wpe.dtype, device=self.dev),
+                             logits=torch.empty(B, self.image_vocab_size, **f32), graph=None, warm=False)
         D = self._dec
-        x, x1, xn, o, h, st, z = D["x"][0], D["x"][1], D["xn"], D["o"], D["h"], D["st"], D["z"]
-        wpe = self._w("positional_embedding/wpe")
-        dh.embed_fwd(tokens_at_pos, self._w("embedding/wte"), wpe[pos:pos + 1], x, 1, d, self.V)   # every row takes wpe[pos]
+        D["tok"].copy_(tokens_at_pos)
+        D["pos_i"].fill_(pos)
+        D["pos_l"].fill_(pos)
+        if not graph:
+            self._decode_body()
+        elif D["graph"] is None and not D["warm"]:
+            self._decode_body()            # first step eager: lazily created views / copies come into being outside the capture
+            D["warm"] = True
+        else:
+            if D["graph"] is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._decode_body()
+                D["graph"] = g             # (capture records, it does not execute: the replay below is the step)
+            D["graph"].replay()
+        return D["logits"]
+
+    def _decode_body(self):
+        """the launches of one decode step; reads D[tok], D[pos_i] / D[pos_l] from device memory, writes D[logits]"""
+        B, d, L, H, S = self.B, self.d, self.L, self.H, self.S
+        D = self._dec
+        x, x1, xn, o, h, st, z, fresh = D["x"][0], D["x"][1], D["xn"], D["o"], D["h"], D["st"], D["z"], D["fresh"]
+        torch.index_select(self._w("positional_embedding/wpe"), 0, D["pos_l"], out=D["wpe_row"])
+        dh.embed_fwd(D["tok"], self._w("embedding/wte"), D["wpe_row"], x, 1, d, self.V)   # every row takes wpe[pos]
         for l in range(L):
             p = f"layer_{l}/"
             cache = self.qkv[l]                                        # [B*S, 3d]; row b*S + pos <- q | k | v of this step
             dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), xn, st[0], st[1], B, d)
-            dh.gemm_nt(xn, d, self.tview(p + "attn/qkv"), d, cache[pos:], S * 3 * d, B, 3 * d, d)
-            dh.attention_decode(cache, o, B, H, S, pos)
+            dh.gemm_nt(xn, d, self.tview(p + "attn/qkv"), d, fresh, 3 * d, B, 3 * d, d)
+            dh.attention_decode(cache, o, B, H, S, 0, fresh=fresh, pos_dev=D["pos_i"])
             dh.gemm_nt(o, d, self.tview(p + "attn/o"), d, x1, d, B, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
                        bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
             dh.layernorm_fwd(x1, self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), xn, st[0], st[1], B, d)
@@ -437,7 +472,7 @@ class DalleEngine:
         lo, nv = self.text_vocab_size, self.image_vocab_size
         Wt = self.tview("to_logits/linear_out/kernel")                 # [Vp, d]: rows lo .. lo + nv are the image vocabulary
         dh.gemm_nt(xn, d, Wt[lo:lo + nv], d, z, nv, B, nv, d)
-        return z.float() + self._w("to_logits/linear_out/bias")[lo:lo + nv].float()
+        torch.add(z.float(), self._w("to_logits/linear_out/bias")[lo:lo + nv], out=D["logits"])
 
     # ------------------------------------------------------------------ backward
     def _gv(self, name):

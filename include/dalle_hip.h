@@ -31,7 +31,8 @@ const char* dmi_last_error_string(void);
 int dmi_version(void);
 /* Test hooks (every setting computes the same results): "nt4" 0/1/2 = never / auto / always use the 256x128 NT tile,
  * "nt8" / "tn8" 0/1/2 = the 256x256 8-wave NT / weight-gradient tiles, "tn_tail" 0/1 = row-split the ragged last residency of
- * unsplit weight gradients, "attn_xcd" = schedule of the persistent attention blocks (0: one serpentine over all blocks,
+ * unsplit weight gradients, "skinny" 0/1 = products with M <= 32 rows (the decode step) on the weight-streaming kernel,
+ * "attn_xcd" = schedule of the persistent attention blocks (0: one serpentine over all blocks,
  * != 0: per-XCD item lists when the (batch, head) count divides by 8).  Unknown name -> -1. */
 int dmi_get_option(const char* name);
 int dmi_set_option(const char* name, int value);
@@ -120,8 +121,13 @@ int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_
 /* Incremental decode (the reference's unfinished is_incremental_inference path, src/dalle_mtf/models.py:246-254,281-285):
  * one query position `pos` against the key/value cache.  qkv = the forward pass's projection buffer [B*S, 3*H*128] used as the
  * cache; row b*S + pos must already hold q | k | v of the new position (the caller's QKV GEMM writes it in place with row
- * pitch S*3d).  o[b, h*128 ..] = softmax(q . K[0..pos]^T) V[0..pos], bf16 [B, H*128].  Unscaled logits, keys <= pos only. */
-int dmi_attention_decode(const uint16_t* qkv, uint16_t* o, int B, int H, int S, int pos, void* stream);
+ * pitch S*3d).  o[b, h*128 ..] = softmax(q . K[0..pos]^T) V[0..pos], bf16 [B, H*128].  Unscaled logits, keys <= pos only.
+ * Graph-replayable form: fresh != NULL = a [B, 3*H*128] staging buffer at a fixed address holding the step's q | k | v (the
+ * QKV GEMM writes it instead of the cache row); the kernel copies it into cache row pos and attends.  pos_dev != NULL = the
+ * position is read from device memory (one int32; `pos` is then ignored and a position outside [0, S) makes the launch a
+ * no-op), so ONE captured HIP graph serves every step of the sampling loop. */
+int dmi_attention_decode(uint16_t* qkv, const uint16_t* fresh, uint16_t* o, int B, int H, int S, int pos, const int* pos_dev,
+                         void* stream);
 
 /* ---- K7/K8  to_logits + cross entropy, labels = shift(tokens)   models.py:391-395,348-359,407-410
  * labels[t] = tokens[t+1], last = eos (bit-exact int path). */

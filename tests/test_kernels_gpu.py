@@ -184,6 +184,29 @@ def test_gemm_nt_epilogues():
     close(C, _gemm_ref(A2[:, K:2 * K], Bt), what="strided A", **tol)
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(32, 512, 512, 0), (32, 1536, 512, 0), (3, 2048, 512, 3), (32, 512, 2048, 5), (17, 48, 64, 1),
+                                         (1, 16, 192, 5), (32, 512, 576, 3)])
+def test_gemm_nt_skinny_rows(M, N, K, flags):
+    """M <= 32 products (the decode step) run on the weight-streaming kernel (8 waves split K, 16 columns per block): against
+    the fp32 product and against the tiled kernel (same inputs, different summation order -> bf16-rounding differences only);
+    lda / ldc larger than the logical widths as in the decode step."""
+    A, Bt = rnd(M, K + 64, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N + 16, seed=4)
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None)
+    ref = _gemm_ref(A[:, :K], Bt, bias if flags & 1 else None, relu=bool(flags & 2), residual=res[:, :N] if flags & 4 else None)
+    outs = []
+    for sk in (1, 0):
+        dh.set_option("skinny", sk)
+        C = torch.full((M + 1, N + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+        dh.gemm_nt(A.to(DEV), K + 64, Bt.to(DEV), K, C, N + 16, M, N, K, flags, **kw)
+        close(C[:M, :N], ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), f"gemm_nt skinny={sk}")
+        assert bool((C[M:] == 7.0).all()) and bool((C[:, N:] == 7.0).all()), "wrote outside the [M, N] block"
+        outs.append(C[:M, :N].float().cpu())
+    dh.set_option("skinny", 1)
+    scale = float(ref.abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 1.6e-2 * scale
+
+
 @pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3),
                                          (515, 136, 64, 8), (700, 264, 128, 32)])
 def test_gemm_nt4_tile_256(M, N, K, flags):

@@ -253,6 +253,19 @@ def test_attention_decode_kernel_vs_fp32_math(B, H, S):
         ref = torch.einsum("bhk,bkhd->bhd", w, v).reshape(B, d)
         err = float((o.float().cpu() - ref).abs().max())
         assert err <= 1.6e-2 * float(ref.abs().max()) + 2e-3, (pos, err)
+        # graph-replayable form: position from device memory, q | k | v of the step handed over in a staging buffer ->
+        # the same bits, and the staging row lands in cache row pos
+        cache = qd.clone()
+        cache.view(B, S, 3 * d)[:, pos] = 0
+        fresh = qd.view(B, S, 3 * d)[:, pos].contiguous()
+        o2 = torch.full_like(o, 7.0)
+        dh.attention_decode(cache, o2, B, H, S, 0, fresh=fresh, pos_dev=torch.tensor([pos], dtype=torch.int32, device="cuda"))
+        assert torch.equal(o2, o), pos
+        assert torch.equal(cache, qd), pos
+    o2.fill_(7.0)            # a position outside [0, S) in device memory: the launch is a no-op
+    dh.attention_decode(cache, o2, B, H, S, 0, fresh=fresh, pos_dev=torch.tensor([S], dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    assert bool((o2 == 7.0).all()) and torch.equal(cache, qd)
 
 
 def test_kv_cached_decode_equals_full_forward():
@@ -272,9 +285,13 @@ def test_kv_cached_decode_equals_full_forward():
     eng.forward(toks, need_grad=False)                      # also the prefill: k, v of every position are in the cache
     full = eng.z.view(B, S, eng.Vp)[:, :, tv:tv + iv].float().clone()
     worst = 0.0
-    for p in list(range(T - 1, T + 70)) + [127, 128, 129, 255, 256, S - 2, S - 1]:
+    for i, p in enumerate(list(range(T - 1, T + 70)) + [127, 128, 129, 255, 256, S - 2, S - 1]):
         z = eng.decode_step(toks[:, p].contiguous(), p)     # rewrites row p of the cache with the same values
         worst = max(worst, float((z - full[:, p]).abs().max()))
+        if i % 7 == 0 or p > 100:   # the replayed HIP graph (steps >= 2) and the eager launches give the same bits
+            zg = z.clone()
+            assert torch.equal(eng.decode_step(toks[:, p].contiguous(), p, graph=False), zg), p
+    assert eng._dec["graph"] is not None
     scale = float(full.abs().max())
     print("decode vs full forward: max |dlogit|", worst, "of", scale)
     assert worst <= 2.5e-2 * scale, (worst, scale)
