@@ -1253,3 +1253,112 @@ extern "C" int dmi_cast_f32_bf16(const float* in, uint16_t* out, int64_t n, void
   DMI_CHECK_LAUNCH("cast");
   return DMI_OK;
 }
+
+// =====================================================================================
+// sampling of the next image token from one row of head logits
+// =====================================================================================
+// The reference stops at the logits (predict raises NotImplementedError, src/model_fns.py:135-136); the sampler around the
+// incremental-inference hooks (src/dalle_mtf/models.py:246-254,281-285) is this repo's.  One block per sequence:
+//   v[i] = (z[b, i] + bias[i]) / temperature;  top-k filter: keep v[i] >= (k-th largest v)  (ties kept, as a masked_fill
+//   of v < kth would);  choice ~ softmax(v) over the kept entries, drawn as argmax_i (v[i] + Gumbel noise) -- the Gumbel-max
+//   form of the same categorical draw -- with counter-based noise hash(seed, position, b, i): reproducible, no RNG state.
+//   temperature <= 0: greedy (first maximum).
+// The k-th largest value is found without a sort: 32 steps of a bitwise binary search on order-preserving integer keys
+// (count(key >= candidate) >= k), a block-wide count per step.
+// Everything that changes between calls may come from device memory (params_dev: {1/temperature or 0, top_k, seed lo, seed hi};
+// pos_dev), and the choice is written where the next decode step reads its input token, so that decode + sampling replay as one
+// HIP graph with no host round trip per position.
+__device__ __forceinline__ unsigned order_key(float v) {
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_value(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+#define SAMPLE_MAX_VOCAB 8192
+__global__ __launch_bounds__(256) void sample_tokens_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ bias, int nv,
+                                                            float inv_temp, int top_k, uint64_t seed, const unsigned* __restrict__ params_dev,
+                                                            int pos_arg, const int* __restrict__ pos_dev, int token_offset,
+                                                            int* __restrict__ next_tok, int* __restrict__ out, int out_ld, int out_col0) {
+  __shared__ unsigned keys[SAMPLE_MAX_VOCAB];
+  __shared__ int cnt[4];
+  __shared__ float bval[4];
+  __shared__ int bidx[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (params_dev) {
+    inv_temp = __uint_as_float(params_dev[0]);
+    top_k = (int)params_dev[1];
+    seed = (uint64_t)params_dev[2] | ((uint64_t)params_dev[3] << 32);
+  }
+  const int counter = pos_dev ? *pos_dev : pos_arg;
+  const bool greedy = !(inv_temp > 0.f);
+  for (int i = tid; i < nv; i += 256) {
+    float v = bf2f(z[(int64_t)b * ldz + i]);
+    if (bias) v += bf2f(bias[i]);
+    if (!greedy) v *= inv_temp;
+    keys[i] = order_key(v);
+  }
+  __syncthreads();
+  unsigned thr = 0u;
+  if (!greedy && top_k > 0 && top_k < nv) {
+    for (int bit = 31; bit >= 0; --bit) {
+      const unsigned cand = thr | (1u << bit);
+      int c = 0;
+      for (int i = tid; i < nv; i += 256) c += keys[i] >= cand;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+      if (lane == 0) cnt[wid] = c;
+      __syncthreads();
+      const int total = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+      __syncthreads();
+      if (total >= top_k) thr = cand;   // block-uniform
+    }
+  }
+  const uint64_t stream_key = splitmix64(seed ^ ((uint64_t)(unsigned)counter * 0xD2B74407B1CE6E93ull));
+  float best = -INFINITY;
+  int besti = nv;
+  for (int i = tid; i < nv; i += 256) {   // ascending i per thread: strict > keeps the first maximum
+    const unsigned k = keys[i];
+    if (k < thr) continue;
+    float s = key_value(k);
+    if (!greedy) {
+      const uint64_t h = splitmix64(stream_key + (((uint64_t)(unsigned)b << 32) | (unsigned)i));
+      const float u = ((float)(unsigned)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+      s -= __logf(-__logf(u));
+    }
+    if (s > best) { best = s; besti = i; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(besti, o, 64);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  }
+  if (lane == 0) { bval[wid] = best; bidx[wid] = besti; }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (bval[w] > best || (bval[w] == best && bidx[w] < besti)) { best = bval[w]; besti = bidx[w]; }
+    if (besti >= nv) besti = 0;          // all-NaN row: defined output
+    if (next_tok) next_tok[b] = token_offset + besti;
+    const int col = counter - out_col0;
+    if (out && col >= 0 && col < out_ld) out[(int64_t)b * out_ld + col] = besti;
+  }
+}
+extern "C" int dmi_sample_tokens(const uint16_t* z, int ldz, const uint16_t* bias, int B, int nv, float temperature, int top_k,
+                                 uint64_t seed, const uint32_t* params_dev, int pos, const int* pos_dev, int token_offset,
+                                 int32_t* next_tok, int32_t* out, int out_ld, int out_col0, void* stream) {
+  DMI_REQUIRE(z && (next_tok || out), "sample_tokens: null pointer");
+  DMI_REQUIRE(B > 0 && nv > 0 && nv <= SAMPLE_MAX_VOCAB && ldz >= nv, "sample_tokens: need 0 < nv <= %d (nv=%d)", SAMPLE_MAX_VOCAB, nv);
+  DMI_REQUIRE(!out || out_ld > 0, "sample_tokens: out_ld");
+  const float inv_temp = temperature > 0.f ? 1.f / temperature : 0.f;
+  sample_tokens_kernel<<<dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream>>>(z, ldz, bias, nv, inv_temp, top_k, seed, params_dev, pos, pos_dev,
+                                                                                token_offset, next_tok, out, out_ld, out_col0);
+  DMI_CHECK_LAUNCH("sample_tokens");
+  return DMI_OK;
+}

@@ -84,6 +84,7 @@ def _declare(L):
         "dmi_cross_entropy": (I, [P, I, P, P, P, L64, I, F, P]),
         "dmi_sum_f32": (I, [P, L64, F, P, P]),
         "dmi_assemble_tokens": (I, [P, P, P, I, I, I, I, I, P]),
+        "dmi_sample_tokens": (I, [P, I, P, I, I, F, I, ctypes.c_uint64, P, I, P, I, P, P, I, I, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
         "dmi_sumsq": (I, [P, L64, P, P, P]),
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P, P]),
@@ -341,6 +342,21 @@ def sum_f32(x, n, scale, out):
 def assemble_tokens(text, vae_logits, tokens_out, B, T, P, C, text_vocab):
     _dev(text, vae_logits, tokens_out)
     _check(lib().dmi_assemble_tokens(_p(text), _p(vae_logits), _p(tokens_out), B, T, P, C, text_vocab, _stream()), "assemble_tokens")
+
+
+def sample_tokens(z, ldz, bias, B, nv, temperature=1.0, top_k=0, seed=0, pos=0, token_offset=0, next_tok=None, out=None,
+                  out_col0=0, params_dev=None, pos_dev=None):
+    """next image token per row of head logits z bf16 [B, ldz] (+ bias bf16 [nv]): temperature / top-k / greedy; the draw is
+    a pure function of (seed, position, row).  params_dev (uint32 [4]) / pos_dev (int32 [1]) override the by-value settings."""
+    _dev(z)
+    assert z.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.bfloat16)
+    for t in (bias, next_tok, out, params_dev, pos_dev):
+        if t is not None:
+            _dev(t)
+    out_ld = int(out.shape[1]) if out is not None else 0
+    _check(lib().dmi_sample_tokens(_p(z), ldz, _p(bias), B, nv, float(temperature), int(top_k), int(seed) & (2 ** 64 - 1),
+                                   _p(params_dev), int(pos), _p(pos_dev), int(token_offset), _p(next_tok), _p(out), out_ld,
+                                   int(out_col0), _stream()), "sample_tokens")
 
 
 def sumsq_workspace_bytes(n):

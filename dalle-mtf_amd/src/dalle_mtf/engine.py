@@ -364,7 +364,7 @@ class DalleEngine:
 
     # ------------------------------------------------------------------ sampling
     def sample_image_tokens(self, text: torch.Tensor, temperature: float = 1.0, top_k: int = 0, seed: int = 0,
-                            kv_cache: bool = True, decode_graph: bool = True) -> torch.Tensor:
+                            kv_cache: bool = True, decode_graph: bool = True, fused_sampling: bool = True) -> torch.Tensor:
         """Autoregressive image-token sampling: text int32 [B, T] -> image-token ids [B, P] in [0, image_vocab_size).
         The reference scaffolds this (is_incremental_inference, models.py:246-254,281-285) but its predict path raises
         NotImplementedError (model_fns.py:135-136).  Logits are restricted to the image vocabulary; temperature / top-k /
@@ -375,6 +375,10 @@ class DalleEngine:
         decode_step(): QKV GEMM writing row `pos` of the cache in place, dmi_attention_decode (one query against keys
         0..pos), out-projection, MLP -- ~90 launches of a few microseconds instead of a 1280-position forward, replayed as
         one HIP graph (decode_graph; see decode_step).
+        fused_sampling (with kv_cache and decode_graph): the draw itself is a kernel at the end of the replayed graph
+        (dmi_sample_tokens: temperature / top-k / Gumbel-max categorical draw, noise a pure function of (seed, position, row))
+        that writes the chosen token where the next step's embedding reads it -- P graph replays back to back, no host round
+        trip per position.  fused_sampling=False draws with torch ops on the host-visible logits (torch.multinomial stream).
         kv_cache=False: the plain form, one full evaluation forward per generated position (the causal mask makes the
         not-yet-generated tail irrelevant); kept as the cross-check the cached path is tested against."""
         B, T, S, P = self.B, self.T, self.S, self.S - self.T
@@ -385,6 +389,18 @@ class DalleEngine:
         gen = torch.Generator(device=self.dev).manual_seed(seed)
         if kv_cache and self.recompute:
             kv_cache = False     # recompute_grad keeps ONE shared set of projection buffers: there is no per-layer cache to decode from
+        if kv_cache and decode_graph and fused_sampling and self.image_vocab_size <= 8192:
+            self.forward(toks, need_grad=False)          # prefill: k, v of the text positions are in the cache
+            D = self._decode_state()
+            D["tok"].copy_(toks[:, T - 1])
+            D["pos_i"].fill_(T - 1)
+            D["pos_l"].fill_(T - 1)
+            inv_t = np.array([1.0 / temperature if temperature > 0 else 0.0], dtype=np.float32).view(np.uint32)[0]
+            prm = np.array([inv_t, int(top_k), seed & 0xffffffff, (seed >> 32) & 0xffffffff], dtype=np.uint32).view(np.int32)
+            D["params"].copy_(torch.from_numpy(prm))
+            for _ in range(P):                           # position T-1+i predicts image token i; the graph advances the position itself
+                self._run_decode(sample=True, graph=True)
+            return D["out"].clone()
 
         def pick(z):
             if temperature <= 0:
@@ -396,13 +412,35 @@ class DalleEngine:
             return torch.multinomial(torch.softmax(z, -1), 1, generator=gen).squeeze(-1)
 
         for pos in range(P):
-            if not kv_cache or pos == 0:      # (prefill: the full forward also leaves k, v of positions < T in the cache)
+            if not kv_cache:
                 self.forward(toks, need_grad=False)
                 z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi].float()   # the position before predicts token T + pos
             else:
+                if pos == 0:
+                    self.forward(toks, need_grad=False)    # prefill: leaves k, v of the text positions in the cache
+                # (position T - 1 is decoded again rather than read from the prefill's logits: every cached path then takes
+                # every token through the same arithmetic)
                 z = self.decode_step(toks[:, T + pos - 1].contiguous(), T + pos - 1, graph=decode_graph)
             toks[:, T + pos] = (pick(z) + lo).to(torch.int32)
         return (toks[:, T:] - lo).contiguous()
+
+    def _decode_state(self):
+        if getattr(self, "_dec", None) is None:
+            B, d = self.B, self.d
+            b16 = dict(dtype=torch.bfloat16, device=self.dev)
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            i32 = dict(dtype=torch.int32, device=self.dev)
+            wpe = self._w("positional_embedding/wpe")
+            self._dec = dict(x=[torch.empty(B, d, **b16) for _ in range(2)], xn=torch.empty(B, d, **b16), o=torch.empty(B, d, **b16),
+                             h=torch.empty(B, 4 * d, **b16), st=[torch.empty(B, **f32) for _ in range(2)],
+                             z=torch.empty(B, self.image_vocab_size, **b16), fresh=torch.empty(B, 3 * d, **b16),
+                             tok=torch.empty(B, **i32), pos_i=torch.zeros(1, **i32),
+                             pos_l=torch.zeros(1, dtype=torch.int64, device=self.dev),
+                             wpe_row=torch.empty(1, d, dtype=wpe.dtype, device=self.dev),
+                             logits=torch.empty(B, self.image_vocab_size, **f32),
+                             params=torch.zeros(4, **i32), out=torch.zeros(B, self.S - self.T, **i32),
+                             graphs={}, warm=set())
+        return self._dec
 
     def decode_step(self, tokens_at_pos: torch.Tensor, pos: int, graph: bool = True) -> torch.Tensor:
         """Incremental inference (reference hooks src/dalle_mtf/models.py:246-254,281-285): the hidden state of sequence
@@ -415,41 +453,35 @@ class DalleEngine:
         is a by-value kernel argument: the position lives in device memory (the positional-embedding row is gathered by it,
         dmi_attention_decode reads it as pos_dev), and the QKV GEMM writes a fixed staging buffer that the attention kernel
         moves into cache row pos.  graph=False runs the same launches eagerly (the cross-check)."""
-        B, d, L, H, S = self.B, self.d, self.L, self.H, self.S
+        B, S = self.B, self.S
         assert tokens_at_pos.shape == (B,) and tokens_at_pos.dtype == torch.int32 and 0 <= pos < S
-        if getattr(self, "_dec", None) is None:
-            b16 = dict(dtype=torch.bfloat16, device=self.dev)
-            f32 = dict(dtype=torch.float32, device=self.dev)
-            wpe = self._w("positional_embedding/wpe")
-            self._dec = dict(x=[torch.empty(B, d, **b16) for _ in range(2)], xn=torch.empty(B, d, **b16), o=torch.empty(B, d, **b16),
-                             h=torch.empty(B, 4 * d, **b16), st=[torch.empty(B, **f32) for _ in range(2)],
-                             z=torch.empty(B, self.image_vocab_size, **b16), fresh=torch.empty(B, 3 * d, **b16),
-                             tok=torch.empty(B, dtype=torch.int32, device=self.dev),
-                             pos_i=torch.zeros(1, dtype=torch.int32, device=self.dev),
-                             pos_l=torch.zeros(1, dtype=torch.int64, device=self.dev),
-                             wpe_row=torch.empty(1, d, dtype=wpe.dtype, device=self.dev),
-                             logits=torch.empty(B, self.image_vocab_size, **f32), graph=None, warm=False)
-        D = self._dec
+        D = self._decode_state()
         D["tok"].copy_(tokens_at_pos)
         D["pos_i"].fill_(pos)
         D["pos_l"].fill_(pos)
-        if not graph:
-            self._decode_body()
-        elif D["graph"] is None and not D["warm"]:
-            self._decode_body()            # first step eager: lazily created views / copies come into being outside the capture
-            D["warm"] = True
-        else:
-            if D["graph"] is None:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._decode_body()
-                D["graph"] = g             # (capture records, it does not execute: the replay below is the step)
-            D["graph"].replay()
+        self._run_decode(sample=False, graph=graph)
         return D["logits"]
 
-    def _decode_body(self):
-        """the launches of one decode step; reads D[tok], D[pos_i] / D[pos_l] from device memory, writes D[logits]"""
+    def _run_decode(self, sample: bool, graph: bool):
+        D = self._dec
+        if not graph:
+            self._decode_body(sample)
+        elif sample not in D["graphs"] and sample not in D["warm"]:
+            self._decode_body(sample)      # first step eager: lazily created views / copies come into being outside the capture
+            D["warm"].add(sample)
+        else:
+            if sample not in D["graphs"]:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other host threads (input producer) stay free to call HIP
+                    self._decode_body(sample)
+                D["graphs"][sample] = g    # (capture records, it does not execute: the replay below is the step)
+            D["graphs"][sample].replay()
+
+    def _decode_body(self, sample: bool = False):
+        """the launches of one decode step; reads D[tok], D[pos_i] / D[pos_l] from device memory.  sample=False: writes
+        D[logits].  sample=True: draws the next token (settings in D[params]) into D[tok] and column pos - (T - 1) of
+        D[out], then advances the position."""
         B, d, L, H, S = self.B, self.d, self.L, self.H, self.S
         D = self._dec
         x, x1, xn, o, h, st, z, fresh = D["x"][0], D["x"][1], D["xn"], D["o"], D["h"], D["st"], D["z"], D["fresh"]
@@ -472,7 +504,14 @@ class DalleEngine:
         lo, nv = self.text_vocab_size, self.image_vocab_size
         Wt = self.tview("to_logits/linear_out/kernel")                 # [Vp, d]: rows lo .. lo + nv are the image vocabulary
         dh.gemm_nt(xn, d, Wt[lo:lo + nv], d, z, nv, B, nv, d)
-        torch.add(z.float(), self._w("to_logits/linear_out/bias")[lo:lo + nv], out=D["logits"])
+        bias = self._w("to_logits/linear_out/bias")[lo:lo + nv]
+        if sample:
+            dh.sample_tokens(z, nv, bias, B, nv, params_dev=D["params"], pos_dev=D["pos_i"], token_offset=lo,
+                             next_tok=D["tok"], out=D["out"], out_col0=self.T - 1)
+            D["pos_i"].add_(1)
+            D["pos_l"].add_(1)
+        else:
+            torch.add(z.float(), bias, out=D["logits"])
 
     # ------------------------------------------------------------------ backward
     def _gv(self, name):

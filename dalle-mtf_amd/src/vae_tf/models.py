@@ -772,7 +772,7 @@ class DiscreteVAE:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 step0 = self.global_step
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other host threads (input producer) stay free to call HIP
                     self._step_body(key)
                 self.global_step = step0          # capture records, it does not execute: the replay below is the step
                 self._graphs[key] = g

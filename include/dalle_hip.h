@@ -167,6 +167,19 @@ int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, void* stream
 int dmi_assemble_tokens(const int32_t* text, const float* vae_logits, int32_t* tokens_out,
                         int B, int T, int P, int C, int text_vocab, void* stream);
 
+/* Sampling of the next image token from head logits (the sampler around the reference's unfinished incremental-inference path,
+ * src/dalle_mtf/models.py:246-254,281-285; src/model_fns.py:135-136 raises).  Per row b of z bf16 [B, ldz] (first nv columns;
+ * bias bf16 [nv] optional, added in fp32): v = (z + bias) / temperature; top_k > 0 keeps v >= the k-th largest v (ties kept); the choice is a
+ * categorical draw from softmax(v) over the kept entries (Gumbel-max with counter-based noise hash(seed, position, b, i):
+ * reproducible, stateless); temperature <= 0: first maximum.  nv <= 8192.
+ * next_tok[b] = token_offset + choice (optional: where the next decode step reads its token);
+ * out[b, position - out_col0] = choice when that column lies in [0, out_ld) (optional).
+ * params_dev (optional, device uint32[4] = {bits of float 1/temperature (0: greedy), top_k, seed low, seed high}) and pos_dev
+ * (optional, device int32) override the by-value arguments: decode step + sampling replay as one HIP graph. */
+int dmi_sample_tokens(const uint16_t* z, int ldz, const uint16_t* bias, int B, int nv, float temperature, int top_k,
+                      uint64_t seed, const uint32_t* params_dev, int pos, const int* pos_dev, int token_offset,
+                      int32_t* next_tok, int32_t* out, int out_ld, int out_col0, void* stream);
+
 /* ---- K9  clip_by_global_norm + AdamWeightDecayOptimizer   src/optimizers.py:11-16,82-89,154-177
  * sumsq: out[0] = sum g^2 (deterministic two-stage; workspace dmi_sumsq_workspace_bytes(n)).
  * adam: mult = clip>0 ? clip/max(sqrt(*gnorm_sq),clip) : 1;  g*=mult; m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;

