@@ -943,9 +943,9 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
 // path.  Here the cache IS the forward pass's [B*S, 3d] projection buffer: the caller's QKV GEMM writes row `pos` of every
 // batch element in place (row pitch S*3d), then this kernel computes, per (batch, head),
 //     o = softmax(q_pos . K[0..pos]^T) V[0..pos]           (unscaled logits, as everywhere on this path)
-// HBM-bound (2 * (pos+1) * 256 B per head): one block per (b, h), a wave per 64-key chunk with key = lane for the scores
-// (no cross-lane reduction per key), online softmax per wave, P.V with lane = 2 output dims; the sixteen waves merge through LDS.
-// (With four waves and one value row in flight per wave the kernel was latency-bound: 46 us at B*H = 128, S = 1280.)
+// HBM-bound (2 * (pos+1) * 256 B per head): one block per (b, h), a wave per 64-key chunk, online softmax per wave, the sixteen
+// waves merge through LDS.  (History at B*H = 128, S = 1280: four waves, key = lane, one value row in flight per wave: 46 us;
+// sixteen waves, eight value rows in flight: 26 us; the row-coalesced form below: see profiles/r03_decode_kernel_stats.csv.)
 // P is rounded to bf16 before P.V and the row sum is taken over the unrounded fp32 values -- the same places where the tiled
 // forward kernel rounds -- so decode logits track full-forward logits to bf16 noise.
 //
@@ -955,9 +955,12 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
 // q | k | v into cache row `pos` for the steps to come, and reads key / value `pos` from the staging row itself (no reliance
 // on the block seeing its own global stores).
 #define DEC_WAVES 16   // 1024 threads: a (batch, head) pair streams <= S keys through ONE block, so the block must itself hold the loads in flight
+// Lane (c = lane & 15, g = lane >> 4) owns head dims [8c, 8c + 8) and, per 64-key chunk, keys 4i + g (i = 0..15): every load
+// instruction of the wave fetches four whole 256-B rows (16 B per lane) -- the first form read one row per LANE, 16 B at a time,
+// and re-fetched each 128-B line from L2 up to eight times.  The 16 partial dot products per lane are combined across the 16
+// lanes of a group by a reduce-scatter butterfly (15 exchanges): lane (c, g) ends up with the whole score of key 4c + g.
 __global__ __launch_bounds__(64 * DEC_WAVES) void attn_decode_kernel(bf16_t* qkv, const bf16_t* __restrict__ fresh, bf16_t* __restrict__ o,
                                                                      int H, int S, int pos_arg, const int* __restrict__ pos_dev) {
-  __shared__ float qs[HD];
   __shared__ float ps[DEC_WAVES][64];
   __shared__ float red_m[DEC_WAVES], red_l[DEC_WAVES];
   __shared__ float oacc[DEC_WAVES][HD];
@@ -965,66 +968,86 @@ __global__ __launch_bounds__(64 * DEC_WAVES) void attn_decode_kernel(bf16_t* qkv
   const int d = H * HD;
   const int64_t ld3 = 3 * (int64_t)d;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
   const int pos = pos_dev ? *pos_dev : pos_arg;
   if (pos < 0 || pos >= S) return;                     // (block-uniform; the host checks the by-value form)
   bf16_t* base = qkv + (int64_t)b * S * ld3 + hh * HD;
   const bf16_t* fr = fresh ? fresh + (int64_t)b * ld3 + hh * HD : nullptr;
-  if (threadIdx.x < HD) qs[threadIdx.x] = bf2f(fr ? fr[threadIdx.x] : base[(int64_t)pos * ld3 + threadIdx.x]);
-  if (fr && threadIdx.x >= HD && threadIdx.x < HD + 3 * HD / 8) {   // q | k | v of this head: 3 x 256 B -> cache row pos
-    const int t = threadIdx.x - HD, part = t / (HD / 8), ch = t % (HD / 8);
+  float q[8];
+  unpack8(*(const u32x4*)((fr ? fr : base + (int64_t)pos * ld3) + 8 * c), q);
+  if (fr && threadIdx.x < 3 * HD / 8) {   // q | k | v of this head: 3 x 256 B -> cache row pos (read back by no one in this launch)
+    const int part = threadIdx.x / (HD / 8), ch = threadIdx.x % (HD / 8);
     *(u32x4*)(base + (int64_t)pos * ld3 + part * d + ch * 8) = *(const u32x4*)(fr + part * d + ch * 8);
   }
-  __syncthreads();
-  float m = -1e30f, l = 0.f, o0 = 0.f, o1 = 0.f;
-  for (int c = wid; c * 64 <= pos; c += DEC_WAVES) {
-    const int key = c * 64 + lane;
-    const bool valid = key <= pos;
-    float s = 0.f;
-    if (valid) {
-      const u32x4* kr = (const u32x4*)((fr && key == pos) ? fr + d : base + d + (int64_t)key * ld3);
-      u32x4 kv[HD / 8];
+  float m = -1e30f, l = 0.f;
+  float oa[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int ch0 = wid; ch0 * 64 <= pos; ch0 += DEC_WAVES) {
+    const int k0 = ch0 * 64;
+    auto row_ptr = [&](int i, int which) -> const u32x4* {   // key k0 + 4i + g, clamped to pos; row pos comes from the staging buffer
+      int key = k0 + 4 * i + g;
+      key = key < pos ? key : pos;
+      return (const u32x4*)((fr && key == pos) ? fr + which * d + 8 * c : base + which * d + (int64_t)key * ld3 + 8 * c);
+    };
+    u32x4 raw[16];
 #pragma unroll
-      for (int i = 0; i < HD / 8; ++i) kv[i] = kr[i];    // the whole 256-B row requested before the first use
+    for (int i = 0; i < 16; ++i) raw[i] = *row_ptr(i, 1);
+    float p[16];
 #pragma unroll
-      for (int i = 0; i < HD / 8; ++i) {
-        float f[8];
-        unpack8(kv[i], f);
+    for (int i = 0; i < 16; ++i) {
+      float f[8];
+      unpack8(raw[i], f);
+      float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s = __builtin_fmaf(f[j], qs[8 * i + j], s);
+      for (int j = 0; j < 8; ++j) t = __builtin_fmaf(f[j], q[j], t);
+      p[i] = t;
+    }
+    // reduce-scatter over the 16 lanes of a group: after the stage with mask w, a lane keeps the half of its values whose
+    // index has bit w equal to its own bit w of c
+#pragma unroll
+    for (int w = 8; w >= 1; w >>= 1) {
+      const bool up = (c & w) != 0;
+#pragma unroll
+      for (int j = 0; j < w; ++j) {
+        const float send = up ? p[j] : p[j + w];
+        const float keep = up ? p[j + w] : p[j];
+        p[j] = keep + __shfl_xor(send, w, 64);
       }
     }
-    s = valid ? s : -1e30f;
-    const float mn = fmaxf(m, wave_max(s));
+#pragma unroll
+    for (int i = 0; i < 16; ++i) raw[i] = *row_ptr(i, 2);     // value rows requested before the softmax' wave reductions
+    const int key = k0 + 4 * c + g;
+    const bool valid = key <= pos;
+    const float sc = valid ? p[0] : -1e30f;
+    const float mn = fmaxf(m, wave_max(sc));
     const float alpha = __expf(m - mn);
-    const float p = valid ? __expf(s - mn) : 0.f;
-    l = l * alpha + wave_sum(p);
-    o0 *= alpha;
-    o1 *= alpha;
+    const float pe = valid ? __expf(sc - mn) : 0.f;
+    l = l * alpha + wave_sum(pe);
     m = mn;
-    ps[wid][lane] = bf2f(f2bf(p));
+    ps[wid][4 * c + g] = bf2f(f2bf(pe));
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: in-order LDS, no block barrier needed
-    const int nk = (pos - c * 64 + 1 < 64) ? pos - c * 64 + 1 : 64;
-    const bf16_t* vr = base + 2 * d + (int64_t)(c * 64) * ld3 + 2 * lane;
-    for (int j0 = 0; j0 < nk; j0 += 8) {                  // eight value rows in flight per wave; rows past nk: clamped, p = 0
-      unsigned vv[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int j = (j0 + u < nk) ? j0 + u : nk - 1;
-        vv[u] = *(const unsigned*)((fr && c * 64 + j == pos) ? fr + 2 * d + 2 * lane : vr + (int64_t)j * ld3);
-      }
+    for (int j = 0; j < 8; ++j) oa[j] *= alpha;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const float pj = ps[wid][j0 + u];                 // (j0 + u <= 63; entries >= nk hold 0)
-        o0 = __builtin_fmaf(pj, __uint_as_float(vv[u] << 16), o0);
-        o1 = __builtin_fmaf(pj, __uint_as_float(vv[u] & 0xffff0000u), o1);
-      }
+    for (int i = 0; i < 16; ++i) {
+      float f[8];
+      unpack8(raw[i], f);
+      const float pj = ps[wid][4 * i + g];               // 0 for keys past pos (their rows were clamped to row pos)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) oa[j] = __builtin_fmaf(pj, f[j], oa[j]);
     }
     __builtin_amdgcn_wave_barrier();
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                          // the four lane groups hold disjoint key subsets of the same dims
+    oa[j] += __shfl_xor(oa[j], 16, 64);
+    oa[j] += __shfl_xor(oa[j], 32, 64);
+  }
   if (lane == 0) { red_m[wid] = m; red_l[wid] = l; }
-  oacc[wid][2 * lane] = o0;
-  oacc[wid][2 * lane + 1] = o1;
+  if (g == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) oacc[wid][8 * c + j] = oa[j];
+  }
   __syncthreads();
   if (wid == 0) {
     float M = red_m[0];

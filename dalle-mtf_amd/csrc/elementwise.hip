@@ -21,13 +21,13 @@ extern "C" int dmi_version(void) { return 100; }
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ tokens,
                                                         const bf16_t* __restrict__ wte,
                                                         const bf16_t* __restrict__ wpe, bf16_t* __restrict__ x,
-                                                        int64_t rows, int S, int d, int vocab) {
+                                                        int64_t rows, int S, int d, int vocab, const int* __restrict__ pos_dev) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wid;
   if (row >= rows) return;
   int tok = tokens[row];
   tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-  const int s = (int)(row % S);
+  const int s = pos_dev ? *pos_dev : (int)(row % S);   // pos_dev: the decode step -- every row sits at that one position
   const u32x4* a = (const u32x4*)(wte + (int64_t)tok * d);
   const u32x4* p = (const u32x4*)(wpe + (int64_t)s * d);
   u32x4* o = (u32x4*)(x + row * d);
@@ -42,10 +42,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
 }
 
 extern "C" int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
-                             int64_t rows, int S, int d, int vocab, void* stream) {
+                             int64_t rows, int S, int d, int vocab, const int* pos_dev, void* stream) {
   DMI_REQUIRE(tokens && wte && wpe && x, "embed_fwd: null pointer");
   DMI_REQUIRE(d % 8 == 0 && rows > 0 && S > 0, "embed_fwd: d %% 8 != 0 or empty (d=%d rows=%lld)", d, (long long)rows);
-  embed_fwd_kernel<<<dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream>>>(tokens, wte, wpe, x, rows, S, d, vocab);
+  embed_fwd_kernel<<<dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, (hipStream_t)stream>>>(tokens, wte, wpe, x, rows, S, d, vocab, pos_dev);
   DMI_CHECK_LAUNCH("embed_fwd");
   return DMI_OK;
 }
@@ -1282,7 +1282,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
 #define SAMPLE_MAX_VOCAB 8192
 __global__ __launch_bounds__(256) void sample_tokens_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ bias, int nv,
                                                             float inv_temp, int top_k, uint64_t seed, const unsigned* __restrict__ params_dev,
-                                                            int pos_arg, const int* __restrict__ pos_dev, int token_offset,
+                                                            int pos_arg, int* pos_dev, int advance, int token_offset,
                                                             int* __restrict__ next_tok, int* __restrict__ out, int out_ld, int out_col0) {
   __shared__ unsigned keys[SAMPLE_MAX_VOCAB];
   __shared__ int cnt[4];
@@ -1348,17 +1348,25 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const bf16_t* __rest
     if (next_tok) next_tok[b] = token_offset + besti;
     const int col = counter - out_col0;
     if (out && col >= 0 && col < out_ld) out[(int64_t)b * out_ld + col] = besti;
+    if (advance && pos_dev) {            // the last block to finish moves the position on (every block has read it by then)
+      __threadfence();
+      if (atomicAdd(pos_dev + 1, 1) == (int)gridDim.x - 1) {
+        pos_dev[1] = 0;
+        pos_dev[0] = counter + 1;
+      }
+    }
   }
 }
 extern "C" int dmi_sample_tokens(const uint16_t* z, int ldz, const uint16_t* bias, int B, int nv, float temperature, int top_k,
-                                 uint64_t seed, const uint32_t* params_dev, int pos, const int* pos_dev, int token_offset,
+                                 uint64_t seed, const uint32_t* params_dev, int pos, int32_t* pos_dev, int advance, int token_offset,
                                  int32_t* next_tok, int32_t* out, int out_ld, int out_col0, void* stream) {
   DMI_REQUIRE(z && (next_tok || out), "sample_tokens: null pointer");
   DMI_REQUIRE(B > 0 && nv > 0 && nv <= SAMPLE_MAX_VOCAB && ldz >= nv, "sample_tokens: need 0 < nv <= %d (nv=%d)", SAMPLE_MAX_VOCAB, nv);
   DMI_REQUIRE(!out || out_ld > 0, "sample_tokens: out_ld");
+  DMI_REQUIRE(!advance || pos_dev, "sample_tokens: advance needs pos_dev");
   const float inv_temp = temperature > 0.f ? 1.f / temperature : 0.f;
   sample_tokens_kernel<<<dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream>>>(z, ldz, bias, nv, inv_temp, top_k, seed, params_dev, pos, pos_dev,
-                                                                                token_offset, next_tok, out, out_ld, out_col0);
+                                                                                advance, token_offset, next_tok, out, out_ld, out_col0);
   DMI_CHECK_LAUNCH("sample_tokens");
   return DMI_OK;
 }

@@ -647,6 +647,111 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_nt_skinny_kernel(const Gem
   }
 }
 
+// LayerNorm fused into the skinny product (decode step: layer_norm + dense, reference src/dalle_mtf/models.py:373-389 feeding
+// :242-244 / :317-324 / :391-395): C[M <= 32, N] = LN(X)[M, K] . Bt[N, K]^T (+ bias, ReLU), K = the normalised width.  Every block
+// normalises the <= 32 rows itself (32 x K bf16 from L2 -- nothing next to the weight stream): the raw rows sit in the MFMA
+// operand registers, mean and centred variance are reduced across the lane groups and the eight waves (two LDS round trips, the
+// two-pass form of ln_fwd_kernel), then each operand is normalised in fp32 and rounded to bf16 exactly where the standalone
+// kernel rounds its output.  Saves one of the ~7 us dependent launches per LayerNorm of the decode step.
+#define SKLN_MAXSTEPS 4   // K <= 64 * SK_WAVES * 4 = 2048
+template <int FLAGS>
+__global__ __launch_bounds__(64 * SK_WAVES) void gemm_ln_nt_skinny_kernel(const GemmArgs a, const bf16_t* __restrict__ gamma,
+                                                                          const bf16_t* __restrict__ beta, float eps) {
+  __shared__ f32x4 red[SK_WAVES][2][64];
+  __shared__ float part[SK_WAVES][32];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int r0 = c < a.M ? c : a.M - 1, r1 = 16 + c < a.M ? 16 + c : a.M - 1;
+  const bf16_t* pa0 = a.A + (int64_t)r0 * a.lda + 16 * g;
+  const bf16_t* pa1 = a.A + (int64_t)r1 * a.lda + 16 * g;
+  const bf16_t* pb = a.B + (int64_t)(n0 + c) * a.ldb + 16 * g;
+  float x[SKLN_MAXSTEPS][2][16];   // [step][row c | row 16 + c][k = k0 + 16 g + 0..15]
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int t = 0; t < SKLN_MAXSTEPS; ++t) {
+    const int k0 = 64 * (wid + SK_WAVES * t);
+    if (k0 < a.K) {
+      unpack8(*(const u32x4*)(pa0 + k0), x[t][0]);
+      unpack8(*(const u32x4*)(pa0 + k0 + 8), x[t][0] + 8);
+      unpack8(*(const u32x4*)(pa1 + k0), x[t][1]);
+      unpack8(*(const u32x4*)(pa1 + k0 + 8), x[t][1] + 8);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { s0 += x[t][0][j]; s1 += x[t][1][j]; }
+    }
+  }
+  auto rows_total = [&](float v0, float v1, float& t0, float& t1) {   // sum over the 4 lane groups and the 8 waves, fixed order
+    v0 += __shfl_xor(v0, 16, 64); v0 += __shfl_xor(v0, 32, 64);
+    v1 += __shfl_xor(v1, 16, 64); v1 += __shfl_xor(v1, 32, 64);
+    if (g == 0) { part[wid][c] = v0; part[wid][16 + c] = v1; }
+    __syncthreads();
+    t0 = 0.f; t1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) { t0 += part[w][c]; t1 += part[w][16 + c]; }
+    __syncthreads();
+  };
+  float mu0, mu1, q0 = 0.f, q1 = 0.f;
+  rows_total(s0, s1, mu0, mu1);
+  mu0 /= (float)a.K; mu1 /= (float)a.K;
+#pragma unroll
+  for (int t = 0; t < SKLN_MAXSTEPS; ++t) {
+    if (64 * (wid + SK_WAVES * t) < a.K) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        x[t][0][j] -= mu0; q0 += x[t][0][j] * x[t][0][j];
+        x[t][1][j] -= mu1; q1 += x[t][1][j] * x[t][1][j];
+      }
+    }
+  }
+  float rs0, rs1;
+  rows_total(q0, q1, rs0, rs1);
+  rs0 = rsqrtf(rs0 / (float)a.K + eps);
+  rs1 = rsqrtf(rs1 / (float)a.K + eps);
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < SKLN_MAXSTEPS; ++t) {
+    const int k0 = 64 * (wid + SK_WAVES * t);
+    if (k0 < a.K) {
+      float fg[16], fb[16], o0[16], o1[16];
+      unpack8(*(const u32x4*)(gamma + k0 + 16 * g), fg);
+      unpack8(*(const u32x4*)(gamma + k0 + 16 * g + 8), fg + 8);
+      unpack8(*(const u32x4*)(beta + k0 + 16 * g), fb);
+      unpack8(*(const u32x4*)(beta + k0 + 16 * g + 8), fb + 8);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        o0[j] = x[t][0][j] * rs0 * fg[j] + fb[j];
+        o1[j] = x[t][1][j] * rs1 * fg[j] + fb[j];
+      }
+      const bf16x8 b0 = *(const bf16x8*)(pb + k0), b1 = *(const bf16x8*)(pb + k0 + 8);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pack8(o0)), b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pack8(o1)), b0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pack8(o0 + 8)), b1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, pack8(o1 + 8)), b1, acc1, 0, 0, 0);
+    }
+  }
+  red[wid][0][lane] = acc0;
+  red[wid][1][lane] = acc1;
+  __syncthreads();
+  if (wid >= 2) return;
+  f32x4 v = red[0][wid][lane];
+#pragma unroll
+  for (int w = 1; w < SK_WAVES; ++w) {
+    const f32x4 t = red[w][wid][lane];
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  const int n = n0 + c;
+  float bias = 0.f;
+  if constexpr (FLAGS & DMI_GEMM_BIAS) bias = bf2f(a.bias[n]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = 16 * wid + 4 * g + e;
+    if (m >= a.M) continue;
+    float y = v[e] + bias;
+    if constexpr (FLAGS & DMI_GEMM_RELU) y = fmaxf(y, 0.f);
+    ((bf16_t*)a.C)[(int64_t)m * a.ldc + n] = f2bf(y);
+  }
+}
+
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
@@ -733,6 +838,34 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
       dmi_set_error("gemm_nt: unsupported flag combination %d", flags);
       return DMI_ERR_UNSUPPORTED;
   }
+}
+
+extern "C" int dmi_ln_gemm_nt(const uint16_t* X, int ldx, const uint16_t* gamma, const uint16_t* beta, float eps, const uint16_t* Bt, int ldb,
+                              uint16_t* C, int ldc, int M, int N, int K, int flags, const uint16_t* bias, void* stream) {
+  int rc = check_nt(X, ldx, Bt, ldb, C, ldc, M, N, K);
+  if (rc) return rc;
+  DMI_REQUIRE(gamma && beta, "ln_gemm_nt: null LayerNorm parameters");
+  DMI_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "ln_gemm_nt: gamma / beta must be 16-byte aligned");
+  DMI_REQUIRE(!(flags & DMI_GEMM_BIAS) || bias, "ln_gemm_nt: bias flag without pointer");
+  if (M > 32 || N % 16 != 0 || K > 64 * SK_WAVES * SKLN_MAXSTEPS) {
+    dmi_set_error("ln_gemm_nt: only the decode-step shapes (M <= 32, N %% 16 == 0, K <= %d); got M=%d N=%d K=%d", 64 * SK_WAVES * SKLN_MAXSTEPS, M, N, K);
+    return DMI_ERR_UNSUPPORTED;
+  }
+  GemmArgs a;
+  fill_nt_args(a, X, ldx, Bt, ldb, C, ldc, M, N, K);
+  a.bias = bias;
+  const dim3 grid(N / 16), blk(64 * SK_WAVES);
+  hipStream_t st = (hipStream_t)stream;
+  switch (flags) {
+    case 0: gemm_ln_nt_skinny_kernel<0><<<grid, blk, 0, st>>>(a, gamma, beta, eps); break;
+    case DMI_GEMM_BIAS: gemm_ln_nt_skinny_kernel<DMI_GEMM_BIAS><<<grid, blk, 0, st>>>(a, gamma, beta, eps); break;
+    case DMI_GEMM_BIAS | DMI_GEMM_RELU: gemm_ln_nt_skinny_kernel<DMI_GEMM_BIAS | DMI_GEMM_RELU><<<grid, blk, 0, st>>>(a, gamma, beta, eps); break;
+    default:
+      dmi_set_error("ln_gemm_nt: unsupported flag combination %d", flags);
+      return DMI_ERR_UNSUPPORTED;
+  }
+  DMI_CHECK_LAUNCH("ln_gemm_nt");
+  return DMI_OK;
 }
 
 // Vocabulary projection with the softmax numerator fused into the epilogue (reference src/dalle_mtf/models.py:391-395 feeding

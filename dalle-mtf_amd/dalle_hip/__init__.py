@@ -56,7 +56,7 @@ def _declare(L):
         "dmi_get_option": (I, [c_char_p]),
         "dmi_set_option": (I, [c_char_p, I]),
         "dmi_set_debug_buffer": (I, [P]),
-        "dmi_embed_fwd": (I, [P, P, P, P, L64, I, I, I, P]),
+        "dmi_embed_fwd": (I, [P, P, P, P, L64, I, I, I, P, P]),
         "dmi_sort_tokens_workspace_bytes": (L64, [L64]),
         "dmi_sort_tokens": (I, [P, P, P, L64, I, P, P]),
         "dmi_embed_bwd_workspace_bytes": (L64, [I, I, I]),
@@ -84,7 +84,8 @@ def _declare(L):
         "dmi_cross_entropy": (I, [P, I, P, P, P, L64, I, F, P]),
         "dmi_sum_f32": (I, [P, L64, F, P, P]),
         "dmi_assemble_tokens": (I, [P, P, P, I, I, I, I, I, P]),
-        "dmi_sample_tokens": (I, [P, I, P, I, I, F, I, ctypes.c_uint64, P, I, P, I, P, P, I, I, P]),
+        "dmi_sample_tokens": (I, [P, I, P, I, I, F, I, ctypes.c_uint64, P, I, P, I, I, P, P, I, I, P]),
+        "dmi_ln_gemm_nt": (I, [P, I, P, P, F, P, I, P, I, I, I, I, I, P, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
         "dmi_sumsq": (I, [P, L64, P, P, P]),
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P, P]),
@@ -156,9 +157,9 @@ def get_option(name: str) -> int:
 
 # ------------------------------------------------------------------ wrappers (torch tensors in/out)
 
-def embed_fwd(tokens, wte, wpe, x, S, d, vocab):
+def embed_fwd(tokens, wte, wpe, x, S, d, vocab, pos_dev=None):
     _dev(tokens, wte, wpe, x)
-    _check(lib().dmi_embed_fwd(_p(tokens), _p(wte), _p(wpe), _p(x), tokens.numel(), S, d, vocab, _stream()), "embed_fwd")
+    _check(lib().dmi_embed_fwd(_p(tokens), _p(wte), _p(wpe), _p(x), tokens.numel(), S, d, vocab, _p(pos_dev), _stream()), "embed_fwd")
 
 
 def sort_tokens_workspace_bytes(n):
@@ -200,6 +201,13 @@ def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None,
     _dev(A, Bt, C)
     _check(lib().dmi_gemm_nt(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _p(residual),
                              _p(relu_src), _p(rowscale), _stream()), "gemm_nt")
+
+
+def ln_gemm_nt(X, ldx, gamma, beta, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, eps=1e-5):
+    """C = LayerNorm(X) . Bt^T (+ bias)(ReLU) for the decode step (M <= 32)"""
+    _dev(X, gamma, beta, Bt, C)
+    _check(lib().dmi_ln_gemm_nt(_p(X), ldx, _p(gamma), _p(beta), eps, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _stream()),
+           "ln_gemm_nt")
 
 
 def attention_decode(qkv, o, B, H, S, pos, fresh=None, pos_dev=None):
@@ -345,7 +353,7 @@ def assemble_tokens(text, vae_logits, tokens_out, B, T, P, C, text_vocab):
 
 
 def sample_tokens(z, ldz, bias, B, nv, temperature=1.0, top_k=0, seed=0, pos=0, token_offset=0, next_tok=None, out=None,
-                  out_col0=0, params_dev=None, pos_dev=None):
+                  out_col0=0, params_dev=None, pos_dev=None, advance=False):
     """next image token per row of head logits z bf16 [B, ldz] (+ bias bf16 [nv]): temperature / top-k / greedy; the draw is
     a pure function of (seed, position, row).  params_dev (uint32 [4]) / pos_dev (int32 [1]) override the by-value settings."""
     _dev(z)
@@ -355,7 +363,7 @@ def sample_tokens(z, ldz, bias, B, nv, temperature=1.0, top_k=0, seed=0, pos=0, 
             _dev(t)
     out_ld = int(out.shape[1]) if out is not None else 0
     _check(lib().dmi_sample_tokens(_p(z), ldz, _p(bias), B, nv, float(temperature), int(top_k), int(seed) & (2 ** 64 - 1),
-                                   _p(params_dev), int(pos), _p(pos_dev), int(token_offset), _p(next_tok), _p(out), out_ld,
+                                   _p(params_dev), int(pos), _p(pos_dev), int(bool(advance)), int(token_offset), _p(next_tok), _p(out), out_ld,
                                    int(out_col0), _stream()), "sample_tokens")
 
 

@@ -393,8 +393,7 @@ class DalleEngine:
             self.forward(toks, need_grad=False)          # prefill: k, v of the text positions are in the cache
             D = self._decode_state()
             D["tok"].copy_(toks[:, T - 1])
-            D["pos_i"].fill_(T - 1)
-            D["pos_l"].fill_(T - 1)
+            D["pos_i"][0:1].fill_(T - 1)
             inv_t = np.array([1.0 / temperature if temperature > 0 else 0.0], dtype=np.float32).view(np.uint32)[0]
             prm = np.array([inv_t, int(top_k), seed & 0xffffffff, (seed >> 32) & 0xffffffff], dtype=np.uint32).view(np.int32)
             D["params"].copy_(torch.from_numpy(prm))
@@ -430,13 +429,10 @@ class DalleEngine:
             b16 = dict(dtype=torch.bfloat16, device=self.dev)
             f32 = dict(dtype=torch.float32, device=self.dev)
             i32 = dict(dtype=torch.int32, device=self.dev)
-            wpe = self._w("positional_embedding/wpe")
             self._dec = dict(x=[torch.empty(B, d, **b16) for _ in range(2)], xn=torch.empty(B, d, **b16), o=torch.empty(B, d, **b16),
                              h=torch.empty(B, 4 * d, **b16), st=[torch.empty(B, **f32) for _ in range(2)],
                              z=torch.empty(B, self.image_vocab_size, **b16), fresh=torch.empty(B, 3 * d, **b16),
-                             tok=torch.empty(B, **i32), pos_i=torch.zeros(1, **i32),
-                             pos_l=torch.zeros(1, dtype=torch.int64, device=self.dev),
-                             wpe_row=torch.empty(1, d, dtype=wpe.dtype, device=self.dev),
+                             tok=torch.empty(B, **i32), pos_i=torch.zeros(2, **i32),    # [position, scratch counter of the sampler]
                              logits=torch.empty(B, self.image_vocab_size, **f32),
                              params=torch.zeros(4, **i32), out=torch.zeros(B, self.S - self.T, **i32),
                              graphs={}, warm=set())
@@ -450,15 +446,14 @@ class DalleEngine:
 
         graph=True: the ~90 launches of a step are a few microseconds of GPU work each, so the step is launch-bound when
         driven from the host; it is captured ONCE as a HIP graph and replayed for every position.  Nothing position-dependent
-        is a by-value kernel argument: the position lives in device memory (the positional-embedding row is gathered by it,
-        dmi_attention_decode reads it as pos_dev), and the QKV GEMM writes a fixed staging buffer that the attention kernel
+        is a by-value kernel argument: the position lives in device memory (pos_dev of dmi_embed_fwd -- the positional-embedding
+        row -- and of dmi_attention_decode), and the QKV GEMM writes a fixed staging buffer that the attention kernel
         moves into cache row pos.  graph=False runs the same launches eagerly (the cross-check)."""
         B, S = self.B, self.S
         assert tokens_at_pos.shape == (B,) and tokens_at_pos.dtype == torch.int32 and 0 <= pos < S
         D = self._decode_state()
         D["tok"].copy_(tokens_at_pos)
-        D["pos_i"].fill_(pos)
-        D["pos_l"].fill_(pos)
+        D["pos_i"][0:1].fill_(pos)
         self._run_decode(sample=False, graph=graph)
         return D["logits"]
 
@@ -479,37 +474,44 @@ class DalleEngine:
             D["graphs"][sample].replay()
 
     def _decode_body(self, sample: bool = False):
-        """the launches of one decode step; reads D[tok], D[pos_i] / D[pos_l] from device memory.  sample=False: writes
+        """the launches of one decode step; reads D[tok] and the position D[pos_i][0] from device memory.  sample=False: writes
         D[logits].  sample=True: draws the next token (settings in D[params]) into D[tok] and column pos - (T - 1) of
-        D[out], then advances the position."""
+        D[out], then advances the position (inside the sampling kernel).
+        B <= 32: LayerNorm rides in the prologue of the product that consumes it (dmi_ln_gemm_nt) -- 5 dependent launches per
+        block instead of 7; a dependent launch costs ~7 us on this part, more than any of these kernels' work."""
         B, d, L, H, S = self.B, self.d, self.L, self.H, self.S
         D = self._dec
         x, x1, xn, o, h, st, z, fresh = D["x"][0], D["x"][1], D["xn"], D["o"], D["h"], D["st"], D["z"], D["fresh"]
-        torch.index_select(self._w("positional_embedding/wpe"), 0, D["pos_l"], out=D["wpe_row"])
-        dh.embed_fwd(D["tok"], self._w("embedding/wte"), D["wpe_row"], x, 1, d, self.V)   # every row takes wpe[pos]
+        fuse_ln = B <= 32 and d <= 2048 and self.image_vocab_size % 16 == 0 and self.hp.get("decode_fuse_ln", True)
+
+        def ln_dense(inp, ln, W, out, N, flags=0, bias=None):       # out = LN(inp) . W^T (+ bias)(ReLU)
+            g, b = self._w(ln + "/g"), self._w(ln + "/b")
+            if fuse_ln:
+                dh.ln_gemm_nt(inp, d, g, b, W, d, out, N, B, N, d, flags, bias=bias)
+            else:
+                dh.layernorm_fwd(inp, g, b, xn, st[0], st[1], B, d)
+                dh.gemm_nt(xn, d, W, d, out, N, B, N, d, flags, bias=bias)
+
+        dh.embed_fwd(D["tok"], self._w("embedding/wte"), self._w("positional_embedding/wpe"), x, 1, d, self.V,
+                     pos_dev=D["pos_i"])                                  # every row takes wpe[pos]
         for l in range(L):
             p = f"layer_{l}/"
             cache = self.qkv[l]                                        # [B*S, 3d]; row b*S + pos <- q | k | v of this step
-            dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), xn, st[0], st[1], B, d)
-            dh.gemm_nt(xn, d, self.tview(p + "attn/qkv"), d, fresh, 3 * d, B, 3 * d, d)
+            ln_dense(x, p + "norm_1", self.tview(p + "attn/qkv"), fresh, 3 * d)
             dh.attention_decode(cache, o, B, H, S, 0, fresh=fresh, pos_dev=D["pos_i"])
             dh.gemm_nt(o, d, self.tview(p + "attn/o"), d, x1, d, B, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
                        bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
-            dh.layernorm_fwd(x1, self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), xn, st[0], st[1], B, d)
-            dh.gemm_nt(xn, d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, h, 4 * d, B, 4 * d, d, dh.GEMM_BIAS | dh.GEMM_RELU,
-                       bias=self._w(p + "mlp/mlp_linear_1/bias"))
+            ln_dense(x1, p + "norm_2", self.tview(p + "mlp/mlp_linear_1/kernel"), h, 4 * d, dh.GEMM_BIAS | dh.GEMM_RELU,
+                     bias=self._w(p + "mlp/mlp_linear_1/bias"))
             dh.gemm_nt(h, 4 * d, self.tview(p + "mlp/mlp_linear_2/kernel"), 4 * d, x, d, B, d, 4 * d,
                        dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=x1)
-        dh.layernorm_fwd(x, self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), xn, st[0], st[1], B, d)
         lo, nv = self.text_vocab_size, self.image_vocab_size
         Wt = self.tview("to_logits/linear_out/kernel")                 # [Vp, d]: rows lo .. lo + nv are the image vocabulary
-        dh.gemm_nt(xn, d, Wt[lo:lo + nv], d, z, nv, B, nv, d)
+        ln_dense(x, "to_logits/layer_norm", Wt[lo:lo + nv], z, nv)
         bias = self._w("to_logits/linear_out/bias")[lo:lo + nv]
         if sample:
-            dh.sample_tokens(z, nv, bias, B, nv, params_dev=D["params"], pos_dev=D["pos_i"], token_offset=lo,
+            dh.sample_tokens(z, nv, bias, B, nv, params_dev=D["params"], pos_dev=D["pos_i"], advance=True, token_offset=lo,
                              next_tok=D["tok"], out=D["out"], out_col0=self.T - 1)
-            D["pos_i"].add_(1)
-            D["pos_l"].add_(1)
         else:
             torch.add(z.float(), bias, out=D["logits"])
 

@@ -41,8 +41,10 @@ int dmi_set_option(const char* name, int value);
 int dmi_set_debug_buffer(void* device_buffer);
 
 /* ---- K1  embedding: mtf.gather(wte, tokens) + wpe[0..S)   src/dalle_mtf/models.py:186-219 ---- */
+/* pos_dev (optional, device int32): every row takes wpe[*pos_dev] instead of wpe[row % S] -- the incremental decode step, whose
+ * position must not be a by-value argument of a replayed HIP graph. */
 int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
-                  int64_t rows /*B*S*/, int S, int d, int vocab, void* stream);
+                  int64_t rows /*B*S*/, int S, int d, int vocab, const int* pos_dev, void* stream);
 /* stable sort of the n token ids (clamped to [0, vocab)): sorted_tokens ascending, perm[i] = source position of sorted
  * position i.  Index plumbing for dmi_embed_bwd; one-block radix sort, deterministic.
  * workspace: dmi_sort_tokens_workspace_bytes(n). */
@@ -81,6 +83,11 @@ int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, 
 int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc,
                 int M, int N, int K, int flags, const uint16_t* bias, const uint16_t* residual,
                 const uint16_t* relu_src, const float* rowscale, void* stream);
+/* LayerNorm (eps, biased variance: K2) fused into the product, for the incremental decode step only (M <= 32 rows, N % 16 == 0,
+ * K = the normalised width <= 2048; anything else -> DMI_ERR_UNSUPPORTED): C = LN(X; gamma, beta) . Bt^T (+ bias bf16 [N])(ReLU).
+ * flags: 0, BIAS, BIAS|RELU.  LN(X) is rounded to bf16 before the product, as dmi_layernorm_fwd + dmi_gemm_nt would. */
+int dmi_ln_gemm_nt(const uint16_t* X, int ldx, const uint16_t* gamma, const uint16_t* beta, float eps, const uint16_t* Bt, int ldb,
+                   uint16_t* C, int ldc, int M, int N, int K, int flags, const uint16_t* bias, void* stream);
 /* same product with the K range split over nsplit block groups (fp32 slabs in workspace, deterministic reduction to
  * bf16 C with ldc == N, optionally times rowscale[m]): for long-K GEMMs whose tile count does not fill whole
  * residencies (the head's input gradient: K = vocabulary). */
@@ -175,9 +182,10 @@ int dmi_assemble_tokens(const int32_t* text, const float* vae_logits, int32_t* t
  * next_tok[b] = token_offset + choice (optional: where the next decode step reads its token);
  * out[b, position - out_col0] = choice when that column lies in [0, out_ld) (optional).
  * params_dev (optional, device uint32[4] = {bits of float 1/temperature (0: greedy), top_k, seed low, seed high}) and pos_dev
- * (optional, device int32) override the by-value arguments: decode step + sampling replay as one HIP graph. */
+ * (optional, device int32) override the by-value arguments: decode step + sampling replay as one HIP graph.  advance != 0
+ * (needs pos_dev = device int32[2], [1] a zero-initialised scratch counter): the last block to finish stores position + 1. */
 int dmi_sample_tokens(const uint16_t* z, int ldz, const uint16_t* bias, int B, int nv, float temperature, int top_k,
-                      uint64_t seed, const uint32_t* params_dev, int pos, const int* pos_dev, int token_offset,
+                      uint64_t seed, const uint32_t* params_dev, int pos, int32_t* pos_dev, int advance, int token_offset,
                       int32_t* next_tok, int32_t* out, int out_ld, int out_col0, void* stream);
 
 /* ---- K9  clip_by_global_norm + AdamWeightDecayOptimizer   src/optimizers.py:11-16,82-89,154-177

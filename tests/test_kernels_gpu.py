@@ -207,6 +207,49 @@ def test_gemm_nt_skinny_rows(M, N, K, flags):
     assert float((outs[0] - outs[1]).abs().max()) <= 1.6e-2 * scale
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(32, 1536, 512, 0), (5, 2048, 512, 3), (32, 512, 128, 0), (17, 64, 2048, 1), (1, 16, 64, 3), (32, 48, 1024, 0)])
+def test_ln_gemm_nt_decode_shapes(M, N, K, flags):
+    """dmi_ln_gemm_nt (LayerNorm in the prologue of the M <= 32 product) against fp32 math with the bf16 rounding of LN's output,
+    and against the two separate kernels (dmi_layernorm_fwd + dmi_gemm_nt): same rounding points, so the results differ by
+    summation order only."""
+    X = rnd(M, K + 8, scale=2.0, seed=1) + 0.7
+    gam, bet = rnd(K, seed=2) + 1.0, rnd(K, scale=0.3, seed=3)
+    Bt, bias = rnd(N, K, scale=0.2, seed=4), rnd(N, seed=5)
+    xf = X[:, :K].float()
+    mu = xf.mean(-1, keepdim=True)
+    xn = ((xf - mu) * torch.rsqrt(((xf - mu) ** 2).mean(-1, keepdim=True) + 1e-5) * gam.float() + bet.float()).to(torch.bfloat16)
+    ref = _gemm_ref(xn, Bt, bias if flags & 1 else None, relu=bool(flags & 2))
+    Xd, Bd = X.to(DEV), Bt.to(DEV)
+    C = torch.full((M + 1, N + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    dh.ln_gemm_nt(Xd, K + 8, gam.to(DEV), bet.to(DEV), Bd, K, C, N + 16, M, N, K, flags, bias=bias.to(DEV) if flags & 1 else None)
+    close(C[:M, :N], ref, 1.6e-2, 3e-2 * math.sqrt(K / 64), "ln_gemm_nt")
+    assert bool((C[M:] == 7.0).all()) and bool((C[:, N:] == 7.0).all()), "wrote outside the [M, N] block"
+    y = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    st = [torch.empty(M, dtype=torch.float32, device=DEV) for _ in range(2)]
+    dh.layernorm_fwd(Xd[:, :K].contiguous(), gam.to(DEV), bet.to(DEV), y, st[0], st[1], M, K)
+    assert float((y.float().cpu() - xn.float()).abs().max()) <= 2e-2 * float(xn.float().abs().max())
+    C2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(y, K, Bd, K, C2, N, M, N, K, flags, bias=bias.to(DEV) if flags & 1 else None)
+    scale = float(ref.abs().max())
+    assert float((C[:M, :N].float() - C2.float()).abs().max()) <= 1.6e-2 * scale
+    with pytest.raises(dh.DalleHipError):      # not a decode-step shape: refused, not silently slow
+        dh.ln_gemm_nt(Xd, K + 8, gam.to(DEV), bet.to(DEV), Bd, K, C, N + 16, 33, N, K, 0)
+
+
+def test_embed_fwd_position_from_device_memory():
+    """pos_dev of dmi_embed_fwd: every row takes wpe[*pos_dev] (the decode step) -- equals the by-value form on a one-row table"""
+    B, d, V, S = 6, 128, 50, 40
+    toks = torch.randint(0, V, (B,), dtype=torch.int32)
+    wte, wpe = rnd(V, d, seed=1), rnd(S, d, seed=2)
+    a = torch.empty(B, d, dtype=torch.bfloat16, device=DEV)
+    b = torch.empty(B, d, dtype=torch.bfloat16, device=DEV)
+    for pos in (0, 17, S - 1):
+        dh.embed_fwd(toks.to(DEV), wte.to(DEV), wpe.to(DEV)[pos:pos + 1], a, 1, d, V)
+        dh.embed_fwd(toks.to(DEV), wte.to(DEV), wpe.to(DEV), b, 1, d, V, pos_dev=torch.tensor([pos], dtype=torch.int32, device=DEV))
+        assert torch.equal(a, b)
+        close(a, wte[toks.long()].float() + wpe[pos].float(), 1e-2, 1e-2, "embed at pos")
+
+
 @pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3),
                                          (515, 136, 64, 8), (700, 264, 128, 32)])
 def test_gemm_nt4_tile_256(M, N, K, flags):

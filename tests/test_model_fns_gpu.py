@@ -375,6 +375,12 @@ def test_sample_tokens_kernel(nv):
         assert bool(((freq - prob).abs() <= 5 * sigma + 1e-4).all()), (b, float((freq - prob).abs().max()))
     dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=T, top_k=k, seed=9, pos=3, out=o1, out_col0=3)
     assert torch.equal(o1[:, 0].cpu().long(), draws[:, 3])
+    # advance: the kernel itself moves the device-side position on (one graph replay per generated token, no host arithmetic)
+    pd = torch.tensor([0, 0], dtype=torch.int32, device="cuda")
+    seq = torch.zeros(B, 6, dtype=torch.int32, device="cuda")
+    for _ in range(6):
+        dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=T, top_k=k, seed=9, pos_dev=pd, advance=True, out=seq, out_col0=0)
+    assert pd.cpu().tolist() == [6, 0] and torch.equal(seq.cpu().long(), draws[:, :6])
 
 
 def test_reference_tf_checkpoints_load_by_variable_name(tmp_path):
