@@ -24,11 +24,13 @@
 #include <type_traits>
 
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
-static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (long K, whole residencies), 2 always (tests)
+static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (K >= nt8_min_k, whole residencies), 2 always (tests)
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn8 = 0;        // 256x256 weight-gradient tile (8 waves, still on 32x32x16 MFMAs): 0 never (default since the 128x128 kernel
                                  // moved to 16x16x32: 45 / 76 us vs 60 / 86 us on the 512x512 / 512x1536 gradients), 1 auto (few tiles), 2 always (tests)
 static int g_opt_tn8_max_tiles = 16;   // auto mode: use the 256x256 weight-gradient kernel below this many tiles (A/B hook)
+static int g_opt_nt8_min_k = 2048;   // auto mode of the 256x256 NT tile: minimum K.  2048 (was 4096): the 1.3B dimensions' K = 2048 products
+                                     // run 354 -> 339 ms/step (profiles/r03_ab_nt8_min_k.log); K = 1024 measured equal, K = 512 slower
 static int g_opt_skinny = 1;     // M <= 32 products (the decode step) on the weight-streaming kernel: 0 never, 1 auto
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static unsigned long long* g_dbg_buf = nullptr;
@@ -38,6 +40,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt8")) return g_opt_nt8;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
+  if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
   if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
@@ -48,6 +51,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
+  if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
   if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
@@ -765,7 +769,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   {
     const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
     // 256x256 tiles (one 8-wave block per CU): main-loop-bound shapes only -- long K and whole residencies of 256 blocks
-    const bool auto8 = g_opt_nt8 == 1 && a.k_per_split >= 4096 && (t8m * t8n * nsplit) % 256 == 0;
+    const bool auto8 = g_opt_nt8 == 1 && a.k_per_split >= g_opt_nt8_min_k && (t8m * t8n * nsplit) % 256 == 0;
     if (auto8 || g_opt_nt8 == 2) {
       static bool attr8 = false;
       if (!attr8) { (void)hipFuncSetAttribute((const void*)gemm_nt8_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8 = true; }

@@ -31,7 +31,7 @@ const char* dmi_last_error_string(void);
 int dmi_version(void);
 /* Test hooks (every setting computes the same results): "nt4" 0/1/2 = never / auto / always use the 256x128 NT tile,
  * "nt8" / "tn8" 0/1/2 = the 256x256 8-wave NT / weight-gradient tiles, "tn_tail" 0/1 = row-split the ragged last residency of
- * unsplit weight gradients, "skinny" 0/1 = products with M <= 32 rows (the decode step) on the weight-streaming kernel,
+ * unsplit weight gradients, "nt8_min_k" = smallest K at which the auto mode picks the 256x256 NT tile, "skinny" 0/1 = products with M <= 32 rows (the decode step) on the weight-streaming kernel,
  * "attn_xcd" = schedule of the persistent attention blocks (0: one serpentine over all blocks,
  * != 0: per-XCD item lists when the (batch, head) count divides by 8).  Unknown name -> -1. */
 int dmi_get_option(const char* name);
