@@ -27,7 +27,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int* __restrict__ 
   if (row >= rows) return;
   int tok = tokens[row];
   tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
-  const int s = pos_dev ? *pos_dev : (int)(row % S);   // pos_dev: the decode step -- every row sits at that one position
+  int s = (int)(row % S);
+  if (pos_dev) {                                        // the decode step: every row sits at that one position (clamped to the table)
+    s = *pos_dev;
+    s = s < 0 ? 0 : (s >= S ? S - 1 : s);
+  }
   const u32x4* a = (const u32x4*)(wte + (int64_t)tok * d);
   const u32x4* p = (const u32x4*)(wpe + (int64_t)s * d);
   u32x4* o = (u32x4*)(x + row * d);

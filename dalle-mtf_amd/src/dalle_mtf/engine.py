@@ -492,7 +492,7 @@ class DalleEngine:
                 dh.layernorm_fwd(inp, g, b, xn, st[0], st[1], B, d)
                 dh.gemm_nt(xn, d, W, d, out, N, B, N, d, flags, bias=bias)
 
-        dh.embed_fwd(D["tok"], self._w("embedding/wte"), self._w("positional_embedding/wpe"), x, 1, d, self.V,
+        dh.embed_fwd(D["tok"], self._w("embedding/wte"), self._w("positional_embedding/wpe"), x, S, d, self.V,
                      pos_dev=D["pos_i"])                                  # every row takes wpe[pos]
         for l in range(L):
             p = f"layer_{l}/"

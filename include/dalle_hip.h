@@ -41,8 +41,8 @@ int dmi_set_option(const char* name, int value);
 int dmi_set_debug_buffer(void* device_buffer);
 
 /* ---- K1  embedding: mtf.gather(wte, tokens) + wpe[0..S)   src/dalle_mtf/models.py:186-219 ---- */
-/* pos_dev (optional, device int32): every row takes wpe[*pos_dev] instead of wpe[row % S] -- the incremental decode step, whose
- * position must not be a by-value argument of a replayed HIP graph. */
+/* pos_dev (optional, device int32): every row takes wpe[*pos_dev] (clamped to [0, S)) instead of wpe[row % S] -- the incremental
+ * decode step, whose position must not be a by-value argument of a replayed HIP graph. */
 int dmi_embed_fwd(const int32_t* tokens, const uint16_t* wte, const uint16_t* wpe, uint16_t* x,
                   int64_t rows /*B*S*/, int S, int d, int vocab, const int* pos_dev, void* stream);
 /* stable sort of the n token ids (clamped to [0, vocab)): sorted_tokens ascending, perm[i] = source position of sorted

@@ -245,9 +245,11 @@ def test_embed_fwd_position_from_device_memory():
     b = torch.empty(B, d, dtype=torch.bfloat16, device=DEV)
     for pos in (0, 17, S - 1):
         dh.embed_fwd(toks.to(DEV), wte.to(DEV), wpe.to(DEV)[pos:pos + 1], a, 1, d, V)
-        dh.embed_fwd(toks.to(DEV), wte.to(DEV), wpe.to(DEV), b, 1, d, V, pos_dev=torch.tensor([pos], dtype=torch.int32, device=DEV))
+        dh.embed_fwd(toks.to(DEV), wte.to(DEV), wpe.to(DEV), b, S, d, V, pos_dev=torch.tensor([pos], dtype=torch.int32, device=DEV))
         assert torch.equal(a, b)
         close(a, wte[toks.long()].float() + wpe[pos].float(), 1e-2, 1e-2, "embed at pos")
+    dh.embed_fwd(toks.to(DEV), wte.to(DEV), wpe.to(DEV), b, S, d, V, pos_dev=torch.tensor([S + 5], dtype=torch.int32, device=DEV))
+    assert torch.equal(a, b)            # a position past the table is clamped to its last row, never read out of bounds
 
 
 @pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 192, 1), (4000, 2568, 128, 5), (2048, 1024, 512, 3),
