@@ -1331,7 +1331,9 @@ __global__ __launch_bounds__(256) void sample_tokens_kernel(const bf16_t* __rest
     float s = key_value(k);
     if (!greedy) {
       const uint64_t h = splitmix64(stream_key + (((uint64_t)(unsigned)b << 32) | (unsigned)i));
-      const float u = ((float)(unsigned)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1)
+      // 23 random bits so that the + 0.5 is exact in fp32: u in [2^-24, 1 - 2^-24], strictly inside (0, 1) -- with 24 bits
+      // 16777215.5 rounds to 2^24, u == 1 and the Gumbel noise -log(-log u) is +inf (the entry then wins regardless of its logit)
+      const float u = ((float)(unsigned)(h >> 41) + 0.5f) * (1.0f / 8388608.0f);
       s -= __logf(-__logf(u));
     }
     if (s > best) { best = s; besti = i; }
@@ -1372,5 +1374,22 @@ extern "C" int dmi_sample_tokens(const uint16_t* z, int ldz, const uint16_t* bia
   sample_tokens_kernel<<<dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream>>>(z, ldz, bias, nv, inv_temp, top_k, seed, params_dev, pos, pos_dev,
                                                                                 advance, token_offset, next_tok, out, out_ld, out_col0);
   DMI_CHECK_LAUNCH("sample_tokens");
+  return DMI_OK;
+}
+
+// fp32 logits of a head-output slice: out[b, i] = float(z[b, i]) + float(bias[i])  (src/dalle_mtf/models.py:394-395)
+__global__ void logits_f32_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ bias, float* __restrict__ out, int nv) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nv) return;
+  float v = bf2f(z[(int64_t)b * ldz + i]);
+  if (bias) v += bf2f(bias[i]);
+  out[(int64_t)b * nv + i] = v;
+}
+extern "C" int dmi_logits_f32(const uint16_t* z, int ldz, const uint16_t* bias, float* out, int B, int nv, void* stream) {
+  DMI_REQUIRE(z && out, "logits_f32: null pointer");
+  DMI_REQUIRE(B > 0 && nv > 0 && ldz >= nv, "logits_f32: need B > 0, 0 < nv <= ldz (B=%d nv=%d ldz=%d)", B, nv, ldz);
+  logits_f32_kernel<<<dim3((unsigned)((nv + 255) / 256), (unsigned)B), dim3(256), 0, (hipStream_t)stream>>>(z, ldz, bias, out, nv);
+  DMI_CHECK_LAUNCH("logits_f32");
   return DMI_OK;
 }

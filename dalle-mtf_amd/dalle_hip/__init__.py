@@ -86,6 +86,7 @@ def _declare(L):
         "dmi_assemble_tokens": (I, [P, P, P, I, I, I, I, I, P]),
         "dmi_sample_tokens": (I, [P, I, P, I, I, F, I, ctypes.c_uint64, P, I, P, I, I, P, P, I, I, P]),
         "dmi_ln_gemm_nt": (I, [P, I, P, P, F, P, I, P, I, I, I, I, I, P, P]),
+        "dmi_logits_f32": (I, [P, I, P, P, I, I, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
         "dmi_sumsq": (I, [P, L64, P, P, P]),
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P, P]),
@@ -355,9 +356,14 @@ def assemble_tokens(text, vae_logits, tokens_out, B, T, P, C, text_vocab):
 def sample_tokens(z, ldz, bias, B, nv, temperature=1.0, top_k=0, seed=0, pos=0, token_offset=0, next_tok=None, out=None,
                   out_col0=0, params_dev=None, pos_dev=None, advance=False):
     """next image token per row of head logits z bf16 [B, ldz] (+ bias bf16 [nv]): temperature / top-k / greedy; the draw is
-    a pure function of (seed, position, row).  params_dev (uint32 [4]) / pos_dev (int32 [1]) override the by-value settings."""
+    a pure function of (seed, position, row).  params_dev (uint32 [4]) / pos_dev (int32) override the by-value settings.
+    pos_dev is int32 [1] (the position) -- or, with advance=True, int32 [2]: [position, arrival counter]; the kernel's last
+    block to finish increments [0] and resets [1], which must be zero on entry (include/dalle_hip.h)."""
     _dev(z)
     assert z.dtype == torch.bfloat16 and (bias is None or bias.dtype == torch.bfloat16)
+    if pos_dev is not None:
+        assert pos_dev.dtype == torch.int32 and pos_dev.numel() >= (2 if advance else 1), \
+            "sample_tokens: pos_dev must be int32 [2] ([position, zeroed counter]) when advance=True, int32 [1] otherwise"
     for t in (bias, next_tok, out, params_dev, pos_dev):
         if t is not None:
             _dev(t)
@@ -365,6 +371,16 @@ def sample_tokens(z, ldz, bias, B, nv, temperature=1.0, top_k=0, seed=0, pos=0, 
     _check(lib().dmi_sample_tokens(_p(z), ldz, _p(bias), B, nv, float(temperature), int(top_k), int(seed) & (2 ** 64 - 1),
                                    _p(params_dev), int(pos), _p(pos_dev), int(bool(advance)), int(token_offset), _p(next_tok), _p(out), out_ld,
                                    int(out_col0), _stream()), "sample_tokens")
+
+
+def logits_f32(z, ldz, bias, out, B, nv):
+    """out fp32 [B, nv] = float(z bf16 [B, ldz][:, :nv]) + float(bias bf16 [nv] or None)"""
+    _dev(z, out)
+    assert z.dtype == torch.bfloat16 and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= B * nv
+    if bias is not None:
+        _dev(bias)
+        assert bias.dtype == torch.bfloat16
+    _check(lib().dmi_logits_f32(_p(z), int(ldz), _p(bias), _p(out), int(B), int(nv), _stream()), "logits_f32")
 
 
 def sumsq_workspace_bytes(n):

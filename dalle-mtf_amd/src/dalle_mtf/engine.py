@@ -378,7 +378,8 @@ class DalleEngine:
         fused_sampling (with kv_cache and decode_graph): the draw itself is a kernel at the end of the replayed graph
         (dmi_sample_tokens: temperature / top-k / Gumbel-max categorical draw, noise a pure function of (seed, position, row))
         that writes the chosen token where the next step's embedding reads it -- P graph replays back to back, no host round
-        trip per position.  fused_sampling=False draws with torch ops on the host-visible logits (torch.multinomial stream).
+        trip per position.  fused_sampling=False launches the same draw kernel from the host after each decode step (same
+        tokens for the same seed: the noise is a pure function of (seed, position, row, index)).
         kv_cache=False: the plain form, one full evaluation forward per generated position (the causal mask makes the
         not-yet-generated tail irrelevant); kept as the cross-check the cached path is tested against."""
         B, T, S, P = self.B, self.T, self.S, self.S - self.T
@@ -386,7 +387,6 @@ class DalleEngine:
         lo, hi = self.text_vocab_size, self.text_vocab_size + self.image_vocab_size
         toks = torch.full((B, S), lo, dtype=torch.int32, device=self.dev)
         toks[:, :T] = text.to(device=self.dev, dtype=torch.int32)
-        gen = torch.Generator(device=self.dev).manual_seed(seed)
         if kv_cache and self.recompute:
             kv_cache = False     # recompute_grad keeps ONE shared set of projection buffers: there is no per-layer cache to decode from
         if kv_cache and decode_graph and fused_sampling and self.image_vocab_size <= 8192:
@@ -401,26 +401,34 @@ class DalleEngine:
                 self._run_decode(sample=True, graph=True)
             return D["out"].clone()
 
-        def pick(z):
-            if temperature <= 0:
-                return z.argmax(-1)
-            z = z / temperature
-            if top_k:
-                kth = z.topk(min(top_k, z.shape[-1]), dim=-1).values[:, -1:]
-                z = z.masked_fill(z < kth, float("-inf"))
-            return torch.multinomial(torch.softmax(z, -1), 1, generator=gen).squeeze(-1)
+        nv = hi - lo
+        if nv > 8192:
+            raise dh.DalleHipError(f"sample_image_tokens: the draw kernel (dmi_sample_tokens) handles image vocabularies up to 8192 (got {nv})")
+        bias = self._w("to_logits/linear_out/bias")[lo:hi]
+        nxt = torch.empty(B, dtype=torch.int32, device=self.dev)
+
+        def pick(z, ldz, zbias, position):
+            """the draw itself is dmi_sample_tokens on every path (temperature / top-k / Gumbel-max with counter-based noise
+            hash(seed, position, row, index), first maximum when temperature <= 0): host-launched here, the last node of the
+            replayed graph on the fused path -- the same (seed, position) gives the same draw on both."""
+            dh.sample_tokens(z, ldz, zbias, B, nv, temperature=temperature, top_k=top_k, seed=seed, pos=position,
+                             token_offset=lo, next_tok=nxt)
+            return nxt
 
         for pos in range(P):
             if not kv_cache:
                 self.forward(toks, need_grad=False)
-                z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi].float()   # the position before predicts token T + pos
+                # the position before predicts token T + pos; the evaluation head already carries the bias (GEMM epilogue)
+                z = self.z.view(B, S, self.Vp)[:, T + pos - 1, lo:hi]
+                tok = pick(z, S * self.Vp, None, T + pos - 1)
             else:
                 if pos == 0:
                     self.forward(toks, need_grad=False)    # prefill: leaves k, v of the text positions in the cache
                 # (position T - 1 is decoded again rather than read from the prefill's logits: every cached path then takes
                 # every token through the same arithmetic)
-                z = self.decode_step(toks[:, T + pos - 1].contiguous(), T + pos - 1, graph=decode_graph)
-            toks[:, T + pos] = (pick(z) + lo).to(torch.int32)
+                self.decode_step(toks[:, T + pos - 1].contiguous(), T + pos - 1, graph=decode_graph)
+                tok = pick(self._dec["z"], nv, bias, T + pos - 1)      # bf16 head output + bias, as the fused path draws
+            toks[:, T + pos] = tok
         return (toks[:, T:] - lo).contiguous()
 
     def _decode_state(self):
@@ -513,7 +521,7 @@ class DalleEngine:
             dh.sample_tokens(z, nv, bias, B, nv, params_dev=D["params"], pos_dev=D["pos_i"], advance=True, token_offset=lo,
                              next_tok=D["tok"], out=D["out"], out_col0=self.T - 1)
         else:
-            torch.add(z.float(), bias, out=D["logits"])
+            dh.logits_f32(z, nv, bias, D["logits"], B, nv)       # "go to full precision for the logits" (models.py:394-395)
 
     # ------------------------------------------------------------------ backward
     def _gv(self, name):

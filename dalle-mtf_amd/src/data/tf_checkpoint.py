@@ -22,6 +22,7 @@ here.  The reader verifies every block and tensor CRC, so a layout misunderstand
 from __future__ import annotations
 
 import os
+import warnings
 import struct
 from collections import OrderedDict
 from typing import Dict, Iterator, List, Tuple
@@ -171,9 +172,11 @@ def list_variables(prefix: str) -> "OrderedDict[str, Tuple[str, tuple]]":
     return out
 
 
-def load_checkpoint(prefix: str, verify_crc=True) -> "OrderedDict[str, np.ndarray]":
+def load_checkpoint(prefix: str, verify_crc=True, select=None) -> "OrderedDict[str, np.ndarray]":
     """{variable name: array} of a TF V2 checkpoint `<prefix>.index` / `<prefix>.data-*`.  bfloat16 tensors come back as
-    float32 (exactly representable)."""
+    float32 (exactly representable).  `select` (callable name -> bool) restricts the load BEFORE any byte of the data shards is
+    read or checksummed (a 1.3B reference checkpoint holds ~15 GB incl. its Adam slots).  Entries of a dtype this reader does
+    not decode (DT_STRING: `_CHECKPOINTABLE_OBJECT_GRAPH`, save counters) are skipped with a warning, not fatal."""
     tab = read_table(prefix + ".index")
     nshards = 1
     for f, _, val in _fields(tab.get(b"", b"")):
@@ -186,22 +189,29 @@ def load_checkpoint(prefix: str, verify_crc=True) -> "OrderedDict[str, np.ndarra
     for k, v in tab.items():
         if k == b"":
             continue
+        if select is not None and not select(k.decode()):
+            continue
         e = _parse_entry(v)
+        dt = DT.get(e["dtype"])
+        if dt is None:
+            warnings.warn(f"tensor bundle {prefix}: skipping {k.decode()!r} (dtype enum {e['dtype']} is not decoded by this reader)")
+            continue
         if e["shard"] not in shards:
-            shards[e["shard"]] = open(f"{prefix}.data-{e['shard']:05d}-of-{nshards:05d}", "rb").read()
-        raw = shards[e["shard"]][e["offset"]:e["offset"] + e["size"]]
+            shards[e["shard"]] = open(f"{prefix}.data-{e['shard']:05d}-of-{nshards:05d}", "rb")
+        f = shards[e["shard"]]
+        f.seek(e["offset"])
+        raw = f.read(e["size"])                       # only the selected tensors' bytes are read and checksummed
         if len(raw) != e["size"]:
             raise IOError(f"{prefix}: tensor {k.decode()!r} runs past the end of its data shard")
         if verify_crc and e["crc"] is not None and e["crc"] != masked_crc32c(raw):
             raise IOError(f"{prefix}: tensor {k.decode()!r} fails its checksum")
-        dt = DT.get(e["dtype"])
-        if dt is None:
-            raise NotImplementedError(f"tensor bundle: dtype enum {e['dtype']} of {k.decode()!r} is not supported")
         if isinstance(dt, str):      # bfloat16: the high half of a float32
             a = (np.frombuffer(raw, dtype="<u2").astype(np.uint32) << 16).view(np.float32)
         else:
             a = np.frombuffer(raw, dtype=dt)
         out[k.decode()] = a.reshape(e["shape"]).copy()
+    for f in shards.values():
+        f.close()
     return out
 
 
@@ -251,17 +261,18 @@ def load_model_variables(prefix: str, scope: str = "") -> "OrderedDict[str, np.n
     """The trainable variables of a reference checkpoint under `scope` (e.g. "vae/" -- reference src/model_fns.py:11-32
     restores exactly those), scope stripped, optimizer slots (`<var>/adam_m`, `<var>/adam_v`, Adam's beta powers) and
     `global_step` dropped: what DalleEngine.load_reference_params / DiscreteVAE.load_reference_params take."""
-    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
-    for name, a in load_checkpoint(prefix).items():
+    def wanted(name):      # decided on the index alone: slots and other scopes are never read from the data shards
         if not name.startswith(scope):
-            continue
+            return False
         n = name[len(scope):]
-        if n == "global_step" or n.endswith(("/adam_m", "/adam_v", "/Adam", "/Adam_1")) or n in ("beta1_power", "beta2_power"):
-            continue
-        out[n] = a.astype(np.float32) if a.dtype.kind == "f" else a
+        return not (n == "global_step" or n.endswith(("/adam_m", "/adam_v", "/Adam", "/Adam_1")) or n in ("beta1_power", "beta2_power"))
+
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, a in load_checkpoint(prefix, select=wanted).items():
+        out[name[len(scope):]] = a.astype(np.float32) if a.dtype.kind == "f" else a
     return out
 
 
 def global_step_of(prefix: str) -> int:
-    v = load_checkpoint(prefix).get("global_step")
+    v = load_checkpoint(prefix, select=lambda n: n == "global_step").get("global_step")     # one 8-byte entry, not the bundle
     return int(np.asarray(v).reshape(-1)[0]) if v is not None else 0

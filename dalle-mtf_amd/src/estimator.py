@@ -48,19 +48,31 @@ class CheckpointSaverHook:
         if not self.is_chief:
             self._sync()
             return
-        err = None
+        err, interrupt = None, None
         try:
             os.makedirs(self.model_dir, exist_ok=True)
             path = os.path.join(self.model_dir, f"model.ckpt-{step}.pt")
             torch.save(self.get_state(), path + ".tmp")
             os.replace(path + ".tmp", path)
-            ck = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
-                        key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
-            for old in ck[:-self.max_to_keep] if self.max_to_keep else []:
-                os.remove(old)
-        except BaseException as e:       # the other ranks are waiting in _sync(): reach it, then fail everywhere
+        except Exception as e:                       # the other ranks are waiting in _sync(): reach it, then fail everywhere
             err = e
-        self._sync(err)
+        except (KeyboardInterrupt, SystemExit) as e:   # same, but the chief re-raises the interrupt as itself afterwards
+            err = interrupt = e
+        if err is None:
+            # pruning old checkpoints happens after the new one is committed: a failure here is a warning, not a failed save
+            try:
+                ck = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
+                            key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
+                for old in ck[:-self.max_to_keep] if self.max_to_keep else []:
+                    os.remove(old)
+            except OSError as e:
+                import warnings
+                warnings.warn(f"checkpoint retention: could not remove an old checkpoint ({e!r}); the new one is saved")
+        try:
+            self._sync(err)
+        finally:
+            if interrupt is not None:
+                raise interrupt
 
     def _sync(self, err=None):
         """every rank leaves save() only after the chief's file is complete (readers: evaluate(), resume); a failed write

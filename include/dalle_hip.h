@@ -188,6 +188,10 @@ int dmi_sample_tokens(const uint16_t* z, int ldz, const uint16_t* bias, int B, i
                       uint64_t seed, const uint32_t* params_dev, int pos, int32_t* pos_dev, int advance, int token_offset,
                       int32_t* next_tok, int32_t* out, int out_ld, int out_col0, void* stream);
 
+/* "Go to full precision for the logits" (src/dalle_mtf/models.py:394-395) for a slice of the head's output:
+ * out[b, i] = float(z[b, i]) + float(bias[i]), z bf16 [B, ldz] (first nv columns), bias bf16 [nv] (nullable), out fp32 [B, nv]. */
+int dmi_logits_f32(const uint16_t* z, int ldz, const uint16_t* bias, float* out, int B, int nv, void* stream);
+
 /* ---- K9  clip_by_global_norm + AdamWeightDecayOptimizer   src/optimizers.py:11-16,82-89,154-177
  * sumsq: out[0] = sum g^2 (deterministic two-stage; workspace dmi_sumsq_workspace_bytes(n)).
  * adam: mult = clip>0 ? clip/max(sqrt(*gnorm_sq),clip) : 1;  g*=mult; m=b1 m+(1-b1)g; v=b2 v+(1-b2)g^2;

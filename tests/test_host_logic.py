@@ -238,3 +238,20 @@ def test_tf_checkpoint_bundle_roundtrip_and_known_constants(tmp_path):
     open(prefix + ".index", "wb").write(bytes(bad))
     with pytest.raises(IOError):
         tfc.read_table(prefix + ".index")
+
+
+def test_sampler_uniform_is_strictly_inside_unit_interval():
+    """dmi_sample_tokens draws Gumbel noise -log(-log u) from u = (float(h >> 41) + 0.5) * 2^-23 (csrc/elementwise.hip): with 23
+    random bits the + 0.5 is exact in fp32, so u stays in [2^-24, 1 - 2^-24] and the noise is finite at both ends.  (With 24
+    bits 16777215.5 rounds to 2^24: u == 1, noise +inf, the entry wins regardless of its logit -- round-3 advisor finding.)"""
+    f32 = np.float32
+    for bits, ok in ((23, True), (24, False)):
+        top = f32((1 << bits) - 1)
+        u_max = f32(f32(top + f32(0.5)) * f32(1.0 / (1 << bits)))
+        u_min = f32(f32(0.5) * f32(1.0 / (1 << bits)))
+        assert (u_max < f32(1.0)) == ok and u_min > 0
+        if ok:
+            noise = -np.log(-np.log(np.array([u_min, u_max], dtype=np.float32)))
+            assert np.all(np.isfinite(noise)) and noise[1] < 17.0 and noise[0] > -3.0
+    src = open(os.path.join(os.path.dirname(__file__), "..", "dalle-mtf_amd", "csrc", "elementwise.hip")).read()
+    assert "(h >> 41) + 0.5f) * (1.0f / 8388608.0f)" in src

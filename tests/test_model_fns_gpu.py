@@ -297,7 +297,7 @@ def test_kv_cached_decode_equals_full_forward():
     assert worst <= 2.5e-2 * scale, (worst, scale)
     text = toks[:, :T].contiguous()
     a = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True)      # decode + draw replayed as one graph per position
-    a2 = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True, fused_sampling=False)   # draw by torch ops on the logits
+    a2 = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True, fused_sampling=False)   # draw kernel launched from the host
     a3 = eng.sample_image_tokens(text, temperature=0.0, kv_cache=True, decode_graph=False)     # host-launched
     assert torch.equal(a, a2) and torch.equal(a, a3) and eng._dec["graphs"].get(True) is not None
     b = eng.sample_image_tokens(text, temperature=0.0, kv_cache=False)
@@ -318,10 +318,11 @@ def test_kv_cached_decode_equals_full_forward():
     c2 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3)
     c3 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=4)
     assert torch.equal(c1, c2) and int(c1.max()) < iv and int(c1.min()) >= 0 and not torch.equal(c1, c3)
-    for kw in (dict(fused_sampling=False), dict(decode_graph=False)):      # the torch.multinomial path stays reproducible too
+    for kw in (dict(fused_sampling=False), dict(decode_graph=False)):      # host-launched draw: the same kernel, the same noise
         d1 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3, **kw)
         d2 = eng.sample_image_tokens(text, temperature=1.0, top_k=8, seed=3, **kw)
         assert torch.equal(d1, d2) and int(d1.max()) < iv and int(d1.min()) >= 0
+        assert torch.equal(d1, c1), "the draw is a pure function of (seed, position, row): graph-replayed and host-launched draws agree"
 
 
 @pytest.mark.parametrize("nv", [64, 512, 2048, 8192])
@@ -381,6 +382,19 @@ def test_sample_tokens_kernel(nv):
     for _ in range(6):
         dh.sample_tokens(zd, nv + 8, bd, B, nv, temperature=T, top_k=k, seed=9, pos_dev=pd, advance=True, out=seq, out_col0=0)
     assert pd.cpu().tolist() == [6, 0] and torch.equal(seq.cpu().long(), draws[:, :6])
+
+
+def test_logits_f32_kernel():
+    """dmi_logits_f32: fp32(z) + fp32(bias) over a column slice of a wider bf16 matrix (exact: both terms are bf16 values)"""
+    import dalle_hip as dh
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(5, 700, generator=g).to(torch.bfloat16).cuda()
+    bias = torch.randn(300, generator=g).to(torch.bfloat16).cuda()
+    out = torch.full((5, 300), -7.0, dtype=torch.float32, device="cuda")
+    dh.logits_f32(z[:, 100:], 700, bias, out, 5, 300)
+    assert torch.equal(out, z[:, 100:400].float() + bias.float())
+    dh.logits_f32(z, 700, None, out, 5, 300)
+    assert torch.equal(out, z[:, :300].float())
 
 
 def test_reference_tf_checkpoints_load_by_variable_name(tmp_path):
