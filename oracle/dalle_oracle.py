@@ -150,10 +150,58 @@ def n_params(cfg: DalleConfig) -> int:
 # --------------------------------------------------------------------------------------
 
 
-def _rb(x: torch.Tensor, bf16: bool) -> torch.Tensor:
+class _RoundBF16Grad(torch.autograd.Function):
+    """y = bf16(x) in the forward and dx = bf16(dy) in the backward, written out explicitly.  Under the reference's `bf_16`
+    policy a tensor of the activation dtype has a gradient of the activation dtype too (mtf computes every op's gradient in
+    the op's own dtype, src/dalle_mtf/ops.py:76-82 VariableDType(activation=bf16)).  NOTE (round 4): the plain round trip
+    `x.to(bfloat16).to(float32)` does exactly the same -- autograd's backward of the up-cast converts the incoming gradient
+    to the bf16 source dtype -- so `bf16=True` has always rounded backward tensors as well (tests/test_oracle.py pins the two
+    forms against each other); round 3's reading that the oracle kept backward activations in fp32 was wrong."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _rb(x: torch.Tensor, bf16) -> torch.Tensor:
     """Round-trip through bf16 when emulating the reference's bf16 activation dtype
-    (src/dalle_mtf/ops.py:76-82: master bf16 / slice fp32 / activation bf16)."""
-    return x.to(torch.bfloat16).to(torch.float32) if bf16 else x
+    (src/dalle_mtf/ops.py:76-82: master bf16 / slice fp32 / activation bf16).  The gradient that flows back through the
+    rounded tensor is rounded to bf16 as well (see _RoundBF16Grad).
+    bf16 = False: fp32 throughout;  True (or "grad", the explicit spelling): forward tensor and its gradient rounded."""
+    if not bf16:
+        return x
+    if bf16 is True:
+        return x.to(torch.bfloat16).to(torch.float32)
+    return _RoundBF16Grad.apply(x)
+
+
+def _rbw(x: torch.Tensor, bf16) -> torch.Tensor:
+    """activation-dtype cast of a WEIGHT (mtf casts the fp32 slice to bf16 for compute; the weight gradient is the bf16 result
+    of a bf16 einsum, cast back to fp32 at src/optimizers.py:44).  bf16 = "fp32w": the weight is rounded in the forward but
+    its gradient stays the fp32 value of that einsum -- what an implementation that accumulates weight gradients in fp32
+    produces (bf16 rounding of a gradient tensor costs 1.6e-3 relative L2)."""
+    if not bf16:
+        return x
+    if bf16 == "fp32w":
+        return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
+    return _rb(x, bf16)
+
+
+def _force(force, name: str, computed: torch.Tensor) -> torch.Tensor:
+    """Teacher forcing for backward-parity tests: when `force` holds a tensor for site `name`, the FORWARD value of the site
+    becomes that tensor (e.g. the activation the implementation under test stored for its backward) while the derivative
+    structure stays the oracle's (straight-through: value = forced, gradient = gradient of `computed`).  Two faithful bf16
+    implementations diverge in the forward by rounding-boundary and ReLU-mask flips that different fp32 summation orders
+    cause (a flipped mask fraction f costs sqrt(f) in relative L2 upstream); forcing removes that divergence so that what
+    remains is the backward arithmetic alone."""
+    if force is None or name not in force:
+        return computed
+    f = torch.as_tensor(force[name], dtype=torch.float32).reshape(computed.shape)
+    return f + (computed - computed.detach())
 
 
 def layer_norm(x, g, b, eps=1e-5):
@@ -172,59 +220,60 @@ def attn_mask(S: int) -> torch.Tensor:
     return (i < j).to(torch.float32) * -1e10
 
 
-def attention(x, wq, wk, wv, wo, o_b, n_heads, mask, bf16=False):
+def attention(x, wq, wk, wv, wo, o_b, n_heads, mask, bf16=False, force=None, site=""):
     """a7: src/dalle_mtf/models.py:229-315.  q,k,v = x@Wq, x@Wk, x@Wv (bias-free, [d, H*k] heads-major,
     Appendix A.1); logits = q.k^T UNSCALED in fp32 (Appendix A.2/A.3) + mask; softmax over keys
     (exp(x - logsumexp(x))); @v; @Wo + o_b."""
     B, S, d = x.shape
     k = d // n_heads
-    q = _rb(x @ wq, bf16).view(B, S, n_heads, k).transpose(1, 2)   # [B,H,S,k]
-    kk = _rb(x @ wk, bf16).view(B, S, n_heads, k).transpose(1, 2)
-    v = _rb(x @ wv, bf16).view(B, S, n_heads, k).transpose(1, 2)
+    q = _force(force, site + "q", _rb(x @ wq, bf16)).view(B, S, n_heads, k).transpose(1, 2)   # [B,H,S,k]
+    kk = _force(force, site + "k", _rb(x @ wk, bf16)).view(B, S, n_heads, k).transpose(1, 2)
+    v = _force(force, site + "v", _rb(x @ wv, bf16)).view(B, S, n_heads, k).transpose(1, 2)
     logits = q @ kk.transpose(-1, -2)                              # fp32, no 1/sqrt(k)
     logits = logits + mask
     w = torch.exp(logits - torch.logsumexp(logits, dim=-1, keepdim=True))
     w = _rb(w, bf16)                                               # "cast to v dtype" (A.3)
     a = _rb(w @ v, bf16)                                           # [B,H,S,k]
-    a = a.transpose(1, 2).reshape(B, S, d)
+    a = _force(force, site + "a", a.transpose(1, 2).reshape(B, S, d))
     return _rb(a @ wo + o_b, bf16)
 
 
-def mlp(x, w1, b1, w2, b2, bf16=False):
+def mlp(x, w1, b1, w2, b2, bf16=False, force=None, site=""):
     """a8: src/dalle_mtf/models.py:317-324 + linear :361-371 -- relu(x@W1+b1)@W2+b2."""
-    h = _rb(torch.relu(x @ w1 + b1), bf16)
+    h = _force(force, site + "h", _rb(torch.relu(x @ w1 + b1), bf16))
     return _rb(h @ w2 + b2, bf16)
 
 
 def forward_hidden(P: Dict[str, torch.Tensor], tokens: torch.Tensor, cfg: DalleConfig, bf16=False,
-                   taps: Optional[dict] = None) -> torch.Tensor:
-    """a3,a4,a9: embedding models.py:186-201, positional :203-219, transformer :337-346, block :326-335."""
+                   taps: Optional[dict] = None, force: Optional[dict] = None) -> torch.Tensor:
+    """a3,a4,a9: embedding models.py:186-201, positional :203-219, transformer :337-346, block :326-335.
+    force: optional {site: tensor} teacher forcing (see _force); sites: "embed", "layer_{i}/xn1|q|k|v|a|x1|xn2|h|out"."""
     B, S = tokens.shape
-    W = (lambda n: _rb(P[n], bf16))                                 # activation-dtype cast of the weights
+    W = (lambda n: _rbw(P[n], bf16))                                # activation-dtype cast of the weights
     x = W("embedding/wte")[tokens.long()]                          # mtf.gather (A.6)
-    x = _rb(x + W("positional_embedding/wpe")[:S], bf16)
+    x = _force(force, "embed", _rb(x + W("positional_embedding/wpe")[:S], bf16))
     mask = attn_mask(S)
     if taps is not None:
         taps["embed"] = x
     for i in range(cfg.n_layers):
         p = f"layer_{i}/"
-        h = _rb(layer_norm(x, W(p + "norm_1/g"), W(p + "norm_1/b")), bf16)
+        h = _force(force, p + "xn1", _rb(layer_norm(x, W(p + "norm_1/g"), W(p + "norm_1/b")), bf16))
         a = attention(h, W(p + "attn/q"), W(p + "attn/k"), W(p + "attn/v"), W(p + "attn/o"),
-                      W(p + "attn/compute_output_bias/o_b"), cfg.n_heads, mask, bf16)
-        x = _rb(x + a, bf16)
-        h = _rb(layer_norm(x, W(p + "norm_2/g"), W(p + "norm_2/b")), bf16)
+                      W(p + "attn/compute_output_bias/o_b"), cfg.n_heads, mask, bf16, force, p)
+        x = _force(force, p + "x1", _rb(x + a, bf16))
+        h = _force(force, p + "xn2", _rb(layer_norm(x, W(p + "norm_2/g"), W(p + "norm_2/b")), bf16))
         m = mlp(h, W(p + "mlp/mlp_linear_1/kernel"), W(p + "mlp/mlp_linear_1/bias"),
-                W(p + "mlp/mlp_linear_2/kernel"), W(p + "mlp/mlp_linear_2/bias"), bf16)
-        x = _rb(x + m, bf16)
+                W(p + "mlp/mlp_linear_2/kernel"), W(p + "mlp/mlp_linear_2/bias"), bf16, force, p)
+        x = _force(force, p + "out", _rb(x + m, bf16))
         if taps is not None:
             taps[f"layer_{i}"] = x
     return x
 
 
-def to_logits(P, x, bf16=False):
+def to_logits(P, x, bf16=False, force=None):
     """a10: src/dalle_mtf/models.py:391-395 -- LN(x) @ Wout + bout, then cast to fp32."""
-    W = (lambda n: _rb(P[n], bf16))
-    h = _rb(layer_norm(x, W("to_logits/layer_norm/g"), W("to_logits/layer_norm/b")), bf16)
+    W = (lambda n: _rbw(P[n], bf16))
+    h = _force(force, "xnf", _rb(layer_norm(x, W("to_logits/layer_norm/g"), W("to_logits/layer_norm/b")), bf16))
     return _rb(h @ W("to_logits/linear_out/kernel") + W("to_logits/linear_out/bias"), bf16)
 
 
@@ -240,11 +289,11 @@ def loss_fn(logits: torch.Tensor, labels: torch.Tensor, num_microbatches: int = 
 
 
 def forward(P: Dict[str, torch.Tensor], tokens: np.ndarray, cfg: DalleConfig, bf16=False,
-            return_logits=False, taps: Optional[dict] = None):
+            return_logits=False, taps: Optional[dict] = None, force: Optional[dict] = None):
     """DALLE.forward src/dalle_mtf/models.py:397-416."""
     tok = torch.as_tensor(np.asarray(tokens), dtype=torch.int64)
-    x = forward_hidden(P, tok, cfg, bf16, taps)
-    logits = to_logits(P, x, bf16)
+    x = forward_hidden(P, tok, cfg, bf16, taps, force)
+    logits = to_logits(P, x, bf16, force)
     labels = torch.as_tensor(shift_labels(np.asarray(tokens), cfg.eos_token_id), dtype=torch.int64)
     loss, loss_batch = loss_fn(logits, labels)
     if return_logits:
@@ -252,10 +301,10 @@ def forward(P: Dict[str, torch.Tensor], tokens: np.ndarray, cfg: DalleConfig, bf
     return loss, loss_batch
 
 
-def loss_and_grads(params_np: Dict[str, np.ndarray], tokens: np.ndarray, cfg: DalleConfig, bf16=False):
+def loss_and_grads(params_np: Dict[str, np.ndarray], tokens: np.ndarray, cfg: DalleConfig, bf16=False, force=None):
     """mtf.gradients([loss], trainable_variables) src/optimizers.py:34; cast to fp32 :44."""
     P = OrderedDict((n, torch.tensor(a, dtype=torch.float32, requires_grad=True)) for n, a in params_np.items())
-    loss, _ = forward(P, tokens, cfg, bf16)
+    loss, _ = forward(P, tokens, cfg, bf16, force=force)
     loss.backward()
     grads = OrderedDict((n, (p.grad.detach().numpy().copy() if p.grad is not None
                              else np.zeros(tuple(p.shape), np.float32))) for n, p in P.items())

@@ -104,7 +104,19 @@ def n_params(cfg: VaeConfig) -> int:
 
 
 def _rb(x, bf16):
+    """use_bf16: round trip through bf16 (the gradient flowing back through the rounded tensor is rounded to bf16 as well:
+    autograd's backward of the up-cast converts it to the bf16 source dtype -- see oracle/dalle_oracle.py _RoundBF16Grad)"""
     return x.to(torch.bfloat16).to(torch.float32) if bf16 else x
+
+
+def _rbw(x, bf16):
+    """cast of a WEIGHT to the activation dtype; use_bf16 = "fp32w" rounds the weight in the forward but keeps its gradient in
+    fp32 (an implementation that accumulates weight gradients in fp32)"""
+    if not bf16:
+        return x
+    if bf16 == "fp32w":
+        return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
+    return x.to(torch.bfloat16).to(torch.float32)
 
 
 def conv2d_same(x_nhwc, kernel, bias, stride):
@@ -157,11 +169,11 @@ def encoder(P, img, cfg: VaeConfig):
         for i in range(stack):
             p = f"encoder/block_{b}/layer_{i}/"
             if i == 0:
-                x = _rb(conv2d_same(x, _rb(P[p + "conv_downsample/kernel"], bf), _rb(P[p + "conv_downsample/bias"], bf), 2), bf)
+                x = _rb(conv2d_same(x, _rbw(P[p + "conv_downsample/kernel"], bf), _rbw(P[p + "conv_downsample/bias"], bf), 2), bf)
             else:
-                o = _rb(conv2d_same(x, _rb(P[p + "conv_in/kernel"], bf), _rb(P[p + "conv_in/bias"], bf), 1), bf)
+                o = _rb(conv2d_same(x, _rbw(P[p + "conv_in/kernel"], bf), _rbw(P[p + "conv_in/bias"], bf), 1), bf)
                 o = torch.relu(o)
-                o = _rb(conv2d_same(o, _rb(P[p + "conv_out/kernel"], bf), _rb(P[p + "conv_out/bias"], bf), 1), bf)
+                o = _rb(conv2d_same(o, _rbw(P[p + "conv_out/kernel"], bf), _rbw(P[p + "conv_out/bias"], bf), 1), bf)
                 x = _rb(x + o, bf)
     return x @ P["codebook/codebook"]              # fp32 matmul, models.py:115-118
 
@@ -189,13 +201,13 @@ def decoder(P, x, cfg: VaeConfig):
         for i in range(stack):
             p = f"decoder/block_{b}/layer_{i}/"
             if i == 0:
-                x = _rb(conv2d_transpose_same(x, _rb(P[p + "conv_upsample/kernel"], bf), _rb(P[p + "conv_upsample/bias"], bf)), bf)
+                x = _rb(conv2d_transpose_same(x, _rbw(P[p + "conv_upsample/kernel"], bf), _rbw(P[p + "conv_upsample/bias"], bf)), bf)
             else:
-                o = _rb(conv2d_same(x, _rb(P[p + "conv_in/kernel"], bf), _rb(P[p + "conv_in/bias"], bf), 1), bf)
+                o = _rb(conv2d_same(x, _rbw(P[p + "conv_in/kernel"], bf), _rbw(P[p + "conv_in/bias"], bf), 1), bf)
                 o = torch.relu(o)
-                o = _rb(conv2d_same(o, _rb(P[p + "conv_out/kernel"], bf), _rb(P[p + "conv_out/bias"], bf), 1), bf)
+                o = _rb(conv2d_same(o, _rbw(P[p + "conv_out/kernel"], bf), _rbw(P[p + "conv_out/bias"], bf), 1), bf)
                 x = _rb(x + o, bf)
-    x = _rb(conv2d_same(x, _rb(P["decoder/conv2d/kernel"], bf), _rb(P["decoder/conv2d/bias"], bf), 1), bf)
+    x = _rb(conv2d_same(x, _rbw(P["decoder/conv2d/kernel"], bf), _rbw(P["decoder/conv2d/bias"], bf), 1), bf)
     if cfg.stack_factor > 1:
         x = depth_to_space(x, cfg.stack_factor)
     return x

@@ -32,8 +32,25 @@ def save_report(name, obj):
         pass
 
 
+def engine_sites(eng):
+    """the activations DalleEngine keeps for its backward, under the oracle's teacher-forcing site names"""
+    assert not eng.recompute, "recompute_grad keeps one shared set of block buffers"
+    B, S, d, L = eng.B, eng.S, eng.d, eng.L
+    f = lambda t, n=None: t.float().cpu().reshape(B, S, -1)
+    sites = {"embed": f(eng.X[0]), "xnf": f(eng.xnf)}
+    for l in range(L):
+        p = f"layer_{l}/"
+        qkv = f(eng.qkv[l])
+        sites.update({p + "xn1": f(eng.xn1[l]), p + "q": qkv[..., :d].contiguous(), p + "k": qkv[..., d:2 * d].contiguous(),
+                      p + "v": qkv[..., 2 * d:].contiguous(), p + "a": f(eng.o[l]), p + "x1": f(eng.x1[l]),
+                      p + "xn2": f(eng.xn2[l]), p + "h": f(eng.h[l]), p + "out": f(eng.X[l + 1])})
+    return sites
+
+
 def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=64, T=16, P=112, B=2, seed=0,
-                 steps=2, verbose=True, hp=None, perturb=0.05, bf16_oracle=True, per_tensor=False):
+                 steps=2, verbose=True, hp=None, perturb=0.05, bf16_oracle=True, per_tensor=False, bf16_grad_oracle=False):
+    """bf16_grad_oracle: also compare against the bf16 oracle with fp32 weight gradients and against the TEACHER-FORCED bf16
+    oracle (oracle/dalle_oracle.py _force: forward = the engine's stored activations, backward = the oracle's)"""
     from oracle import dalle_oracle as do
     from src.dalle_mtf.engine import DalleEngine
     cfg = do.DalleConfig(n_embd, text_vocab, image_vocab, T, P, n_layers, n_heads)
@@ -67,6 +84,19 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
             rec["worst_grad_rel_l2_vs_bf16_oracle"] = max(((e, k) for k, e in table16.items()), key=lambda t: t[0])
             if per_tensor:
                 rec["grad_rel_l2_vs_bf16_oracle"] = table16
+        if bf16_grad_oracle:
+            # (a) free-running bf16 oracle whose weight gradients stay fp32 (the engine accumulates them in fp32);
+            # (b), (c) TEACHER-FORCED: the oracle's forward takes the activations the engine stored for its own backward, so the
+            # forward divergence of two bf16 implementations (rounding-boundary / ReLU-mask flips from different fp32
+            # summation orders) is gone and the BACKWARD arithmetic is compared alone
+            sites = engine_sites(eng)
+            for tag, mode, force in (("bf16_fp32w", "fp32w", None), ("forced_bf16", True, sites), ("forced_fp32w", "fp32w", sites)):
+                loss_og, gg = do.loss_and_grads(Po, tokens, cfg, bf16=mode, force=force)
+                tab = {k: rel_l2(gh[k], gg[k]) for k in gg}
+                rec[f"loss_oracle_{tag}"] = loss_og
+                rec[f"worst_grad_rel_l2_vs_{tag}_oracle"] = max(((e, k) for k, e in tab.items()), key=lambda t: t[0])
+                if per_tensor:
+                    rec[f"grad_rel_l2_vs_{tag}_oracle"] = tab
         gn_h = math.sqrt(sum(float((gh[k].astype(np.float64) ** 2).sum()) for k in gh))
         gn_o = math.sqrt(sum(float((g32[k].astype(np.float64) ** 2).sum()) for k in g32))
         eng.global_step = step + 1  # past step 0 (lr(0) = 0 under warm-up)

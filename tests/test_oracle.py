@@ -233,3 +233,45 @@ def test_block_matches_huggingface_gpt_neo_port():
     # the scale matters: with 1/sqrt(head_dim) applied the blocks would differ visibly on these weights
     a_scaled = do.attention(h, P["q"] / (d // H) ** 0.5, P["k"], P["v"], P["o"], P["ob"], H, do.attn_mask(S))
     assert float((a_scaled - a).abs().max()) > 1e-2
+
+
+def test_bf16_oracle_rounds_gradients_and_teacher_forcing_is_consistent():
+    """(1) The bf16 oracle's BACKWARD tensors are bf16: autograd's backward of `.to(float32)` on a bf16 tensor converts the
+    incoming gradient to bf16, so the plain round trip equals the explicit _RoundBF16Grad (forward AND gradient rounded) --
+    bit for bit on every gradient of a 2-layer model.  (2) "fp32w" changes only the weight gradients' final rounding
+    (<= 2^-8 relative per element).  (3) Teacher forcing with the oracle's OWN activations is the identity."""
+    cfg = do.DalleConfig(128, 60, 64, 8, 24, 2, 1)
+    P = do.init_params(cfg, seed=1, perturb=0.05)
+    tok = do.assemble_tokens(do.synthetic_captions(2, 8, 60, seed=1), do.synthetic_image_tokens(2, 24, 64, seed=2), 60)
+    l1, g1 = do.loss_and_grads(P, tok, cfg, bf16=True)
+    l2, g2 = do.loss_and_grads(P, tok, cfg, bf16="grad")
+    assert l1 == l2 and all(np.array_equal(g1[k], g2[k]) for k in g1)
+    x = torch.randn(64, requires_grad=True)
+    (do._rb(x, True) * torch.linspace(0.1, 7.7, 64)).sum().backward()
+    assert torch.equal(x.grad, torch.linspace(0.1, 7.7, 64).to(torch.bfloat16).float())
+    l3, g3 = do.loss_and_grads(P, tok, cfg, bf16="fp32w")
+    assert l3 == l1
+    for k in g1:
+        assert np.all(np.abs(g1[k] - g3[k]) <= 2.0 ** -8 * np.abs(g3[k]) + 1e-12), k
+    # capture the oracle's own sites by forcing with a recording dict, then force with them
+    class Rec(dict):
+        def __contains__(self, k):
+            return False
+    sites = {}
+    orig = do._force
+    try:
+        def rec_force(force, name, computed):
+            sites[name] = computed.detach().clone()
+            return computed
+        do._force = rec_force
+        do.loss_and_grads(P, tok, cfg, bf16=True)
+    finally:
+        do._force = orig
+    assert {"embed", "xnf", "layer_1/h", "layer_0/q", "layer_1/out"} <= set(sites)
+    l4, g4 = do.loss_and_grads(P, tok, cfg, bf16=True, force=sites)
+    assert l4 == l1 and all(np.array_equal(g1[k], g4[k]) for k in g1)
+    # forcing a perturbed hidden layer changes the gradients upstream of it (the forced value is really used)
+    sites2 = dict(sites)
+    sites2["layer_1/h"] = sites["layer_1/h"] * 1.5
+    _, g5 = do.loss_and_grads(P, tok, cfg, bf16=True, force=sites2)
+    assert not np.array_equal(g5["layer_1/mlp/mlp_linear_2/kernel"], g1["layer_1/mlp/mlp_linear_2/kernel"])
