@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (weak scaling); default: the model's BASELINE value")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the primary line): per-GPU batch fixed, global batch = batch x N.  strong (BASELINE.md §2's "
+                         "secondary number): GLOBAL batch fixed at the model's BASELINE value, per-GPU batch = global / N")
     ap.add_argument("--model", default="dalle_example", choices=sorted(MODELS) + sorted(VAE_MODELS))
     args = ap.parse_args()
     world, rank, pg, comm = setup_dist(args)
@@ -295,6 +298,9 @@ def main():
     import torch.distributed as dist
     from src.dalle_mtf.engine import DalleEngine
     B = args.batch or PER_GPU_BATCH
+    if args.scaling == "strong":
+        assert B % world == 0, f"strong scaling: the global batch {B} must divide by the number of GPUs {world}"
+        B = B // world
     eng = DalleEngine(CFG["n_embd"], CFG["n_layers"], CFG["n_heads"], CFG["text_vocab_size"], CFG["image_vocab_size"],
                       CFG["text_seq_len"], CFG["image_seq_len"], batch_size=B, global_batch_size=B * world, hparams=HP,
                       process_group=pg, world_size=world, comm=comm)
@@ -342,19 +348,28 @@ def main():
         achieved = gemm_flops / (k_avg * 1e-3) / 1e12 if k_ms else float("nan")
         # 256x128 tiles when the grid covers >= 3 residencies and K <= 1024 (csrc/gemm.hip launch_nt), else 128x128
         tiles4 = ((B * S + 255) // 256) * ((eng.Vp + 127) // 128)
-        kname = "gemm_nt4_kernel<65>" if (tiles4 >= 1536 and d <= 1024) else "gemm_nt2_kernel<65>"
+        tiles8 = ((B * S + 255) // 256) * ((eng.Vp + 255) // 256)
+        if tiles8 >= 512 and d <= 1024 and d % 128 == 0:      # persistent 256x256 tiles (csrc/gemm.hip launch_nt, option nt8p = auto)
+            kname = "gemm_nt8p_kernel<65>"
+        else:
+            kname = "gemm_nt4_kernel<65>" if (tiles4 >= 1536 and d <= 1024) else "gemm_nt2_kernel<65>"
         traffic, tsrc = (load_traffic("vocab_gemm", kname) if (B == PER_GPU_BATCH and args.model == "dalle_example") else (None, None))
         algo_bytes = (B * S * d + eng.Vp * d) * 2 + B * S * eng.Vp * 2 + (eng.Vp // 64) * B * S * 4
         out = {
             "metric": f"train tokens/sec (text+image) per node, {args.model}", "value": tokens_per_s, "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"configs/{args.model if args.model != '1.3B' else 'dalle_example (1.3B dimensions, SURVEY §8(d) C5)'}.json transformer train step (n_embd={d}, {L} layers, "
                                    f"{CFG['n_heads']} heads, seq 256+1024, V={V}), synthetic captions + synthetic image-token ids",
                        "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
                        "dp_transport": eng.reducer.transport if world > 1 else None,
                        "dp_pieces_per_step": len(schedule) if world > 1 else None,
                        "dp_largest_piece_MB": (max(b - a for a, b in schedule) * 4 / 2 ** 20) if (world > 1 and schedule) else None,
+                       # every exchange piece in issue order, and the bytes issued after the last backward kernel (the embedding
+                       # gradients): nothing is left to hide those behind, they are the exposed tail of the exchange
+                       "dp_piece_MB": [round((b - a) * 4 / 2 ** 20, 2) for a, b in schedule] if world > 1 else None,
+                       "dp_exposed_tail_MB": (sum(b - a for a, b in schedule if a >= eng.lay.offset["positional_embedding/wpe"]) * 4 / 2 ** 20)
+                       if world > 1 else None,
                        "final_loss": loss},
             "roofline": {"bound": "mfma",
                          "kernel": f"{kname} (vocabulary projection with the softmax-numerator epilogue, dmi_gemm_nt_softmax: M=B*S={B * S}, N={eng.Vp}, K={d})",

@@ -33,12 +33,30 @@ static int g_opt_nt8_min_k = 2048;   // auto mode of the 256x256 NT tile: minimu
                                      // run 354 -> 339 ms/step (profiles/r03_ab_nt8_min_k.log); K = 1024 measured equal, K = 512 slower
 static int g_opt_skinny = 1;     // M <= 32 products (the decode step) on the weight-streaming kernel: 0 never, 1 auto
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
+static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1): 0 never, 1 auto (outputs >= cstream_min_mb MiB: they cannot be re-read from
+                                 // L2 anyway, and as plain stores they evict the operand panels the co-resident tiles share), 2 always
+static int g_opt_cstream_min_mb = 256;
+static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
+static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
+                                 // tiles per CU), 2 whenever the shape allows it (tests, tools/kbench.py)
+static int g_opt_nt8p_pd = 1;    // load pipeline of the persistent kernel: 1 = v8p (64-wide k-steps, two buffers, one k-step ahead),
+                                 // 2 / 3 = v8q (32-wide k-steps, four buffers, 2 / 3 k-steps ahead, counted vmcnt)
+static int g_opt_nt8p_max_k = 1024;   // auto mode: K above this keeps the one-tile-per-block kernels (the main loop then dominates a tile)
+static int g_opt_nt4_lds = 49152;   // dynamic LDS requested by the 256x128 NT kernel: 49152 = what it uses (3 blocks / CU); 65536 / 98304
+                                    // cap the residency at 2 / 1 blocks per CU (tools/phases.py: a block's phases without co-resident blocks)
 static unsigned long long* g_dbg_buf = nullptr;
 extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt8")) return g_opt_nt8;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
+  if (!strcmp(name, "nt4_lds")) return g_opt_nt4_lds;
+  if (!strcmp(name, "nt8p")) return g_opt_nt8p;
+  if (!strcmp(name, "ntr")) return g_opt_ntr;
+  if (!strcmp(name, "cstream")) return g_opt_cstream;
+  if (!strcmp(name, "cstream_min_mb")) return g_opt_cstream_min_mb;
+  if (!strcmp(name, "nt8p_max_k")) return g_opt_nt8p_max_k;
+  if (!strcmp(name, "nt8p_pd")) return g_opt_nt8p_pd;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
@@ -50,6 +68,13 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
+  if (!strcmp(name, "nt4_lds")) { if (value < 49152 || value > 163840) return -1; g_opt_nt4_lds = value; return 0; }
+  if (!strcmp(name, "nt8p")) { g_opt_nt8p = value; return 0; }
+  if (!strcmp(name, "ntr")) { g_opt_ntr = value; return 0; }
+  if (!strcmp(name, "cstream")) { g_opt_cstream = value; return 0; }
+  if (!strcmp(name, "cstream_min_mb")) { g_opt_cstream_min_mb = value; return 0; }
+  if (!strcmp(name, "nt8p_max_k")) { g_opt_nt8p_max_k = value; return 0; }
+  if (!strcmp(name, "nt8p_pd")) { if (value < 1 || value > 3) return -1; g_opt_nt8p_pd = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
@@ -80,6 +105,7 @@ struct GemmArgs {
   int k_per_split;     // multiple of BK
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
+  int cpol;                 // cache policy of the bf16 output stores: 0 plain, 1 sc1 (write-through, the line is not kept in the XCD's L2)
 };
 #define GEMM_SOFTMAX 64   // internal epilogue flag of dmi_gemm_nt_softmax (not part of the public flag set)
 
@@ -98,6 +124,9 @@ __device__ __forceinline__ void tile_of_block(int L, int tiles_m, int tiles_n, i
 
 // byte offset inside a [128][64] bf16 LDS tile of the 16-B chunk `ch` (0..7) of row `row`
 __device__ __forceinline__ int lds_chunk_off(int row, int ch) { return (row * 8 + (ch ^ ((row >> 1) & 7))) * 16; }
+// 64-B LDS rows (32-wide k-steps, 4 chunks of 16 B): see the 256x128 kernel below
+__device__ __forceinline__ int lds4_swz(int row) { return (-(row >> 2)) & 3; }
+__device__ __forceinline__ int lds4_off(int row, int ch) { return row * 64 + ((ch ^ lds4_swz(row)) << 4); }
 
 // =====================================================================================
 // NT kernel v2: same tiling/swizzle as gemm_nt_kernel, with
@@ -121,6 +150,18 @@ __device__ __forceinline__ int lds_chunk_off(int row, int ch) { return (row * 8 
 // accumulators -> wave-private fp32 staging block of 32 rows x 64 columns (pitch 68 floats), for the two MFMA shapes:
 //   32x32x16: acc[MI][2] (f32x16): lane (r = lane & 31, h = lane >> 5) holds row r, columns j*32 + 8q + 4h + {0..3}
 //   16x16x32: acc[2 MI][4] (f32x4): lane (c = lane & 15, g = lane >> 4) holds row ii*16 + c, columns j*16 + 4g + {0..3}
+// 16-B store of 8 bf16 outputs at element offset `off` of C.  cpol 1: through a buffer descriptor with the sc1 bit -- written
+// through to the memory side, the line is not kept in the XCD's L2.  The 4 GB of softmax numerators the vocabulary projection
+// writes would otherwise pass through the 4-MiB L2s as dirty lines and evict the A / B panels that the XCD's 32 concurrent tiles
+// share (round 3 measured 2.5 GB fetched per launch against 94 MB of operands).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t c_rsrc(const GemmArgs& a) {
+  return __builtin_amdgcn_make_buffer_rsrc(a.C, 0, -1 /* 2^32 - 1 bytes: the host checks the matrix is smaller */, 0x00020000);
+}
+__device__ __forceinline__ void store_c16(const GemmArgs& a, __amdgpu_buffer_rsrc_t rc, int64_t off, u32x4 v) {
+  if (a.cpol == 1) __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(unsigned)(off * 2), 0, 16);
+  else *(u32x4*)((bf16_t*)a.C + off) = v;
+}
+
 template <int MI>
 __device__ __forceinline__ void stage_rows32(const f32x16 (&acc)[MI][2], int i, float* stg, int lane) {
   const int r = lane & 31, h = lane >> 5;
@@ -140,6 +181,149 @@ __device__ __forceinline__ void stage_rows32(const f32x4 (&acc)[2 * MI][4], int 
     for (int j = 0; j < 4; ++j) *(f32x4*)(stg + (ii * 16 + c) * 68 + j * 16 + 4 * g) = acc[2 * i + ii][j];
 }
 
+// ---- register epilogue (round 4) ----------------------------------------------------------------------------------
+// The LDS-staged epilogue above needs 8.5 KB of LDS per wave, i.e. the stage buffers: nothing can be prefetched into them while
+// it runs, and its write -> wait -> read -> wait -> VALU -> store chains take 13 k cycles of a lone block's life with the
+// softmax-numerator epilogue (tools/phases.py, profiles/r04a_phases_*.log).  This form keeps everything in registers: the element-wise part (bias, ReLU, row scale,
+// exp2) runs on the accumulators where they are -- lane (c = lane & 15, g = lane >> 4) holds C[row 16 t + c][16 j + 4 g + {0..3}]
+// of the wave tile -- the results are packed to bf16 (P[j][0..1]: the 4-column chunk 4 j + g of the 16 chunks of a row) and ONE
+// round of row swaps, v_permlane16_swap (odd 16-lane rows of the first operand <-> even rows of the second) on (P[0], P[1]) and
+// (P[2], P[3]), leaves lane group g with chunks {2p, 2p+1} and {8+2p, 8+2p+1}, p = 0, 2, 1, 3 for g = 0..3: two 16-B pieces of
+// its row, and the four lane groups of a row write 64 contiguous bytes per store instruction.  (The full 4 x 4 transpose --
+// a v_permlane32_swap round first, 32 contiguous bytes per lane -- stores alternating 16-B pieces per instruction and measured
+// 10 % SLOWER than the LDS form: the co-resident blocks' DMA loads share the memory path with those stores, r04b_kbench_k512.log.)
+// No LDS, no waits, the 2 MI row tiles of a wave are independent chains.  The ReLU mask of the FFN-2 input gradient is applied
+// to the ROUNDED values after the transpose (a select commutes with rounding: bit-identical) from two 16-B loads of the
+// lane's own 16 columns.  The residual epilogues (fp32 add before rounding) keep the LDS form.  bf16 outputs are bit-identical
+// to the LDS form; the softmax row-sum partials add the same 64 fp32 exponentials in a different (fixed) order.
+// Where it is used: the persistent 256x256 kernel (gemm_nt8p_kernel), whose stage buffers must stay free for the next tile's
+// prefetch.  In the one-tile-per-block kernels it measured equal (vocabulary projection) to 6-18 % SLOWER (QKV, FFN-1, FFN-2
+// input gradient: profiles/r04c_kbench_k512.log, step 16.35 -> 16.50 ms): a lone block's plain epilogue takes 4.8 k cycles in
+// both forms -- it is bound by the 64 KB of stores (~14 B / clk / CU), not by the LDS round trips -- and with three blocks per CU
+// a shorter epilogue only moves the wait into the DMA-bound k-steps (2008 -> 2415 cycles per k-step).  Those kernels keep the
+// LDS form, whose stores are whole 128-B lines.
+template <int FLAGS>
+constexpr bool epi_regs_ok = !(FLAGS & DMI_GEMM_OUT_F32);
+
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap16(unsigned& a, unsigned& b) {   // a: rows 1, 3 <-> b: rows 0, 2 (16-lane rows)
+  const u32x2v r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+// keep the bf16 halves of `v` whose counterpart in `src` (packed bf16) is > 0  (DMI_GEMM_RELU_MASK)
+__device__ __forceinline__ unsigned relu_mask2(unsigned v, unsigned src) {
+  const unsigned lo = (__uint_as_float(src << 16) > 0.f) ? 0x0000ffffu : 0u;
+  const unsigned hi = (__uint_as_float(src & 0xffff0000u) > 0.f) ? 0xffff0000u : 0u;
+  return v & (lo | hi);
+}
+
+template <int FLAGS, int NT>     // NT = 16-row tiles of the wave tile (its width is 64 columns)
+__device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&acc)[NT][4], int lane, int mrow0, int ncol0) {
+  const int c16 = lane & 15, g16 = lane >> 4;
+  constexpr float LOG2E = 1.4426950408889634f;
+  float bias[4][4];
+  bool jok[4];   // column chunk 16 j + 4 g of the wave tile lies inside the matrix (N % 8 == 0: a chunk is whole or absent)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = ncol0 + 16 * j + 4 * g16;
+    jok[j] = n < a.N;
+    if constexpr (FLAGS & DMI_GEMM_BIAS) {
+      u32x2 raw = {0u, 0u};
+      if (jok[j]) raw = *(const u32x2*)(a.bias + n);
+      bias[j][0] = __uint_as_float(raw[0] << 16);
+      bias[j][1] = __uint_as_float(raw[0] & 0xffff0000u);
+      bias[j][2] = __uint_as_float(raw[1] << 16);
+      bias[j][3] = __uint_as_float(raw[1] & 0xffff0000u);
+      if constexpr (FLAGS & GEMM_SOFTMAX) {   // the bias rides in the exponent's fma
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bias[j][e] *= LOG2E;
+      }
+    }
+  }
+  const bool shifted = (FLAGS & GEMM_SOFTMAX) && a.rowshift != nullptr;   // wave-uniform
+  const __amdgpu_buffer_rsrc_t rc = c_rsrc(a);
+  // this lane's two 16-B pieces of its row: columns nst + {0..7} and nst + 32 + {0..7}; the four lane groups of a row cover
+  // pieces 0, 2, 1, 3 (+4): each store instruction writes 64 contiguous bytes per row
+  const int nst = ncol0 + 8 * (((g16 & 1) << 1) | (g16 >> 1));
+  const bool ok0 = nst < a.N, ok1 = nst + 32 < a.N;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int m = mrow0 + 16 * t + c16;
+    const bool mok = m < a.M;
+    const int64_t off = (int64_t)m * a.ldc + nst;
+    u32x2 rres[4];
+    if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {   // fp32 add before rounding: 8-B pieces in the accumulator layout
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        rres[j] = (mok && jok[j]) ? *(const u32x2*)(a.residual + (int64_t)m * a.ldc + ncol0 + 16 * j + 4 * g16) : u32x2{0u, 0u};
+    }
+    float rsc = 0.f;
+    if constexpr (FLAGS & DMI_GEMM_ROWSCALE) rsc = mok ? a.rowscale[m] : 0.f;
+    if constexpr (FLAGS & GEMM_SOFTMAX) rsc = (shifted && mok) ? a.rowshift[m] * LOG2E : 0.f;
+    u32x4 src0 = {0u, 0u, 0u, 0u}, src1 = {0u, 0u, 0u, 0u};
+    if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+      if (mok && ok0) src0 = *(const u32x4*)(a.relu_src + off);
+      if (mok && ok1) src1 = *(const u32x4*)(a.relu_src + off + 32);
+    }
+    unsigned P[4][2];
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[4] = {acc[t][j][0], acc[t][j][1], acc[t][j][2], acc[t][j][3]};
+      if constexpr ((FLAGS & DMI_GEMM_BIAS) && !(FLAGS & GEMM_SOFTMAX)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bias[j][e];
+      }
+      if constexpr (FLAGS & DMI_GEMM_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {
+        v[0] += __uint_as_float(rres[j][0] << 16);
+        v[1] += __uint_as_float(rres[j][0] & 0xffff0000u);
+        v[2] += __uint_as_float(rres[j][1] << 16);
+        v[3] += __uint_as_float(rres[j][1] & 0xffff0000u);
+      }
+      if constexpr (FLAGS & DMI_GEMM_ROWSCALE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= rsc;
+      }
+      if constexpr (FLAGS & GEMM_SOFTMAX) {   // exp(v + bias - shift) as one fma + v_exp_f32 per element; the fp32 values feed the row sum
+        float pj = 0.f;
+        if (shifted) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], LOG2E, bias[j][e] - rsc)); pj += v[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[e], LOG2E, bias[j][e])); pj += v[e]; }
+        }
+        ps += jok[j] ? pj : 0.f;
+      }
+      P[j][0] = pack2bf(v[0], v[1]);
+      P[j][1] = pack2bf(v[2], v[3]);
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      swap16(P[0][d], P[1][d]);
+      swap16(P[2][d], P[3][d]);
+    }
+    u32x4 lo = {P[0][0], P[0][1], P[1][0], P[1][1]}, hi = {P[2][0], P[2][1], P[3][0], P[3][1]};
+    if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { lo[e] = relu_mask2(lo[e], src0[e]); hi[e] = relu_mask2(hi[e], src1[e]); }
+    }
+    if (mok && ok0) store_c16(a, rc, off, lo);
+    if (mok && ok1) store_c16(a, rc, off + 32, hi);
+    if constexpr (FLAGS & GEMM_SOFTMAX) {
+      // the four lane groups of a row hold its 64 columns: two fixed-order exchanges (deterministic), group 0 writes the
+      // row's partial to slot ncol0 / 64 of the [slots][M] table
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      if (g16 == 0 && mok && ncol0 < a.N) a.rowsum_part[(int64_t)(ncol0 >> 6) * a.M + m] = ps;
+    }
+  }
+}
+
 template <int FLAGS, int MI, class ACC>
 __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, ACC& acc, float* stg, int lane, int mrow0, int ncol0) {
   const int orow = lane >> 3, ocol = (lane & 7) * 8;
@@ -157,6 +341,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, ACC& acc, float
     }
   }
   const bool shifted = (FLAGS & GEMM_SOFTMAX) && a.rowshift != nullptr;   // wave-uniform
+  const __amdgpu_buffer_rsrc_t rc = c_rsrc(a);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     u32x4 rres[4], rsrc[4];
@@ -222,7 +407,7 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, ACC& acc, float
         }
         psum[it] = nok ? ps : 0.f;
       }
-      if (nok && m < a.M) *(u32x4*)((bf16_t*)a.C + (int64_t)m * a.ldc + n) = pack8(v);
+      if (nok && m < a.M) store_c16(a, rc, (int64_t)m * a.ldc + n, pack8(v));
     }
     if constexpr (FLAGS & GEMM_SOFTMAX) {
       // the 8 lanes of a row (lane & 7) hold its 64 columns: butterfly over xor 1, 2, 4 (fixed order -> deterministic),
@@ -301,43 +486,54 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
       glds16(rb, base + 16384 + i * 4096, vob[i], soff);
     }
   };
-  auto compute = [&](int st) {
+  // [r04] The k-step in buffer st as 8 groups of 4 MFMAs (group g: A fragment g & 3 of k-substep g >> 2 against the four B
+  // fragments).  The NEXT k-step's load into the other buffer goes out behind groups 0..3 (one A and one B piece each) instead
+  // of as a burst behind the barrier -- the four waves leave it together, and 32 LDS-DMA instructions in a row hold them in the
+  // address unit's queue with the matrix pipe idle (see gemm_nt8p_kernel).  Order pinned by sched_barrier(0); fragments
+  // requested two groups ahead of their first use.  Same k order as before: bit-identical results.
+  auto compute = [&](int st, int soff) {
     const char* cur = smem + st * 32768;
+    char* dst = smem + (st ^ 1) * 32768 + wid * 1024;
+    bf16x8 fb[2][4], fa[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[0][j] = *(const bf16x8*)(cur + offb[0] + j * 2048);
+    fa[0] = *(const bf16x8*)(cur + offa[0]);
+    fa[1] = *(const bf16x8*)(cur + offa[0] + 2048);
     MFMA_PRIO(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
+    for (int g = 0; g < 8; ++g) {
+      const int ks = g >> 2, i = g & 3;
+      if (g + 2 < 8) fa[g + 2] = *(const bf16x8*)(cur + offa[(g + 2) >> 2] + ((g + 2) & 3) * 2048);
+      if (g == 1) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *(const bf16x8*)(cur + offa[ks] + i * 2048);
-        fb[i] = *(const bf16x8*)(cur + offb[ks] + i * 2048);
+        for (int j = 0; j < 4; ++j) fb[1][j] = *(const bf16x8*)(cur + offb[1] + j * 2048);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[g], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+      if (g < 4) {
+        glds16(ra, dst + g * 4096, voa[g], soff);
+        glds16(rb, dst + 16384 + g * 4096, vob[g], soff);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     MFMA_PRIO(0);
   };
 
+  // every k-step loads the next one; the LAST k-step of the tile re-loads k-step 0 into the idle buffer (read by nobody, landed
+  // before the epilogue re-uses the buffers: one code path for every k-step keeps the accumulators out of branch merges)
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int t = 0;
-  for (; t + 2 <= nt; t += 2) {
-    if (t + 1 < nt) stage(1, (t + 1) * BK * 2);
-    compute(0);
+  for (int t = 0; t < nt; t += 2) {
+    compute(0, (t + 1 < nt ? t + 1 : 0) * BK * 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 2 < nt) stage(0, (t + 2) * BK * 2);
-    compute(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  if (t < nt) {  // odd tail (stage 0 holds it)
-    compute(0);
-    __syncthreads();
+    if (t + 1 < nt) {
+      compute(1, (t + 2 < nt ? t + 2 : 0) * BK * 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
@@ -370,8 +566,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
 // 64-B LDS rows (4 chunks of 16 B): chunk ^= (-(row >> 2)) & 3.  A ds_read_b128 of the 16x16x32 fragments is served in lane groups
 // {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} (+32): rows 0-3 and 12-15 with chunk g, rows 4-11 with chunk g + 1 -- the row-quad map
 // 0, 3, 2, 1 puts those four (row quad, chunk) pairs on four different 64-B columns of the 256-B bank row: conflict-free.
-__device__ __forceinline__ int lds4_swz(int row) { return (-(row >> 2)) & 3; }
-__device__ __forceinline__ int lds4_off(int row, int ch) { return row * 64 + ((ch ^ lds4_swz(row)) << 4); }
 
 template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
@@ -455,12 +649,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   if (a.dbg) t2 = __builtin_readcyclecounter();
 
   epilogue_bf16<FLAGS, 4>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 128, n0 + wn * 64);
-  if (a.dbg && tid == 0) {  // {start, after prologue, after main loop, end, hw id} of this block
+  if (a.dbg) {  // {start, after prologue, after main loop, stores issued, hw id, stores retired} of this block (wave 0's clock)
     const unsigned long long t3 = __builtin_readcyclecounter();  // stores issued, not necessarily retired
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    unsigned long long* d = a.dbg + (size_t)blockIdx.x * 5;
-    d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = hwid;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t4 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      unsigned long long* d = a.dbg + (size_t)blockIdx.x * 6;
+      d[0] = t0; d[1] = t1; d[2] = t2; d[3] = t3; d[4] = hwid; d[5] = t4;
+    }
   }
 }
 
@@ -526,42 +724,51 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
       glds16(rb, base + 32768 + i * 8192, vob[i], soff);
     }
   };
-  auto compute = [&](int st) {
+  // [r04] The k-step in buffer st as 16 groups of 4 MFMAs (group g: A fragment g & 7 of k-substep g >> 3 against the four B
+  // fragments).  DMA: behind group p = 0..7 goes piece p (0..3: A rows 64 p.., 4..7: B rows) of the NEXT k-step's load into the
+  // other buffer, instead of all eight as a burst behind the barrier (the eight waves leave it together and 64 LDS-DMA
+  // instructions in a row hold every wave in the address unit's queue with the matrix pipe idle -- see gemm_nt8p_kernel).
+  // Order pinned by sched_barrier(0); fragments requested two groups ahead of their first use.  Same k order as before.
+  auto compute = [&](int st, int soff) {
     const char* cur = smem + st * STG;
+    char* dst = smem + (st ^ 1) * STG + wid * 1024;
+    bf16x8 fb[2][4], fa[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[0][j] = *(const bf16x8*)(cur + offb[0] + j * 2048);
+    fa[0] = *(const bf16x8*)(cur + offa[0]);
+    fa[1] = *(const bf16x8*)(cur + offa[0] + 2048);
     MFMA_PRIO(1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[8], fb[4];
+    for (int g = 0; g < 16; ++g) {
+      const int ks = g >> 3, i = g & 7;
+      if (g + 2 < 16) fa[g + 2] = *(const bf16x8*)(cur + offa[(g + 2) >> 3] + ((g + 2) & 7) * 2048);
+      if (g == 5) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = *(const bf16x8*)(cur + offa[ks] + i * 2048);
+        for (int j = 0; j < 4; ++j) fb[1][j] = *(const bf16x8*)(cur + offb[1] + j * 2048);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(cur + offb[ks] + j * 2048);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[g], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+      if (g < 4) glds16(ra, dst + g * 8192, voa[g], soff);
+      else if (g < 8) glds16(rb, dst + 32768 + (g - 4) * 8192, vob[g - 4], soff);
+      __builtin_amdgcn_sched_barrier(0);
     }
     MFMA_PRIO(0);
   };
-
+  // every k-step loads the next one; the LAST k-step of the tile re-loads k-step 0 into the idle buffer (read by nobody, landed
+  // before the epilogue re-uses the buffers: one code path for every k-step keeps the accumulators out of branch merges)
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int t = 0;
-  for (; t + 2 <= nt; t += 2) {
-    if (t + 1 < nt) stage(1, (t + 1) * BK * 2);
-    compute(0);
+  for (int t = 0; t < nt; t += 2) {
+    compute(0, (t + 1 < nt ? t + 1 : 0) * BK * 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t + 2 < nt) stage(0, (t + 2) * BK * 2);
-    compute(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  if (t < nt) {  // odd tail (stage 0 holds it)
-    compute(0);
-    __syncthreads();
+    if (t + 1 < nt) {
+      compute(1, (t + 2 < nt ? t + 2 : 0) * BK * 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
   }
 
   if constexpr (FLAGS & DMI_GEMM_OUT_F32) {
@@ -578,6 +785,390 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
     }
   } else {
     epilogue_bf16<FLAGS, 4>(a, acc, (float*)(smem + wid * 8704), lane, m0 + wm * 128, n0 + wn * 64);
+  }
+}
+
+// =====================================================================================
+// NT kernel v8p (round 4): the 256x256x64 / 8-wave tile of v8 as a PERSISTENT kernel for the short-K products (K = 512:
+// QKV, FFN-1, FFN-2 input gradient, vocabulary projection), one block per CU looping over its tiles.
+// Why: the LDS-DMA path delivers ~36 B / clk / CU from L2 (three co-resident 256x128 blocks move 72 KB per ~2000-cycle k-step,
+// tools/phases.py), so the 256x128 tile (48 B per MFMA-issue clock) cannot run the matrix pipe above ~75 % in its main loop and
+// the 128x128 tile (64 B) not above ~55 %; only this tile (32 B) fits.  What it lacked at K = 512 was overlap around its 8
+// k-steps (one block per CU: nothing hides the first tile load, the epilogue, the 128 KB of output stores) and inside them:
+//   * the register epilogue (epilogue_regs) needs no LDS, so the next tile's k-step 0 is loaded under this tile's LAST k-step
+//     and the next main loop starts right behind the epilogue; the epilogue's stores are not waited for -- the first wait that
+//     covers them is the vmcnt(0) at the end of the next tile's first k-step;
+//   * the eight 1-KB LDS-DMA pieces a wave issues per k-step go out BETWEEN the MFMA groups of the k-step that runs meanwhile,
+//     not as a burst behind the barrier: all eight waves leave the barrier together, and 64 LDS-DMA instructions in a row keep
+//     every wave in the queue of the CU's one address unit for ~1200 cycles with the matrix pipe idle (the one-tile kernels run
+//     4.1 k cycles per k-step against 2 k of MFMA issue per SIMD).
+// One buffer descriptor per operand for the whole kernel (based at the matrix origin, exact size: rows past M / N read as
+// zeros), tile and k position in the scalar offset: the per-lane offsets are tile-independent and "which tile does this load
+// belong to" is two scalar selects -- every k-step of every tile runs the same code.
+// Tiles: virtual block id v = blockIdx + i * gridDim (gridDim a multiple of 8, so v % 8 is this block's XCD) through the same
+// XCD remap + GROUP_M order as the one-tile-per-block kernels: the 32 CUs of an XCD work on 32 consecutive tiles of its list.
+// Same k order as every other NT kernel -> bit-identical results.  Needs K % 128 == 0 (a tile's k-steps alternate between the
+// two buffers and every tile must start in buffer 0), operands below 2 GiB, and an epilogue that has a register form.
+// =====================================================================================
+template <int FLAGS>
+__global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 32K | B 32K]
+  constexpr int STG = 65536;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int nt = a.K / BK;   // even
+
+  const int c16 = lane & 15, g16 = lane >> 4;
+  int offa[2], offb[2];    // per 32-wide k-substep: chunk 4 ks + g of row (tile base + c); tiles are 16 rows = 2048 B apart
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    offa[ks] = lds_chunk_off(wm * 128 + c16, ks * 4 + g16);
+    offb[ks] = 32768 + lds_chunk_off(wn * 64 + c16, ks * 4 + g16);
+  }
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)(((int64_t)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
+  int voa[4], vob[4];      // per-lane source offsets inside a tile (16-B chunk XOR-swizzled on the source side), tile-independent
+  {
+    const int chp = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 64 * i;
+      const int src_ch = chp ^ ((row >> 1) & 7);
+      voa[i] = (row * a.lda + 8 * src_ch) * 2;
+      vob[i] = (row * a.ldb + 8 * src_ch) * 2;
+    }
+  }
+
+  f32x4 acc[8][4];
+  // The k-step in buffer st as 16 groups of 4 MFMAs (group g: A fragment g & 7 of k-substep g >> 3 against the four B
+  // fragments); behind group p = 0..7 goes piece p (0..3: A rows 64 p.., 4..7: B rows) of the load into the OTHER buffer -- the
+  // second substep's groups cover the landing of the last pieces.  The order is pinned with sched_barrier(0) between the groups
+  // (left alone, hipcc clusters the DMAs again) and the fragment reads are software-pipelined by hand: the A fragment of group
+  // g + 2 and, in group 5, the second substep's B fragments are requested two groups ahead of their first use.
+  auto compute = [&](int st, int sa, int sb) {   // sa / sb: byte offsets (tile origin + k) of the A / B rows being loaded
+    const char* cur = smem + st * STG;
+    char* dst = smem + (st ^ 1) * STG + wid * 1024;
+    bf16x8 fb[2][4], fa[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[0][j] = *(const bf16x8*)(cur + offb[0] + j * 2048);
+    fa[0] = *(const bf16x8*)(cur + offa[0]);
+    fa[1] = *(const bf16x8*)(cur + offa[0] + 2048);
+    MFMA_PRIO(1);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int ks = g >> 3, i = g & 7;
+      if (g + 2 < 16) fa[g + 2] = *(const bf16x8*)(cur + offa[(g + 2) >> 3] + ((g + 2) & 7) * 2048);
+      if (g == 5) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[1][j] = *(const bf16x8*)(cur + offb[1] + j * 2048);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[g], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+      if (g < 4) glds16(ra, dst + g * 8192, voa[g], sa);
+      else if (g < 8) glds16(rb, dst + 32768 + (g - 4) * 8192, vob[g - 4], sb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MFMA_PRIO(0);
+  };
+
+  int v = blockIdx.x;
+  if (v >= ntiles) return;
+  int tm, tn;
+  tile_of_block(xcd_remap(v, ntiles), a.tiles_m, a.tiles_n, tm, tn);
+  int m0 = tm * BM8, n0 = tn * BN8;
+  {   // first tile only: nothing to hide its first k-step behind
+    char* base = smem + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(ra, base + i * 8192, voa[i], m0 * a.lda * 2);
+      glds16(rb, base + 32768 + i * 8192, vob[i], n0 * a.ldb * 2);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  unsigned long long c_main = 0, c_epi = 0, c_first = 0, c_start = 0;   // tools/phases.py: per-block phase totals (a.dbg only)
+  int ntl = 0;
+  if (a.dbg) c_start = __builtin_readcyclecounter();
+  while (true) {
+    // on entry: k-step 0 of this tile has landed in buffer 0 (every wave waited for its pieces, then the barrier)
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    if (a.dbg) s0 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < ntiles;       // block-uniform
+    int nm0 = m0, nn0 = n0;                  // the last tile of a block re-loads its own k-step 0 into the idle buffer: harmless
+    if (has_next) {
+      int tm2, tn2;
+      tile_of_block(xcd_remap(vn, ntiles), a.tiles_m, a.tiles_n, tm2, tn2);
+      nm0 = tm2 * BM8; nn0 = tn2 * BN8;
+    }
+    const int ca = m0 * a.lda * 2, cb = n0 * a.ldb * 2;        // this tile's origin in A / B (bytes)
+    const int na = nm0 * a.lda * 2, nb = nn0 * a.ldb * 2;      // the next tile's
+    for (int t = 0; t < nt; t += 2) {
+      // k-step t in buffer 0 while k-step t+1 loads into buffer 1
+      compute(0, ca + (t + 1) * BK * 2, cb + (t + 1) * BK * 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // t = 0 of a later tile: also the previous tile's output stores
+      __syncthreads();
+      if (a.dbg && t == 0) c_first += __builtin_readcyclecounter() - s0;
+      // k-step t+1 in buffer 1 while k-step t+2 -- or the NEXT tile's k-step 0 -- loads into buffer 0
+      const bool last = t + 2 >= nt;
+      compute(1, last ? na : ca + (t + 2) * BK * 2, last ? nb : cb + (t + 2) * BK * 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (a.dbg) s1 = __builtin_readcyclecounter();
+    epilogue_regs<FLAGS, 8>(a, acc, lane, m0 + wm * 128, n0 + wn * 64);
+    if (a.dbg) { s2 = __builtin_readcyclecounter(); c_main += s1 - s0; c_epi += s2 - s1; ++ntl; }
+    if (!has_next) break;
+    v = vn; m0 = nm0; n0 = nn0;
+  }
+  if (a.dbg && tid == 0) {   // {life, main loops, epilogues (issue), first k-steps, tiles} of this block
+    unsigned long long* d = a.dbg + (size_t)blockIdx.x * 6;
+    d[0] = __builtin_readcyclecounter() - c_start; d[1] = c_main; d[2] = c_epi; d[3] = c_first; d[4] = (unsigned long long)ntl; d[5] = 0;
+  }
+}
+
+// =====================================================================================
+// NT kernel v8q: v8p with a deeper load pipeline -- k-steps of 32 in FOUR 32-KiB buffers (A 256 rows x 64 B | B 256 rows x 64 B,
+// the 64-B-row swizzle of the 256x128 kernel), the load of k-step s + PD issued under k-step s (PD = 2 or 3 k-steps = 2-3 k
+// cycles of cover) and waited for with a COUNTED vmcnt: the pieces of the youngest PD - 1 k-steps stay in flight across the
+// barrier.  v8p loads one 64-wide k-step ahead: where the weight matrix streams from the Infinity Cache / HBM (vocabulary
+// projection: 52 MB) a load does not land within the 2 k cycles of the k-step it hides behind and every k-step ends in a
+// wait (4.0 k cycles per k-step against 3.0 k with an L2-resident weight matrix, tools/phases.py).
+// =====================================================================================
+template <int FLAGS, int PD>
+__global__ __launch_bounds__(512, 2) void gemm_nt8q_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 buffers][A 16K | B 16K]
+  constexpr int BUF = 32768;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int ns = a.K / 32;   // k-steps per tile, a multiple of 4
+
+  const int c16 = lane & 15, g16 = lane >> 4;
+  const int offa = lds4_off(wm * 128 + c16, g16);            // 16-row tiles are 1024 B apart
+  const int offb = 16384 + lds4_off(wn * 64 + c16, g16);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)(((int64_t)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
+  int voa[2], vob[2];      // per-lane source offsets inside a tile, tile-independent: chunk c = tid + 512 i -> row c / 4, 16-B piece c % 4
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 512 * i, row = c >> 2, pc = c & 3;
+    voa[i] = (row * a.lda + 8 * (pc ^ lds4_swz(row))) * 2;
+    vob[i] = (row * a.ldb + 8 * (pc ^ lds4_swz(row))) * 2;
+  }
+  auto load = [&](int buf, int sa, int sb) {   // a whole k-step at once (first tile only)
+    char* dst = smem + buf * BUF + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      glds16(ra, dst + i * 8192, voa[i], sa);
+      glds16(rb, dst + 16384 + i * 8192, vob[i], sb);
+    }
+  };
+
+  f32x4 acc[8][4];
+  // k-step in buffer `buf` as 8 groups of 4 MFMAs (A fragment g against the four B fragments); behind groups 0..3 go the four
+  // 1-KB pieces of the load into buffer `nbuf`; order pinned by sched_barrier(0), fragments requested two groups ahead
+  auto compute = [&](int buf, int nbuf, int sa, int sb) {
+    const char* cur = smem + buf * BUF;
+    char* dst = smem + nbuf * BUF + wid * 1024;
+    bf16x8 fb[4], fa[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(cur + offb + j * 1024);
+    fa[0] = *(const bf16x8*)(cur + offa);
+    fa[1] = *(const bf16x8*)(cur + offa + 1024);
+    MFMA_PRIO(1);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g + 2 < 8) fa[g + 2] = *(const bf16x8*)(cur + offa + (g + 2) * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[g], acc[g][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+      if (g < 2) glds16(ra, dst + g * 8192, voa[g], sa);
+      else if (g < 4) glds16(rb, dst + 16384 + (g - 2) * 8192, vob[g - 2], sb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MFMA_PRIO(0);
+  };
+
+  int v = blockIdx.x;
+  if (v >= ntiles) return;
+  int tm, tn;
+  tile_of_block(xcd_remap(v, ntiles), a.tiles_m, a.tiles_n, tm, tn);
+  int m0 = tm * BM8, n0 = tn * BN8;
+#pragma unroll
+  for (int s = 0; s < PD; ++s) load(s, m0 * a.lda * 2 + s * 64, n0 * a.ldb * 2 + s * 64);   // first tile only: k-steps 0 .. PD-1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  unsigned long long c_main = 0, c_epi = 0, c_first = 0, c_start = 0;   // tools/phases.py: per-block phase totals (a.dbg only)
+  int ntl = 0;
+  if (a.dbg) c_start = __builtin_readcyclecounter();
+  while (true) {
+    // on entry: k-step 0 of this tile has landed in buffer 0; k-steps 1 .. PD-1 are landed or in flight in buffers 1 .. PD-1
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    if (a.dbg) s0 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < ntiles;       // block-uniform
+    int nm0 = m0, nn0 = n0;                  // the last tile of a block re-loads its own first k-steps into idle buffers: harmless
+    if (has_next) {
+      int tm2, tn2;
+      tile_of_block(xcd_remap(vn, ntiles), a.tiles_m, a.tiles_n, tm2, tn2);
+      nm0 = tm2 * BM8; nn0 = tn2 * BN8;
+    }
+    const int ca = m0 * a.lda * 2, cb = n0 * a.ldb * 2;        // this tile's origin in A / B (bytes)
+    const int na = nm0 * a.lda * 2, nb = nn0 * a.ldb * 2;      // the next tile's
+    for (int s = 0; s < ns; s += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // k-step s+u in buffer u while k-step s+u+PD (of this tile, or of the next one) loads into buffer (u + PD) % 4
+        const int q = s + u + PD;
+        const bool nxt = q >= ns;
+        const int kq = (nxt ? q - ns : q) * 64;
+        compute(u, (u + PD) & 3, (nxt ? na : ca) + kq, (nxt ? nb : cb) + kq);
+        // the 4 pieces of each of the youngest PD - 1 k-steps may stay in flight: k-step s+u+1 is the oldest of the rest
+        if constexpr (PD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if constexpr (PD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (a.dbg && s == 0 && u == 0) c_first += __builtin_readcyclecounter() - s0;
+      }
+    }
+    if (a.dbg) s1 = __builtin_readcyclecounter();
+    epilogue_regs<FLAGS, 8>(a, acc, lane, m0 + wm * 128, n0 + wn * 64);
+    if (a.dbg) { s2 = __builtin_readcyclecounter(); c_main += s1 - s0; c_epi += s2 - s1; ++ntl; }
+    if (!has_next) break;
+    v = vn; m0 = nm0; n0 = nn0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the idle re-loads of the last tile
+  if (a.dbg && tid == 0) {   // {life, main loops, epilogues (issue), first k-steps, tiles} of this block
+    unsigned long long* d = a.dbg + (size_t)blockIdx.x * 6;
+    d[0] = __builtin_readcyclecounter() - c_start; d[1] = c_main; d[2] = c_epi; d[3] = c_first; d[4] = (unsigned long long)ntl; d[5] = 0;
+  }
+}
+
+// =====================================================================================
+// NT kernel "row" (round 4): FULL-ROW tiles for the products with N = 512 outputs (out-projection, FFN-2, the three input
+// gradients that end in the residual stream).  Tile = (32 RT) rows x 512 columns, 8 waves as 2 (rows) x 4 (columns), wave tile
+// (16 RT) x 128 = RT x 8 MFMA tiles (RT = 5: 160 accumulator registers).  With M = 40960 rows and 256 CUs a tile of 160 rows
+// is exactly one tile per CU: no ragged residency, and 672 operand rows are loaded per 160 x 512 outputs -- 1 / 122 B per MAC
+// against 1 / 64 for the 128x128 tile these products ran on (the LDS-DMA path from L2 is what bounds the NT kernels, see
+// gemm_nt8p_kernel) and 1 / 128 for the 256x256 tile, which N = 512 cannot fill the chip with.  A block owning whole rows is
+// also what a fused LayerNorm needs (dmi_gemm_nt_ln).
+// k-steps of 32 in three 42-KiB buffers (A (32 RT) rows x 64 B | B 512 rows x 64 B, the 64-B-row swizzle), loads two k-steps
+// ahead with a counted vmcnt; the 42 1-KB pieces of a k-step are dealt round-robin to the 8 waves and go out between the
+// MFMA groups.  Same k order as every NT kernel -> bit-identical results.
+// =====================================================================================
+template <int FLAGS, int RT>
+__global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RM = 32 * RT;                 // rows per tile
+  constexpr int ABYTES = RM * 64;             // A part of a buffer (RT = 5: 10240)
+  constexpr int BUF = ABYTES + 32768;
+  constexpr int NPA = RM / 16;                // 1-KB pieces of A per k-step (16 rows each)
+  constexpr int NP = NPA + 32;                // + B
+  constexpr int PW = (NP + 7) / 8;            // pieces per wave (the last round is partial)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 2, wn = wid & 3;
+  const int m0 = blockIdx.x * RM;
+  const int ns = a.K / 32;
+
+  const int c16 = lane & 15, g16 = lane >> 4;
+  const int offa = lds4_off(wm * (RM / 2) + c16, g16);                // 16-row tiles are 1024 B apart
+  const int offb = ABYTES + lds4_off(wn * 128 + c16, g16);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda), 0,
+                                                                       (int)(((int64_t)(a.M - 1 - m0) * a.lda + a.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
+  // piece p = wid + 8 q of a k-step: p < NPA -> A rows 16 p .., else B rows 16 (p - NPA) ..; this lane's chunk = row 16 p' + lane / 4, 16-B piece lane % 4
+  int vo[PW];
+#pragma unroll
+  for (int q = 0; q < PW; ++q) {
+    const int p = wid + 8 * q;
+    const bool isa = p < NPA;
+    const int row = 16 * (isa ? p : p - NPA) + (lane >> 2), pc = lane & 3;
+    vo[q] = (row * (isa ? a.lda : a.ldb) + 8 * (pc ^ lds4_swz(row))) * 2;
+  }
+  auto piece = [&](int buf, int q, int soff) {
+    const int p = wid + 8 * q;             // wave-uniform
+    if (p >= NP) return;
+    char* dst = smem + buf * BUF + (p < NPA ? p * 1024 : ABYTES + (p - NPA) * 1024);
+    if (p < NPA) glds16(ra, dst, vo[q], soff);
+    else glds16(rb, dst, vo[q], soff);
+  };
+
+  f32x4 acc[RT][8];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // k-step in buffer `buf`: RT groups of 8 MFMAs (A fragment i against the eight B fragments); behind the groups go the pieces
+  // of the load into buffer `nbuf`
+  auto compute = [&](int buf, int nbuf, int soff) {
+    const char* cur = smem + buf * BUF;
+    bf16x8 fb[8], fa[RT];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) fb[j] = *(const bf16x8*)(cur + offb + j * 1024);
+    fa[0] = *(const bf16x8*)(cur + offa);
+    if (RT > 1) fa[1] = *(const bf16x8*)(cur + offa + 1024);
+    MFMA_PRIO(1);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+      if (i + 2 < RT) fa[i + 2] = *(const bf16x8*)(cur + offa + (i + 2) * 1024);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
+#pragma unroll
+      for (int q = 2 * i; q < 2 * i + 2; ++q)
+        if (q < PW) piece(nbuf, q, soff);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    MFMA_PRIO(0);
+  };
+
+  // prologue: k-steps 0 and 1
+#pragma unroll
+  for (int q = 0; q < PW; ++q) piece(0, q, 0);
+#pragma unroll
+  for (int q = 0; q < PW; ++q) piece(1, q, ns > 1 ? 64 : 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  // k-step s in buffer s % 3 while k-step s + 2 loads into buffer (s + 2) % 3 (past the end: k-step 0 again, read by nobody);
+  // the pieces of k-step s + 2 may stay in flight across the barrier, those of s + 1 must have landed: every wave issued PW
+  // pieces (or PW - 1) per k-step -> vmcnt(PW - 1) is conservative for both
+  for (int s = 0; s < ns; s += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (s + u < ns) {
+        const int q = s + u + 2;
+        compute(u, (u + 2) % 3, (q < ns ? q : 0) * 64);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW - 1) : "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {   // the register epilogue works on 64-column halves of the wave tile
+    f32x4 lo[RT][4], hi[RT][4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lo[i][j] = acc[i][j]; hi[i][j] = acc[i][j + 4]; }
+    epilogue_regs<FLAGS, RT>(a, lo, lane, m0 + wm * (RM / 2), wn * 128);
+    epilogue_regs<FLAGS, RT>(a, hi, lane, m0 + wm * (RM / 2), wn * 128 + 64);
   }
 }
 
@@ -756,6 +1347,17 @@ __global__ __launch_bounds__(64 * SK_WAVES) void gemm_ln_nt_skinny_kernel(const 
   }
 }
 
+static int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n < 8) n = 256;
+  }
+  return n;
+}
+
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
@@ -763,6 +1365,46 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     if (g_opt_skinny && a.M <= 32 && nsplit == 1 && a.N % 16 == 0) {
       gemm_nt_skinny_kernel<FLAGS><<<dim3(a.N / 16), dim3(64 * SK_WAVES), 0, st>>>(a);
       DMI_CHECK_LAUNCH("gemm_nt_skinny");
+      return DMI_OK;
+    }
+  }
+  if constexpr (epi_regs_ok<FLAGS> && !(FLAGS & GEMM_SOFTMAX)) {
+    // full-row tiles: N = 512 exactly, one 160-row tile per block
+    if (g_opt_ntr && a.N == 512 && nsplit == 1 && a.k_per_split == a.K && a.K % 32 == 0 && (int64_t)a.N * a.ldb < (1 << 30) &&
+        (g_opt_ntr == 2 || (a.M >= 160 * (num_cus() / 2) && a.K <= 4096))) {   // (the head's input gradient, K = 50816: 1.83 ms here vs 1.32 ms on 256x256 tiles)
+      constexpr int RT = 5;
+      constexpr int LDSB = 3 * (32 * RT * 64 + 32768);
+      static bool attrr = false;
+      if (!attrr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<FLAGS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attrr = true; }
+      gemm_ntr_kernel<FLAGS, RT><<<dim3((a.M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, st>>>(a);
+      DMI_CHECK_LAUNCH("gemm_ntr");
+      return DMI_OK;
+    }
+  }
+  if constexpr (epi_regs_ok<FLAGS>) {
+    // persistent 256x256 tiles: short-K products with at least two tiles per CU (see gemm_nt8p_kernel)
+    const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
+    const bool can = nsplit == 1 && a.k_per_split == a.K && a.K % 128 == 0 && (int64_t)a.M * a.lda < (1 << 30) && (int64_t)a.N * a.ldb < (1 << 30);
+    // auto: not the ReLU-mask epilogue (its per-row-tile loads of the mask source sit exposed in front of the stores: 130 vs 124 us on
+    // the FFN-2 input gradient, profiles/r04f_kbench_k512.log)
+    if (can && ((g_opt_nt8p == 1 && a.K <= g_opt_nt8p_max_k && t8m * t8n >= 2 * num_cus() && !(FLAGS & DMI_GEMM_RELU_MASK)) || g_opt_nt8p == 2)) {
+      static bool attr8p = false;
+      if (!attr8p) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8p = true; }
+      GemmArgs b = a;
+      b.tiles_m = t8m; b.tiles_n = t8n;
+      if (g_opt_nt8p_pd == 1) {
+        gemm_nt8p_kernel<FLAGS><<<dim3(num_cus() & ~7), dim3(512), 131072, st>>>(b);
+      } else {
+        static bool attr8q = false;
+        if (!attr8q) {
+          (void)hipFuncSetAttribute((const void*)gemm_nt8q_kernel<FLAGS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+          (void)hipFuncSetAttribute((const void*)gemm_nt8q_kernel<FLAGS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+          attr8q = true;
+        }
+        if (g_opt_nt8p_pd == 2) gemm_nt8q_kernel<FLAGS, 2><<<dim3(num_cus() & ~7), dim3(512), 131072, st>>>(b);
+        else gemm_nt8q_kernel<FLAGS, 3><<<dim3(num_cus() & ~7), dim3(512), 131072, st>>>(b);
+      }
+      DMI_CHECK_LAUNCH("gemm_nt8p");
       return DMI_OK;
     }
   }
@@ -784,11 +1426,11 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     const int tiles4 = ((a.M + BM4 - 1) / BM4) * a.tiles_n;
     // 256x128 tiles when the grid still covers >= 3 residencies; long-K shapes prefer the BK = 64 kernel.  2 = force (tests)
     if (g_opt_nt4 && nsplit == 1 && a.k_per_split == a.K && ((tiles4 >= 1536 && a.K <= 1024) || g_opt_nt4 == 2)) {
-      static bool attr4 = false;
-      if (!attr4) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 49152); attr4 = true; }
+      static int attr4 = 0;
+      if (attr4 != g_opt_nt4_lds) { (void)hipFuncSetAttribute((const void*)gemm_nt4_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, g_opt_nt4_lds); attr4 = g_opt_nt4_lds; }
       GemmArgs b = a;
       b.tiles_m = (a.M + BM4 - 1) / BM4;
-      gemm_nt4_kernel<FLAGS><<<dim3(tiles4), blk, 49152, st>>>(b);
+      gemm_nt4_kernel<FLAGS><<<dim3(tiles4), blk, g_opt_nt4_lds, st>>>(b);
       DMI_CHECK_LAUNCH("gemm_nt4");
       return DMI_OK;
     }
@@ -814,6 +1456,8 @@ static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr;
+  const int64_t cbytes = ((int64_t)(M - 1) * ldc + N) * 2;     // bf16 outputs (the fp32 forms do not use the policy)
+  a.cpol = (cbytes < (int64_t)0xffffffff && (g_opt_cstream == 2 || (g_opt_cstream == 1 && cbytes >= ((int64_t)g_opt_cstream_min_mb << 20)))) ? 1 : 0;
 }
 
 extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc, int M, int N,
@@ -1867,7 +2511,7 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.M = (int)Ml; a.N = N; a.K = ntaps * C; a.lda = (int)xbytes /* descriptor size */; a.ldb = ldw; a.ldc = ldc;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr;
-  a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr;
+  a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr; a.cpol = 0;
   ConvGeom g;
   g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = 0; g.lh = 0;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }

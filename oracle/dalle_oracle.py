@@ -186,9 +186,24 @@ def _rbw(x: torch.Tensor, bf16) -> torch.Tensor:
     produces (bf16 rounding of a gradient tensor costs 1.6e-3 relative L2)."""
     if not bf16:
         return x
-    if bf16 == "fp32w":
+    if isinstance(bf16, str) and "fp32w" in bf16:
         return x + (x.to(torch.bfloat16).to(torch.float32) - x).detach()
     return _rb(x, bf16)
+
+
+class _RoundGradOnly(torch.autograd.Function):
+    """identity in the forward, bf16 rounding of the gradient in the backward.  Mode "...+ds" places it on the attention
+    logits: the reference computes the logits einsum and its gradient in fp32 (float32_logits, Appendix A.3), a matrix-core
+    implementation feeds dS = P (dP - delta) to the dQ / dK products as a bf16 operand.  Used only to ATTRIBUTE the remaining
+    difference of the q / k weight gradients under teacher forcing (tests/test_headline_parity_gpu.py)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
 
 
 def _force(force, name: str, computed: torch.Tensor) -> torch.Tensor:
@@ -230,9 +245,17 @@ def attention(x, wq, wk, wv, wo, o_b, n_heads, mask, bf16=False, force=None, sit
     kk = _force(force, site + "k", _rb(x @ wk, bf16)).view(B, S, n_heads, k).transpose(1, 2)
     v = _force(force, site + "v", _rb(x @ wv, bf16)).view(B, S, n_heads, k).transpose(1, 2)
     logits = q @ kk.transpose(-1, -2)                              # fp32, no 1/sqrt(k)
+    if isinstance(bf16, str) and "ds" in bf16:
+        logits = _RoundGradOnly.apply(logits)
     logits = logits + mask
     w = torch.exp(logits - torch.logsumexp(logits, dim=-1, keepdim=True))
-    w = _rb(w, bf16)                                               # "cast to v dtype" (A.3)
+    if isinstance(bf16, str) and "dp32" in bf16:
+        # attribution mode: P rounded to bf16 in the forward, its gradient dP = dO V^T NOT rounded (a flash-style kernel keeps
+        # dP in the fp32 accumulators; the reference's bf16 einsum rounds it).  dS = P (dP - sum_j P dP) cancels heavily when
+        # dP varies little over the keys, so that rounding can dominate the q / k gradients of a layer.
+        w = w + (w.to(torch.bfloat16).to(torch.float32) - w).detach()
+    else:
+        w = _rb(w, bf16)                                           # "cast to v dtype" (A.3)
     a = _rb(w @ v, bf16)                                           # [B,H,S,k]
     a = _force(force, site + "a", a.transpose(1, 2).reshape(B, S, d))
     return _rb(a @ wo + o_b, bf16)

@@ -119,6 +119,15 @@ def _rbw(x, bf16):
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def _force(force, name, computed):
+    """teacher forcing for backward-parity tests (see oracle/dalle_oracle.py _force): forward value = force[name] (the
+    activation the implementation under test stored), gradient = the oracle's"""
+    if force is None or name not in force:
+        return computed
+    f = torch.as_tensor(force[name], dtype=torch.float32).reshape(computed.shape)
+    return f + (computed - computed.detach())
+
+
 def conv2d_same(x_nhwc, kernel, bias, stride):
     """tf.layers.conv2d(padding='SAME') NHWC, kernel [kh,kw,Cin,Cout] (Appendix A.8).
     SAME: out = ceil(H/s); pad_total = max((out-1)*s + k - H, 0); before = total//2."""
@@ -158,9 +167,10 @@ def depth_to_space(x, r):
     return x.reshape(B, H * r, W * r, c)
 
 
-def encoder(P, img, cfg: VaeConfig):
+def encoder(P, img, cfg: VaeConfig, force=None):
     """v1: vae_tf/models.py:81-120.  Per block: conv 4x4 s2 SAME (no activation), then (stack-1) x
-    `x + conv3x3(relu(conv3x3(x)))`; then fp32 x @ codebook."""
+    `x + conv3x3(relu(conv3x3(x)))`; then fp32 x @ codebook.
+    force: optional {variable scope of a conv: its output} teacher forcing (conv_in: after the ReLU; conv_out: after the residual add)"""
     bf = cfg.use_bf16
     x = _rb(img, bf)
     if cfg.stack_factor > 1:
@@ -170,11 +180,12 @@ def encoder(P, img, cfg: VaeConfig):
             p = f"encoder/block_{b}/layer_{i}/"
             if i == 0:
                 x = _rb(conv2d_same(x, _rbw(P[p + "conv_downsample/kernel"], bf), _rbw(P[p + "conv_downsample/bias"], bf), 2), bf)
+                x = _force(force, p + "conv_downsample", x)
             else:
                 o = _rb(conv2d_same(x, _rbw(P[p + "conv_in/kernel"], bf), _rbw(P[p + "conv_in/bias"], bf), 1), bf)
-                o = torch.relu(o)
+                o = _force(force, p + "conv_in", torch.relu(o))
                 o = _rb(conv2d_same(o, _rbw(P[p + "conv_out/kernel"], bf), _rbw(P[p + "conv_out/bias"], bf), 1), bf)
-                x = _rb(x + o, bf)
+                x = _force(force, p + "conv_out", _rb(x + o, bf))
     return x @ P["codebook/codebook"]              # fp32 matmul, models.py:115-118
 
 
@@ -191,23 +202,25 @@ def gumbel_softmax(logits, u, temperature=1.0, hard=True):
     return y
 
 
-def decoder(P, x, cfg: VaeConfig):
+def decoder(P, x, cfg: VaeConfig, force=None):
     """v3: vae_tf/models.py:123-163.  x @ codebook^T (tied); per reversed block: conv-transpose 4x4 s2
     (no activation) then residual stacks; final 1x1 conv; fp32; depth_to_space."""
     bf = cfg.use_bf16
     x = x @ P["codebook/codebook"].t()
-    x = _rb(x, bf)
+    x = _force(force, "dec_in", _rb(x, bf))
     for b, (stack, ch) in enumerate(reversed(cfg.convblocks)):
         for i in range(stack):
             p = f"decoder/block_{b}/layer_{i}/"
             if i == 0:
                 x = _rb(conv2d_transpose_same(x, _rbw(P[p + "conv_upsample/kernel"], bf), _rbw(P[p + "conv_upsample/bias"], bf)), bf)
+                x = _force(force, p + "conv_upsample", x)
             else:
                 o = _rb(conv2d_same(x, _rbw(P[p + "conv_in/kernel"], bf), _rbw(P[p + "conv_in/bias"], bf), 1), bf)
-                o = torch.relu(o)
+                o = _force(force, p + "conv_in", torch.relu(o))
                 o = _rb(conv2d_same(o, _rbw(P[p + "conv_out/kernel"], bf), _rbw(P[p + "conv_out/bias"], bf), 1), bf)
-                x = _rb(x + o, bf)
+                x = _force(force, p + "conv_out", _rb(x + o, bf))
     x = _rb(conv2d_same(x, _rbw(P["decoder/conv2d/kernel"], bf), _rbw(P["decoder/conv2d/bias"], bf), 1), bf)
+    x = _force(force, "decoder/conv2d", x)
     if cfg.stack_factor > 1:
         x = depth_to_space(x, cfg.stack_factor)
     return x
@@ -219,13 +232,13 @@ def mse_loss(pred, target):
 
 
 def forward(P, img, cfg: VaeConfig, u=None, return_recon_loss=False, return_logits=False,
-            hard_gumbel=True, temperature=1.0):
+            hard_gumbel=True, temperature=1.0, force=None):
     """DiscreteVAE.forward vae_tf/models.py:165-184."""
-    logits = encoder(P, img, cfg)
+    logits = encoder(P, img, cfg, force)
     if return_logits:
         return logits
     y = gumbel_softmax(logits, u, temperature, hard_gumbel)
-    out = decoder(P, y, cfg)
+    out = decoder(P, y, cfg, force)
     if not return_recon_loss:
         return out
     return mse_loss(img, out), out
@@ -239,10 +252,10 @@ def temperature(step: int, params: dict) -> float:
     return float(params.get("temp", 1.0))
 
 
-def loss_and_grads(params_np, img_np, u_np, cfg: VaeConfig, hard=True, temp=1.0):
+def loss_and_grads(params_np, img_np, u_np, cfg: VaeConfig, hard=True, temp=1.0, force=None):
     P = OrderedDict((n, torch.tensor(a, requires_grad=True)) for n, a in params_np.items())
     loss, out = forward(P, torch.tensor(img_np), cfg, torch.tensor(u_np), return_recon_loss=True,
-                        hard_gumbel=hard, temperature=temp)
+                        hard_gumbel=hard, temperature=temp, force=force)
     loss.backward()
     grads = OrderedDict((n, p.grad.detach().numpy().copy()) for n, p in P.items())
     return float(loss.detach()), grads, out.detach().numpy()

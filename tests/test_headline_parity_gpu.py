@@ -16,7 +16,7 @@ BF16_ORACLE_GRAD_TOL = 0.034     # measured 0.0272 (profiles/r03_parity_dalle_ex
 # [r04] against the TEACHER-FORCED bf16 oracle (forward = the engine's own stored activations, backward = the oracle's
 # arithmetic, oracle/dalle_oracle.py _force): provisional bound, replaced by measured + 25 % once
 # profiles/r04_parity_dalle_example.json exists
-FORCED_ORACLE_GRAD_TOL = 0.015
+FORCED_ORACLE_GRAD_TOL = 0.022   # measured 0.0176 (layer_5/attn/k; every other tensor <= 0.0067) + 25 %
 DALLE_EXAMPLE = dict(n_embd=512, n_heads=4, n_layers=6, text_vocab=50258, image_vocab=512, T=256, P=1024)
 
 

@@ -307,6 +307,68 @@ def test_gemm_nt8_tile_256x256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "256x256 and 128x128 tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,N,K,flags", [(300, 256, 128, 0), (1000, 1160, 256, 1), (2100, 520, 384, 3), (515, 136, 128, 8),
+                                         (700, 264, 128, 32), (6000, 5000, 512, 0), (40960, 1536, 512, 0)])
+def test_gemm_nt8p_persistent_tile_256x256(M, N, K, flags):
+    """[r04] persistent 256x256 kernel with the register epilogue (forced): several tiles per block incl. M / N tails, one
+    tile per block, fewer tiles than blocks, every register-form epilogue -- bit-identical to the 128x128x64 kernel (same k
+    order; the register epilogue rounds the same fp32 values)."""
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias = rnd(N, seed=3)
+    hsrc = torch.relu(rnd(M, N, seed=5)) if flags & 8 else None
+    rs = torch.rand(M, generator=torch.Generator().manual_seed(6)) + 0.5
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, relu_src=hsrc.to(DEV) if flags & 8 else None,
+              rowscale=rs.to(DEV) if flags & 32 else None)
+    Ad, Bd = A.to(DEV), Bt.to(DEV)
+    outs = []
+    dh.set_option("nt4", 0)
+    dh.set_option("nt8", 0)
+    try:
+        for p8, pd in ((2, 1), (2, 2), (2, 3), (0, 1)):     # pd: loads 1 (two 64-wide buffers) / 2 / 3 (four 32-wide buffers) k-steps ahead
+            dh.set_option("nt8p", p8)
+            dh.set_option("nt8p_pd", pd)
+            C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, flags, **kw)
+            outs.append(C)
+    finally:
+        dh.set_option("nt8p", 1)
+        dh.set_option("nt8p_pd", 1)
+        dh.set_option("nt8", 1)
+        dh.set_option("nt4", 1)
+    if M * N <= 4_000_000:
+        ref = _gemm_ref(A, Bt, bias if flags & 1 else None, relu=bool(flags & 2), relu_src=hsrc)
+        if flags & 32:
+            ref = ref * rs[:, None]
+        close(outs[0], ref, 1.6e-2, 2e-2 * math.sqrt(K / 64), "gemm_nt nt8p")
+    for o in outs[:3]:
+        assert torch.equal(o, outs[3]), "persistent 256x256 and 128x128 tile kernels must be bit-identical"
+
+
+@pytest.mark.parametrize("M,K,flags", [(160, 64, 0), (1000, 192, 5), (2100, 512, 5), (40960, 1536, 0), (5000, 2048, 1), (333, 256, 4)])
+def test_gemm_ntr_full_row_tiles(M, K, flags):
+    """[r04] full-row 160x512 tiles (forced; N = 512): k-step counts of every residue mod 3 (three-buffer ring), an M tail,
+    bias / residual in the register epilogue -- bit-identical to the 128x128x64 kernel and equal to fp32 math on the same
+    bf16 operands."""
+    N = 512
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    kw = dict(bias=bias.to(DEV) if flags & 1 else None, residual=res.to(DEV) if flags & 4 else None)
+    Ad, Bd = A.to(DEV), Bt.to(DEV)
+    outs = []
+    try:
+        for ntr in (2, 0):
+            dh.set_option("ntr", ntr)
+            C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            dh.gemm_nt(Ad, K, Bd, K, C, N, M, N, K, flags, **kw)
+            outs.append(C)
+    finally:
+        dh.set_option("ntr", 1)
+    if M * N <= 4_000_000:
+        ref = _gemm_ref(A, Bt, bias if flags & 1 else None, residual=res if flags & 4 else None)
+        close(outs[0], ref, 1.6e-2, 2e-2 * math.sqrt(max(K, 64) / 64), "gemm_nt ntr")
+    assert torch.equal(outs[0], outs[1]), "full-row and 128x128 tile kernels must be bit-identical"
+
+
 def test_gemm_nt8_splitk_rowscale():
     """the head input-gradient form: long K split in 4, 256x256 tiles (auto: 4 x 64 tiles = 256 blocks), row scale in the reduce"""
     M, N, K = 2048, 2048, 4096 * 4
@@ -435,7 +497,7 @@ def _run_head(X, Wt, bias, labels, V, Vp, dz_scale, shift=True):
 
 
 @pytest.mark.parametrize("shift", [False, True])
-@pytest.mark.parametrize("nt4", [0, 2])
+@pytest.mark.parametrize("nt4", [0, 2, "nt8p", "nt8q"])
 @pytest.mark.parametrize("M,K,V", [(300, 128, 1000), (1024, 512, 5000), (77, 256, 777), (257, 64, 200)])
 def test_fused_softmax_head(M, K, V, nt4, shift):
     """label logit -> exp-epilogue GEMM -> finish: loss_rows = logsumexp - label logit, rowscale * E = dz_scale * (softmax -
@@ -443,11 +505,19 @@ def test_fused_softmax_head(M, K, V, nt4, shift):
     engine's mode) and with the label logit as shift."""
     X, Wt, bias, labels, Vp = _head_case(M, K, V, seed=M)
     dz_scale = 1.0 / M
-    dh.set_option("nt4", nt4)
+    if nt4 in ("nt8p", "nt8q"):
+        if K % 128:
+            pytest.skip("the persistent 256x256 kernel needs K % 128 == 0")
+        dh.set_option("nt8p", 2)
+        dh.set_option("nt8p_pd", 1 if nt4 == "nt8p" else 3)
+    else:
+        dh.set_option("nt4", nt4)
     try:
         zl, E, loss, rsc, rsb, Xs, flag = _run_head(X, Wt, bias, labels, V, Vp, dz_scale, shift)
     finally:
         dh.set_option("nt4", 1)
+        dh.set_option("nt8p", 1)
+        dh.set_option("nt8p_pd", 1)
     assert flag == 0
     z = X.float() @ Wt.float()[:V].t() + bias.float()[:V]
     lab = labels.long()

@@ -223,9 +223,15 @@ def test_vae_coco_whole_model_step_vs_both_oracles(coco):
                               noise=torch.from_numpy(u), need_grad=True)
     vae.backward()
     gh = vae.export_reference(vae.g)
-    for tag, bf in (("fp32", False), ("bf16", True), ("bf16_fp32w", "fp32w")):
+    # teacher forcing (oracle/vae_oracle.py _force): the oracle's forward takes the activations the engine stored for its own
+    # backward (every convolution's output: after the ReLU for conv_in, after the residual add for conv_out; the decoder's
+    # input), so the forward divergence of two bf16 implementations over 27 layers is gone and the backward chain is compared alone
+    sites = {"dec_in": vae.xdec.float().cpu().reshape(1, cfg.grid, cfg.grid, -1)}
+    for i, c in enumerate(vae.convs):
+        sites[c.name] = vae.act_out[i].float().cpu().reshape(1, c.Ho, c.Wo, -1)[..., :c.cout_ref].contiguous()
+    for tag, bf, force in (("fp32", False, None), ("bf16", True, None), ("bf16_fp32w", "fp32w", None), ("forced_bf16_fp32w", "fp32w", sites)):
         ocfg = vo.VaeConfig(cfg.num_tokens, 256, cfg.convblocks, use_bf16=bf)
-        loss_o, g_o, out_o = vo.loss_and_grads(P, img, u, ocfg, hard=False, temp=1.0)
+        loss_o, g_o, out_o = vo.loss_and_grads(P, img, u, ocfg, hard=False, temp=1.0, force=force)
         table = {k: float(np.linalg.norm(gh[k].astype(np.float64) - g_o[k]) / max(np.linalg.norm(g_o[k]), 1e-30)) for k in g_o}
         worst = max(table.items(), key=lambda t: t[1])
         rep[tag] = dict(loss_hip=float(loss), loss_oracle=loss_o, recon_max_err=float(np.abs(recon.cpu().numpy() - out_o).max()),
@@ -244,3 +250,5 @@ def test_vae_coco_whole_model_step_vs_both_oracles(coco):
     # [r04] (the bf16 oracle's backward tensors are bf16 too -- see oracle/dalle_oracle.py _RoundBF16Grad; "fp32w" keeps only the
     # weight gradients in fp32 as the engine does)
     assert rep["bf16_fp32w"]["worst_grad"][1] <= 0.14, rep["bf16_fp32w"]["worst_grad"]
+    # teacher-forced: provisional bound until measured (profiles/r04_parity_vae_coco_model.json)
+    assert rep["forced_bf16_fp32w"]["worst_grad"][1] <= 0.03, rep["forced_bf16_fp32w"]["worst_grad"]
