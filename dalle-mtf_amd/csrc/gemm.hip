@@ -106,6 +106,14 @@ struct GemmArgs {
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
   int cpol;                 // cache policy of the bf16 output stores: 0 plain, 1 sc1 (write-through, the line is not kept in the XCD's L2)
+  // fused LayerNorm of the output rows (dmi_gemm_nt_ln, full-row tiles only): Y = LN(C) * gamma + beta, row statistics
+  const bf16_t* ln_gamma;
+  const bf16_t* ln_beta;
+  bf16_t* ln_y;
+  float* ln_mean;
+  float* ln_rstd;
+  float ln_eps;
+  int ln_ldy;
 };
 #define GEMM_SOFTMAX 64   // internal epilogue flag of dmi_gemm_nt_softmax (not part of the public flag set)
 
@@ -246,6 +254,12 @@ __device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&a
   // pieces 0, 2, 1, 3 (+4): each store instruction writes 64 contiguous bytes per row
   const int nst = ncol0 + 8 * (((g16 & 1) << 1) | (g16 >> 1));
   const bool ok0 = nst < a.N, ok1 = nst + 32 < a.N;
+  u32x4 nsrc0 = {0u, 0u, 0u, 0u}, nsrc1 = {0u, 0u, 0u, 0u};
+  if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
+    const int m = mrow0 + c16;
+    if (m < a.M && ok0) nsrc0 = *(const u32x4*)(a.relu_src + (int64_t)m * a.ldc + nst);
+    if (m < a.M && ok1) nsrc1 = *(const u32x4*)(a.relu_src + (int64_t)m * a.ldc + nst + 32);
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int m = mrow0 + 16 * t + c16;
@@ -261,9 +275,14 @@ __device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&a
     if constexpr (FLAGS & DMI_GEMM_ROWSCALE) rsc = mok ? a.rowscale[m] : 0.f;
     if constexpr (FLAGS & GEMM_SOFTMAX) rsc = (shifted && mok) ? a.rowshift[m] * LOG2E : 0.f;
     u32x4 src0 = {0u, 0u, 0u, 0u}, src1 = {0u, 0u, 0u, 0u};
-    if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
-      if (mok && ok0) src0 = *(const u32x4*)(a.relu_src + off);
-      if (mok && ok1) src1 = *(const u32x4*)(a.relu_src + off + 32);
+    if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {   // mask source of THIS row tile: requested one row tile ahead (below), so that its
+      src0 = nsrc0; src1 = nsrc1;                 // latency sits behind the previous tile's arithmetic and stores
+      const int m2 = m + 16;
+      nsrc0 = u32x4{0u, 0u, 0u, 0u}; nsrc1 = u32x4{0u, 0u, 0u, 0u};
+      if (t + 1 < NT && m2 < a.M) {
+        if (ok0) nsrc0 = *(const u32x4*)(a.relu_src + off + (int64_t)16 * a.ldc);
+        if (ok1) nsrc1 = *(const u32x4*)(a.relu_src + off + (int64_t)16 * a.ldc + 32);
+      }
     }
     unsigned P[4][2];
     float ps = 0.f;
@@ -1071,7 +1090,131 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8q_kernel(GemmArgs a) {
 // ahead with a counted vmcnt; the 42 1-KB pieces of a k-step are dealt round-robin to the 8 waves and go out between the
 // MFMA groups.  Same k order as every NT kernel -> bit-identical results.
 // =====================================================================================
-template <int FLAGS, int RT>
+// Epilogue of the full-row kernel with a fused LayerNorm (reference src/dalle_mtf/models.py:330,333,373-389 + layers.py:30-33,
+// applied to the output of the product that feeds it: out-projection + residual -> norm_2, FFN-2 + residual -> the next
+// block's norm_1 / to_logits' norm):
+//   C = bf16(acc + bias + residual)                    (what the unfused path stores, then reads back)
+//   mean = sum(C) / 512;  rstd = rsqrt(sum((C - mean)^2) / 512 + eps)          (two passes over the ROUNDED row, as ln_fwd_kernel)
+//   Y = bf16((C - mean) * rstd * gamma + beta)
+// A row's 512 columns live in the four waves of a row group (128 each): per pass the lanes sum their 32 values, the four lane
+// groups combine by two cross-lane exchanges, the four waves through 2.5 KB of LDS (the stage buffers are free by now) in
+// fixed order -- deterministic.  The centred values replace the accumulators in place.
+template <int RT>
+__device__ __forceinline__ void epilogue_ln(const GemmArgs& a, f32x4 (&acc)[RT][8], char* smem, int lane, int wm, int wn, int m0) {
+  constexpr int RM = 32 * RT;
+  const int c16 = lane & 15, g16 = lane >> 4;
+  float* red = (float*)smem;                       // [2 passes][RM rows][4 waves]
+  const __amdgpu_buffer_rsrc_t rc = c_rsrc(a);
+  const int ncolw = wn * 128;
+  const int pcol = 8 * (((g16 & 1) << 1) | (g16 >> 1));   // this lane's 16-B pieces after the row swap: columns pcol + {0..7} and + 32 of a 64-column half
+  // ---- C = bf16(acc + bias + residual), kept as fp32 in place; row sums; store C
+  float s[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) s[t] = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    unsigned P[RT][4][2];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * h + jj;
+      const int n = ncolw + 16 * j + 4 * g16;
+      const u32x2 braw = a.bias ? *(const u32x2*)(a.bias + n) : u32x2{0u, 0u};
+      const float b0 = __uint_as_float(braw[0] << 16), b1 = __uint_as_float(braw[0] & 0xffff0000u);
+      const float b2 = __uint_as_float(braw[1] << 16), b3 = __uint_as_float(braw[1] & 0xffff0000u);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int m = m0 + wm * (RM / 2) + 16 * t + c16;
+        u32x2 r = {0u, 0u};
+        if (a.residual && m < a.M) r = *(const u32x2*)(a.residual + (int64_t)m * a.ldc + n);
+        const float v0 = acc[t][j][0] + b0 + __uint_as_float(r[0] << 16);
+        const float v1 = acc[t][j][1] + b1 + __uint_as_float(r[0] & 0xffff0000u);
+        const float v2 = acc[t][j][2] + b2 + __uint_as_float(r[1] << 16);
+        const float v3 = acc[t][j][3] + b3 + __uint_as_float(r[1] & 0xffff0000u);
+        const unsigned p0 = pack2bf(v0, v1), p1 = pack2bf(v2, v3);
+        P[t][jj][0] = p0; P[t][jj][1] = p1;
+        const f32x4 vr = {__uint_as_float(p0 << 16), __uint_as_float(p0 & 0xffff0000u), __uint_as_float(p1 << 16), __uint_as_float(p1 & 0xffff0000u)};
+        acc[t][j] = vr;
+        s[t] += (vr[0] + vr[1]) + (vr[2] + vr[3]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int m = m0 + wm * (RM / 2) + 16 * t + c16;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) { swap16(P[t][0][d], P[t][1][d]); swap16(P[t][2][d], P[t][3][d]); }
+      if (m < a.M) {
+        const int64_t off = (int64_t)m * a.ldc + ncolw + 64 * h + pcol;
+        store_c16(a, rc, off, u32x4{P[t][0][0], P[t][0][1], P[t][1][0], P[t][1][1]});
+        store_c16(a, rc, off + 32, u32x4{P[t][2][0], P[t][2][1], P[t][3][0], P[t][3][1]});
+      }
+    }
+  }
+  // ---- mean
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    s[t] += __shfl_xor(s[t], 16, 64);
+    s[t] += __shfl_xor(s[t], 32, 64);
+    if (g16 == 0) red[(wm * (RM / 2) + 16 * t + c16) * 4 + wn] = s[t];
+  }
+  __syncthreads();
+  float mu[RT], q[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const f32x4 r = *(const f32x4*)(red + (wm * (RM / 2) + 16 * t + c16) * 4);
+    mu[t] = ((r[0] + r[1]) + (r[2] + r[3])) * (1.0f / 512.0f);
+    q[t] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[t][j][e] -= mu[t]; q[t] += acc[t][j][e] * acc[t][j][e]; }
+    }
+    q[t] += __shfl_xor(q[t], 16, 64);
+    q[t] += __shfl_xor(q[t], 32, 64);
+    if (g16 == 0) red[RM * 4 + (wm * (RM / 2) + 16 * t + c16) * 4 + wn] = q[t];
+  }
+  __syncthreads();
+  float rs[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const f32x4 r = *(const f32x4*)(red + RM * 4 + (wm * (RM / 2) + 16 * t + c16) * 4);
+    rs[t] = rsqrtf(((r[0] + r[1]) + (r[2] + r[3])) * (1.0f / 512.0f) + a.ln_eps);
+    const int m = m0 + wm * (RM / 2) + 16 * t + c16;
+    if (wn == 0 && g16 == 0 && m < a.M) { a.ln_mean[m] = mu[t]; a.ln_rstd[m] = rs[t]; }
+  }
+  // ---- Y = (C - mean) * rstd * gamma + beta
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    unsigned P[RT][4][2];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * h + jj;
+      const int n = ncolw + 16 * j + 4 * g16;
+      const u32x2 graw = *(const u32x2*)(a.ln_gamma + n), braw = *(const u32x2*)(a.ln_beta + n);
+      const float g0 = __uint_as_float(graw[0] << 16), g1 = __uint_as_float(graw[0] & 0xffff0000u);
+      const float g2 = __uint_as_float(graw[1] << 16), g3 = __uint_as_float(graw[1] & 0xffff0000u);
+      const float b0 = __uint_as_float(braw[0] << 16), b1 = __uint_as_float(braw[0] & 0xffff0000u);
+      const float b2 = __uint_as_float(braw[1] << 16), b3 = __uint_as_float(braw[1] & 0xffff0000u);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        P[t][jj][0] = pack2bf(acc[t][j][0] * rs[t] * g0 + b0, acc[t][j][1] * rs[t] * g1 + b1);
+        P[t][jj][1] = pack2bf(acc[t][j][2] * rs[t] * g2 + b2, acc[t][j][3] * rs[t] * g3 + b3);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int m = m0 + wm * (RM / 2) + 16 * t + c16;
+#pragma unroll
+      for (int d = 0; d < 2; ++d) { swap16(P[t][0][d], P[t][1][d]); swap16(P[t][2][d], P[t][3][d]); }
+      if (m < a.M) {
+        bf16_t* yp = a.ln_y + (int64_t)m * a.ln_ldy + ncolw + 64 * h + pcol;
+        *(u32x4*)yp = u32x4{P[t][0][0], P[t][0][1], P[t][1][0], P[t][1][1]};
+        *(u32x4*)(yp + 32) = u32x4{P[t][2][0], P[t][2][1], P[t][3][0], P[t][3][1]};
+      }
+    }
+  }
+}
+
+template <int FLAGS, int RT, bool LN = false>
 __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RM = 32 * RT;                 // rows per tile
@@ -1161,7 +1304,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  {   // the register epilogue works on 64-column halves of the wave tile
+  if constexpr (LN) {
+    epilogue_ln<RT>(a, acc, smem, lane, wm, wn, m0);     // (the last k-step's barrier: every wave is done with the stage buffers)
+  } else {   // the register epilogue works on 64-column halves of the wave tile
     f32x4 lo[RT][4], hi[RT][4];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -1385,9 +1530,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     // persistent 256x256 tiles: short-K products with at least two tiles per CU (see gemm_nt8p_kernel)
     const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
     const bool can = nsplit == 1 && a.k_per_split == a.K && a.K % 128 == 0 && (int64_t)a.M * a.lda < (1 << 30) && (int64_t)a.N * a.ldb < (1 << 30);
-    // auto: not the ReLU-mask epilogue (its per-row-tile loads of the mask source sit exposed in front of the stores: 130 vs 124 us on
-    // the FFN-2 input gradient, profiles/r04f_kbench_k512.log)
-    if (can && ((g_opt_nt8p == 1 && a.K <= g_opt_nt8p_max_k && t8m * t8n >= 2 * num_cus() && !(FLAGS & DMI_GEMM_RELU_MASK)) || g_opt_nt8p == 2)) {
+    if (can && ((g_opt_nt8p == 1 && a.K <= g_opt_nt8p_max_k && t8m * t8n >= 2 * num_cus()) || g_opt_nt8p == 2)) {
       static bool attr8p = false;
       if (!attr8p) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8p = true; }
       GemmArgs b = a;
@@ -1456,6 +1599,7 @@ static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr;
+  a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
   const int64_t cbytes = ((int64_t)(M - 1) * ldc + N) * 2;     // bf16 outputs (the fp32 forms do not use the policy)
   a.cpol = (cbytes < (int64_t)0xffffffff && (g_opt_cstream == 2 || (g_opt_cstream == 1 && cbytes >= ((int64_t)g_opt_cstream_min_mb << 20)))) ? 1 : 0;
 }
@@ -1486,6 +1630,33 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
       dmi_set_error("gemm_nt: unsupported flag combination %d", flags);
       return DMI_ERR_UNSUPPORTED;
   }
+}
+
+// Product with N = 512 outputs + bias + residual, and the LayerNorm of the result in the same pass (full-row tiles, see
+// gemm_ntr_kernel / epilogue_ln): C = bf16(A . Bt^T + bias + residual) [M, 512], Y = bf16(LN(C) * gamma + beta), mean / rstd fp32 [M].
+extern "C" int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
+                              const uint16_t* bias, const uint16_t* residual, const uint16_t* gamma, const uint16_t* beta, float eps,
+                              uint16_t* Y, int ldy, float* mean, float* rstd, void* stream) {
+  int rc = check_nt(A, lda, Bt, ldb, C, ldc, M, N, K);
+  if (rc) return rc;
+  DMI_REQUIRE(gamma && beta && Y && mean && rstd, "gemm_nt_ln: null pointer");
+  DMI_REQUIRE((((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)Y | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0 && ldy % 8 == 0 && ldy >= N,
+              "gemm_nt_ln: operands must be 16-byte aligned");
+  if (N != 512 || (int64_t)N * ldb >= (1 << 30) || (int64_t)M * lda >= ((int64_t)1 << 31)) {
+    dmi_set_error("gemm_nt_ln: the fused form needs N = 512 (one block owns whole rows); got N=%d", N);
+    return DMI_ERR_UNSUPPORTED;
+  }
+  GemmArgs a;
+  fill_nt_args(a, A, lda, Bt, ldb, C, ldc, M, N, K);
+  a.bias = bias; a.residual = residual;
+  a.ln_gamma = gamma; a.ln_beta = beta; a.ln_y = Y; a.ln_ldy = ldy; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_eps = eps;
+  constexpr int RT = 5;
+  constexpr int LDSB = 3 * (32 * RT * 64 + 32768);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  gemm_ntr_kernel<0, RT, true><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
+  DMI_CHECK_LAUNCH("gemm_nt_ln");
+  return DMI_OK;
 }
 
 extern "C" int dmi_ln_gemm_nt(const uint16_t* X, int ldx, const uint16_t* gamma, const uint16_t* beta, float eps, const uint16_t* Bt, int ldb,
@@ -2512,6 +2683,7 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr;
   a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr; a.cpol = 0;
+  a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
   ConvGeom g;
   g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = 0; g.lh = 0;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }

@@ -87,6 +87,7 @@ def _declare(L):
         "dmi_sample_tokens": (I, [P, I, P, I, I, F, I, ctypes.c_uint64, P, I, P, I, I, P, P, I, I, P]),
         "dmi_ln_gemm_nt": (I, [P, I, P, P, F, P, I, P, I, I, I, I, I, P, P]),
         "dmi_logits_f32": (I, [P, I, P, P, I, I, P]),
+        "dmi_gemm_nt_ln": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, F, P, I, P, P, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
         "dmi_sumsq": (I, [P, L64, P, P, P]),
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P, P]),
@@ -202,6 +203,15 @@ def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None,
     _dev(A, Bt, C)
     _check(lib().dmi_gemm_nt(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, flags, _p(bias), _p(residual),
                              _p(relu_src), _p(rowscale), _stream()), "gemm_nt")
+
+
+def gemm_nt_ln(A, lda, Bt, ldb, C, ldc, M, N, K, gamma, beta, Y, ldy, mean, rstd, bias=None, residual=None, eps=1e-5):
+    """C = bf16(A . Bt^T + bias + residual) and, in the same pass, Y = LayerNorm(C) * gamma + beta with the row statistics
+    (N = 512: full-row tiles).  Raises DalleHipError (unsupported) for other widths: the caller keeps gemm_nt + layernorm_fwd."""
+    _dev(A, Bt, C, gamma, beta, Y, mean, rstd)
+    assert mean.dtype == torch.float32 and rstd.dtype == torch.float32 and mean.numel() >= M and rstd.numel() >= M
+    _check(lib().dmi_gemm_nt_ln(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, _p(bias), _p(residual), _p(gamma), _p(beta), float(eps),
+                                _p(Y), ldy, _p(mean), _p(rstd), _stream()), "gemm_nt_ln")
 
 
 def ln_gemm_nt(X, ldx, gamma, beta, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, eps=1e-5):

@@ -283,6 +283,15 @@ class DalleEngine:
                        for i_, j_ in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d))]
         self.deferred = dh.DeferredReduces()
         # tuning switch: hparams win, the environment variable gives the default (A/B runs: tools/ab_env.sh)
+        # LayerNorm fused into the products that feed it (dmi_gemm_nt_ln): the full-row tiles exist for n_embd = 512
+        # Measured (profiles/r04q_kbench_ln512.log, r04q_ab_fuse_ln.log): out-projection + norm_2 46.5 us fused vs 33.4 + 16.1 us,
+        # FFN-2 + norm 98.9 vs 77.9 + 16.4 us, step 15.98 vs 15.95 ms -- with ONE tile per CU nothing overlaps the fused epilogue,
+        # and its two 160-KB outputs per tile leave at the CU's ~14 B / clk store-issue rate, which costs what the HBM-bound
+        # standalone kernel costs.  Off by default; hparams["fuse_ln"] / DALLE_FUSE_LN=1 select it.
+        self.fuse_ln = bool(self.hp.get("fuse_ln", os.environ.get("DALLE_FUSE_LN", "0") != "0")) and d == 512
+        # FFN-2 -> next norm_1: not under recompute_grad, whose re-run of a block starts from the stored residual stream with a
+        # standalone norm_1 (its statistics sum in another order; the re-run must reproduce the forward bit for bit)
+        self.fuse_ln1 = self.fuse_ln and not self.recompute
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
         self.hp.setdefault("defer_reduces", os.environ.get("DALLE_DEFER_REDUCES", "1") != "0")
 
@@ -311,8 +320,9 @@ class DalleEngine:
         dh.embed_fwd(self.tokens, self._w("embedding/wte"), self._w("positional_embedding/wpe"), self.X[0], S, d, self.V)
         for l in range(L):
             self._block_forward(l)
-        dh.layernorm_fwd(self.X[L], self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), self.xnf,
-                         self.statf[0], self.statf[1], M, d)
+        if not (self.fuse_ln1 and L > 0):      # (fused: written by the last block's FFN-2)
+            dh.layernorm_fwd(self.X[L], self._w("to_logits/layer_norm/g"), self._w("to_logits/layer_norm/b"), self.xnf,
+                             self.statf[0], self.statf[1], M, d)
         Wt, bias = self.tview("to_logits/linear_out/kernel"), self._w("to_logits/linear_out/bias")
         nmb = (self.hp.get("num_microbatches", 1) or 1) if need_grad else 1
         if need_grad:
@@ -340,22 +350,43 @@ class DalleEngine:
 
     def _block_forward(self, l):
         """one transformer block (src/dalle_mtf/models.py:326-335): X[l] -> X[l+1]; also what backward() re-runs under
-        recompute_grad."""
-        M, d, B, H, S = self.M, self.d, self.B, self.H, self.S
+        recompute_grad.
+        fuse_ln (n_embd = 512): the two products that end in the residual stream run on full-row tiles and emit the LayerNorm
+        that follows them in the same pass (dmi_gemm_nt_ln) -- out-projection + residual -> norm_2, FFN-2 + residual -> the
+        NEXT block's norm_1 (or to_logits' norm): 12 of the 13 standalone LayerNorm launches of a forward pass disappear."""
+        M, d, B, H, S, L = self.M, self.d, self.B, self.H, self.S, self.L
         p = f"layer_{l}/"
         x = self.X[l]
         st = self.stats[l]
-        dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
+        rerun = getattr(self, "_in_backward", False)
+        if not (self.fuse_ln1 and l > 0):   # (fused: written by block l-1's FFN-2)
+            dh.layernorm_fwd(x, self._w(p + "norm_1/g"), self._w(p + "norm_1/b"), self.xn1[l], st[0], st[1], M, d)
         dh.gemm_nt(self.xn1[l], d, self.tview(p + "attn/qkv"), d, self.qkv[l], 3 * d, M, 3 * d, d)
         dh.attention_fwd(self.qkv[l], self.o[l], self.lse[l], B, H, S)   # no transposed copies: hardware transpose reads
-        dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
-                   bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
-        dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
+        if self.fuse_ln:
+            dh.gemm_nt_ln(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d,
+                          self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], d, st[2], st[3],
+                          bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
+        else:
+            dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
+                       bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
+            dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
         dh.gemm_nt(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
                    dh.GEMM_BIAS | dh.GEMM_RELU, bias=self._w(p + "mlp/mlp_linear_1/bias"))
-        if not getattr(self, "_in_backward", False):   # the re-run stops here: X[l+1] is already stored
-            dh.gemm_nt(self.h[l], 4 * d, self.tview(p + "mlp/mlp_linear_2/kernel"), 4 * d, self.X[l + 1], d, M, d, 4 * d,
-                       dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=self._w(p + "mlp/mlp_linear_2/bias"), residual=self.x1[l])
+        if rerun:   # the re-run stops here: X[l+1] is already stored
+            return
+        W2, b2 = self.tview(p + "mlp/mlp_linear_2/kernel"), self._w(p + "mlp/mlp_linear_2/bias")
+        if self.fuse_ln1:
+            if l + 1 < L:
+                q = f"layer_{l + 1}/norm_1/"
+                y, mean, rstd = self.xn1[l + 1], self.stats[l + 1][0], self.stats[l + 1][1]
+            else:
+                q = "to_logits/layer_norm/"
+                y, mean, rstd = self.xnf, self.statf[0], self.statf[1]
+            dh.gemm_nt_ln(self.h[l], 4 * d, W2, 4 * d, self.X[l + 1], d, M, d, 4 * d, self._w(q + "g"), self._w(q + "b"), y, d, mean, rstd,
+                          bias=b2, residual=self.x1[l])
+        else:
+            dh.gemm_nt(self.h[l], 4 * d, W2, 4 * d, self.X[l + 1], d, M, d, 4 * d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=b2, residual=self.x1[l])
 
     def logits(self) -> torch.Tensor:
         """fp32 logits [B,S,V] of the last forward(need_grad=False) ("go to full precision", models.py:395)."""

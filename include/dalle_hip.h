@@ -159,6 +159,14 @@ int dmi_cross_entropy(uint16_t* z, int ldz, const int32_t* labels, float* loss_r
 int dmi_label_logit(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                     const int32_t* labels, float* zl, int32_t* flag, int64_t M, int K, int V, void* stream);
 int64_t dmi_gemm_nt_softmax_partials(int N);
+/* Product + bias + residual with the LayerNorm of the result fused into the epilogue (reference src/dalle_mtf/models.py:303-314
+ * feeding :333,373-389 -- out-projection + residual -> norm_2; :321-324 feeding the next block's :330 / to_logits' :392 -- FFN-2 +
+ * residual -> norm_1 / final norm):  C[M, N] = bf16(A . Bt^T + bias + residual)  (bias, residual nullable),
+ * Y[M, N] = bf16((C - mean) * rstd * gamma + beta), mean / rstd fp32 [M] over the ROUNDED row (biased variance, eps inside the
+ * rsqrt: what dmi_layernorm_fwd computes from the stored C).  N = 512 only (a block owns whole rows): DMI_ERR_UNSUPPORTED otherwise. */
+int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
+                   const uint16_t* bias, const uint16_t* residual, const uint16_t* gamma, const uint16_t* beta, float eps,
+                   uint16_t* Y, int ldy, float* mean, float* rstd, void* stream);
 int dmi_gemm_nt_softmax(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                         const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K, void* stream);
 int dmi_softmax_finish(const float* rowsum_part, int nparts, const float* label_logit, const float* rowshift,

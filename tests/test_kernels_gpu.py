@@ -369,6 +369,45 @@ def test_gemm_ntr_full_row_tiles(M, K, flags):
     assert torch.equal(outs[0], outs[1]), "full-row and 128x128 tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,K,with_res", [(160, 512, True), (1000, 2048, True), (2100, 512, False), (40960, 512, True)])
+def test_gemm_nt_ln_fused_layernorm(M, K, with_res):
+    """[r04] dmi_gemm_nt_ln (full-row tiles, N = 512): C is bit-identical to dmi_gemm_nt with the same bias / residual; Y and the
+    row statistics equal dmi_layernorm_fwd applied to that C up to the summation order of the statistics (<= 1 bf16 ulp on Y),
+    and fp32 LayerNorm math on the same rounded C."""
+    N = 512
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    gam = (torch.rand(N, generator=torch.Generator().manual_seed(5)) + 0.5).to(torch.bfloat16)
+    bet = rnd(N, seed=6)
+    Ad, Bd, bd, rd = A.to(DEV), Bt.to(DEV), bias.to(DEV), (res.to(DEV) if with_res else None)
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    Y = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    mean = torch.zeros(M, dtype=torch.float32, device=DEV)
+    rstd = torch.zeros(M, dtype=torch.float32, device=DEV)
+    dh.gemm_nt_ln(Ad, K, Bd, K, C, N, M, N, K, gam.to(DEV), bet.to(DEV), Y, N, mean, rstd, bias=bd, residual=rd)
+    C2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.set_option("ntr", 0)
+    try:
+        dh.gemm_nt(Ad, K, Bd, K, C2, N, M, N, K, dh.GEMM_BIAS | (dh.GEMM_RESIDUAL if with_res else 0), bias=bd, residual=rd)
+    finally:
+        dh.set_option("ntr", 1)
+    assert torch.equal(C, C2), "the fused kernel's C must be bit-identical to the plain product"
+    Y2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    m2 = torch.zeros(M, dtype=torch.float32, device=DEV)
+    r2 = torch.zeros(M, dtype=torch.float32, device=DEV)
+    dh.layernorm_fwd(C2, gam.to(DEV), bet.to(DEV), Y2, m2, r2, M, N)
+    close(mean, m2.cpu(), 1e-5, 1e-6, "mean vs layernorm_fwd")
+    close(rstd, r2.cpu(), 1e-5, 1e-7, "rstd vs layernorm_fwd")
+    dy = (Y.float() - Y2.float()).abs()
+    assert float((dy > 2.0 ** -7 * Y2.float().abs() + 1e-6).float().mean()) == 0.0, "Y differs from layernorm_fwd by more than one bf16 ulp"
+    assert float((Y != Y2).float().mean()) < 5e-3, float((Y != Y2).float().mean())   # only where the statistics' last bits tip a rounding
+    cf = C.float().cpu()
+    ref = torch.nn.functional.layer_norm(cf, (N,), gam.float(), bet.float(), 1e-5)
+    close(Y, ref, 1.6e-2, 2e-2, "Y vs fp32 layer_norm")
+    with pytest.raises(dh.DalleHipError):      # other widths: refused, the caller keeps the two-kernel form
+        dh.gemm_nt_ln(Ad, K, Bd, K, C, N, M, 256, K, gam.to(DEV), bet.to(DEV), Y, N, mean, rstd)
+
+
 def test_gemm_nt8_splitk_rowscale():
     """the head input-gradient form: long K split in 4, 256x256 tiles (auto: 4 x 64 tiles = 256 blocks), row scale in the reduce"""
     M, N, K = 2048, 2048, 4096 * 4

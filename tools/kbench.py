@@ -201,6 +201,17 @@ if __name__ == "__main__":
         bench_gemm_nt(M, d, 4 * d, 0, " ffn1-dgrad", two)
         bench_gemm_nt(M, d, 3 * d, 0, " qkv-dgrad", two)
         bench_gemm_nt(M, d, d, 0, " attn-out-dgrad", two)
+    if "ln512" in what:    # product + bias + residual -> LayerNorm: two kernels vs the fused full-row form
+        for K, tag in ((d, "attn-out"), (4 * d, "ffn2")):
+            A, Bt = rb(M, K), rb(d, K, scale=0.05)
+            bias, res, gam, bet = rb(d), rb(M, d), rb(d), rb(d)
+            C, Y = torch.empty(M, d, dtype=torch.bfloat16, device=DEV), torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+            mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+            for rep in range(2):
+                t1 = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, d, M, d, K, 5, bias=bias, residual=res))
+                t2 = timeit(lambda: dh.layernorm_fwd(C, gam, bet, Y, mean, rstd, M, d))
+                t3 = timeit(lambda: dh.gemm_nt_ln(A, K, Bt, K, C, d, M, d, K, gam, bet, Y, d, mean, rstd, bias=bias, residual=res))
+                print(f"ln512 {tag} K={K}: gemm_nt {t1*1e6:7.1f} us + layernorm_fwd {t2*1e6:6.1f} us = {(t1+t2)*1e6:7.1f} us   fused gemm_nt_ln {t3*1e6:7.1f} us", flush=True)
     if "tn" in what:
         for I, J in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d), (d, 50816)):
             bench_gemm_tn(M, I, J, weighted=(J == 50816))
