@@ -235,6 +235,32 @@ def attn_mask(S: int) -> torch.Tensor:
     return (i < j).to(torch.float32) * -1e10
 
 
+class _FlashCore(torch.autograd.Function):
+    """softmax(logits) @ v with the backward written the way a flash-attention kernel computes it (attribution mode "+fa"):
+    forward  P = softmax(logits) (fp32), a = bf16(bf16(P) @ v);
+    backward dv = bf16(P)^T da;  dP = da v^T kept in fp32;  delta = sum_d da * a taken from the ROUNDED output a (the kernel
+    reads the stored bf16 O);  dlogits = P * (dP - delta).
+    The reference's autograd subtracts sum_j P_j dP_j instead -- the same number in exact arithmetic, but delta inherits the
+    bf16 rounding of a, and its error enters every dlogit of a row with one sign (the row no longer sums to zero)."""
+
+    @staticmethod
+    def forward(ctx, logits, v):
+        w = torch.exp(logits - torch.logsumexp(logits, dim=-1, keepdim=True))
+        wr = w.to(torch.bfloat16).to(torch.float32)
+        a = (wr @ v).to(torch.bfloat16).to(torch.float32)
+        ctx.save_for_backward(w, wr, v, a)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        w, wr, v, a = ctx.saved_tensors
+        da = da.to(torch.bfloat16).to(torch.float32)
+        dv = wr.transpose(-1, -2) @ da
+        dp = da @ v.transpose(-1, -2)
+        delta = (da * a).sum(dim=-1, keepdim=True)
+        return w * (dp - delta), dv
+
+
 def attention(x, wq, wk, wv, wo, o_b, n_heads, mask, bf16=False, force=None, site=""):
     """a7: src/dalle_mtf/models.py:229-315.  q,k,v = x@Wq, x@Wk, x@Wv (bias-free, [d, H*k] heads-major,
     Appendix A.1); logits = q.k^T UNSCALED in fp32 (Appendix A.2/A.3) + mask; softmax over keys
@@ -248,6 +274,10 @@ def attention(x, wq, wk, wv, wo, o_b, n_heads, mask, bf16=False, force=None, sit
     if isinstance(bf16, str) and "ds" in bf16:
         logits = _RoundGradOnly.apply(logits)
     logits = logits + mask
+    if isinstance(bf16, str) and "fa" in bf16:
+        a = _FlashCore.apply(logits, v)
+        a = _force(force, site + "a", a.transpose(1, 2).reshape(B, S, d))
+        return _rb(a @ wo + o_b, bf16)
     w = torch.exp(logits - torch.logsumexp(logits, dim=-1, keepdim=True))
     if isinstance(bf16, str) and "dp32" in bf16:
         # attribution mode: P rounded to bf16 in the forward, its gradient dP = dO V^T NOT rounded (a flash-style kernel keeps

@@ -92,7 +92,8 @@ def compare_step(n_embd=256, n_heads=2, n_layers=2, text_vocab=300, image_vocab=
             sites = engine_sites(eng)
             for tag, mode, force in (("bf16_fp32w", "fp32w", None), ("forced_bf16", True, sites), ("forced_fp32w", "fp32w", sites),
                                      ("forced_fp32w_ds", "fp32w+ds", sites),      # "+ds": dS rounded to bf16 as a matrix-core operand
-                                     ("forced_fp32w_dp32", "fp32w+dp32", sites)):  # "+dp32": dP = dO V^T kept in fp32 (flash-style kernels)
+                                     ("forced_fp32w_dp32", "fp32w+dp32", sites),  # "+dp32": dP = dO V^T kept in fp32 (flash-style kernels)
+                                     ("forced_fp32w_fa", "fp32w+fa", sites)):     # "+fa": delta = rowsum(dO * O) from the bf16-rounded O
                 loss_og, gg = do.loss_and_grads(Po, tokens, cfg, bf16=mode, force=force)
                 tab = {k: rel_l2(gh[k], gg[k]) for k in gg}
                 rec[f"loss_oracle_{tag}"] = loss_og

@@ -250,5 +250,8 @@ def test_vae_coco_whole_model_step_vs_both_oracles(coco):
     # [r04] (the bf16 oracle's backward tensors are bf16 too -- see oracle/dalle_oracle.py _RoundBF16Grad; "fp32w" keeps only the
     # weight gradients in fp32 as the engine does)
     assert rep["bf16_fp32w"]["worst_grad"][1] <= 0.14, rep["bf16_fp32w"]["worst_grad"]
-    # teacher-forced: provisional bound until measured (profiles/r04_parity_vae_coco_model.json)
-    assert rep["forced_bf16_fp32w"]["worst_grad"][1] <= 0.03, rep["forced_bf16_fp32w"]["worst_grad"]
+    # teacher-forced (profiles/r04_parity_vae_coco_model.json): loss 7e-8 relative, reconstruction identical, worst gradient tensor
+    # 0.0106 (the first encoder kernel; 0.0088 / 0.0067 on the next two, <= 0.006 below) against 0.111 free-running: the 11 % was
+    # forward divergence over 27 bf16 layers, not the backward chain.  Bound = measured + 25 %.
+    assert rep["forced_bf16_fp32w"]["worst_grad"][1] <= 0.0135, rep["forced_bf16_fp32w"]["worst_grad"]
+    assert abs(rep["forced_bf16_fp32w"]["loss_hip"] - rep["forced_bf16_fp32w"]["loss_oracle"]) <= 2e-6 * rep["forced_bf16_fp32w"]["loss_oracle"]
