@@ -180,6 +180,7 @@ __device__ __forceinline__ void fr3_wait(Fr3& f) {
 }
 
 extern int g_opt_attn_xcd;
+extern int g_opt_reserve_cus;   // CUs the persistent grids leave to concurrent kernels (csrc/gemm.hip)
 // Persistent-block schedule: the grid is one (dK/dV) or two (forward, dQ) blocks per CU; hardware block L (dispatched to XCD L % 8) owns
 // bin k = L / 8 of its XCD.  The XCD's work items -- (tile, batch*head) for its contiguous eighth of the (batch, head) pairs,
 // sorted heaviest tile first -- are dealt to the bins in serpentine order (round 0: bins 0..P-1, round 1: P-1..0, ...): with
@@ -392,7 +393,8 @@ static int attn_num_cus() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) n = p.multiProcessorCount;
     else n = 256;
   }
-  return n;
+  const int m = (n - g_opt_reserve_cus) & ~7;     // persistent grids: leave the reserved CUs free, keep a multiple of 8
+  return m < 8 ? 8 : m;
 }
 
 extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int H, int S, void* stream) {

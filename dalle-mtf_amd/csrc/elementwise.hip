@@ -74,74 +74,78 @@ __global__ __launch_bounds__(256) void embed_bwd_wpe_kernel(const bf16_t* __rest
   }
 }
 // ---- stable sort of the token ids (index plumbing for the scatter-add below) -----------------------------------------
-// One 1024-thread block, LSD radix sort with 4-bit digits: thread t owns the contiguous chunk [t*cpt, (t+1)*cpt) of the
-// current order, counts its digits into its own column of hist[16][1024] (no atomics), a block-wide exclusive scan in
-// (digit, thread) order turns the counts into destinations, and the thread scatters its chunk in order -> stable and
-// deterministic.  ceil(log2(vocab) / 4) passes ping-pong between (sorted, perm) and the workspace; the last pass lands in
-// the outputs.  The ids are known when the forward starts, so the engine runs this on a side stream under the forward.
-#define SORT_T 1024
-__global__ __launch_bounds__(SORT_T) void sort_tokens_kernel(const int* __restrict__ tokens, int* __restrict__ out_key,
-                                                             int* __restrict__ out_perm, int* __restrict__ tmp_key,
-                                                             int* __restrict__ tmp_perm, int n, int vocab, int npass) {
-  extern __shared__ __attribute__((aligned(16))) char sort_sm[];
-  int* hist = (int*)sort_sm;              // [16][SORT_T]
-  int* wtot = hist + 16 * SORT_T;         // [16] wave totals
-  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-  const int cpt = (n + SORT_T - 1) / SORT_T;
-  const int i0 = t * cpt < n ? t * cpt : n;
+// LSD radix sort with 4-bit digits over SORT_T = 2048 threads (8 blocks): thread g owns the contiguous chunk
+// [g*cpt, (g+1)*cpt) of the current order.  Per pass three short launches: COUNT (every thread counts its digits into its own
+// column of hist[16][SORT_T], no atomics), SCAN (one block: exclusive scan of the 16 * SORT_T counts in (digit, thread) order =
+// the destinations), SCATTER (every thread writes its chunk in order) -> stable and deterministic.  ceil(log2(vocab) / 4)
+// passes ping-pong between (sorted, perm) and the workspace; the last pass lands in the outputs.
+// [r04] Rounds 2-3 ran this as ONE 1024-thread block for 0.62 ms on a side stream "hidden" under the forward.  It was not
+// hidden: the forward's kernels are persistent (one or two blocks per CU, each with its own tile list), and the block whose CU
+// the sort occupied started ~0.6 ms late -- a per-launch trace showed layer 0's forward taking 687 us instead of 410 us
+// (attention 210 us instead of 70).  Moving it under the head's weight gradient moved the damage there (+340 us).  As 12
+// launches of 3-5 us it disturbs nothing.
+#define SORT_T 2048
+#define SORT_BLK 256
+__device__ __forceinline__ int sort_clamp(int k, int vocab) { return k < 0 ? 0 : (k >= vocab ? vocab - 1 : k); }
+__global__ __launch_bounds__(SORT_BLK) void sort_count_kernel(const int* __restrict__ keys, int* __restrict__ hist, int n, int vocab,
+                                                              int shift, int cpt) {
+  __shared__ int col[16][SORT_BLK];
+  const int t = threadIdx.x, g = blockIdx.x * SORT_BLK + t;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) col[d][t] = 0;
+  const int i0 = (int64_t)g * cpt < n ? g * cpt : n;
   const int i1 = i0 + cpt < n ? i0 + cpt : n;
-  for (int p = 0; p < npass; ++p) {
-    const int shift = 4 * p;
-    const bool to_out = ((npass - 1 - p) & 1) == 0;
-    const int* sk = (p == 0) ? tokens : (to_out ? tmp_key : out_key);
-    const int* sp = to_out ? tmp_perm : out_perm;
-    int* dk = to_out ? out_key : tmp_key;
-    int* dp = to_out ? out_perm : tmp_perm;
+  for (int i = i0; i < i1; ++i) col[(sort_clamp(keys[i], vocab) >> shift) & 15][t] += 1;
 #pragma unroll
-    for (int d = 0; d < 16; ++d) hist[d * SORT_T + t] = 0;
-    for (int i = i0; i < i1; ++i) {
-      int k = sk[i];
-      k = k < 0 ? 0 : (k >= vocab ? vocab - 1 : k);
-      hist[((k >> shift) & 15) * SORT_T + t] += 1;
-    }
-    __syncthreads();
-    // exclusive scan over the 16 * 1024 counts in linear (digit-major) order; thread t owns entries [16 t, 16 t + 16)
-    int loc[16], tot = 0;
+  for (int d = 0; d < 16; ++d) hist[d * SORT_T + g] = col[d][t];
+}
+// exclusive scan of hist[16 * SORT_T] in linear (digit-major) order, in place; thread t owns 16 * SORT_T / 1024 = 32 entries
+__global__ __launch_bounds__(1024) void sort_scan_kernel(int* __restrict__ hist) {
+  __shared__ int wtot[16];
+  constexpr int PER = 16 * SORT_T / 1024;
+  const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+  int* h = hist + t * PER;
+  int tot = 0;
+  for (int j = 0; j < PER; j += 4) {
+    const int4 v = *(const int4*)(h + j);
+    tot += (v.x + v.y) + (v.z + v.w);
+  }
+  int inc = tot;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      loc[j] = hist[16 * t + j];
-      tot += loc[j];
-    }
-    int inc = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += v;
-    }
-    if (lane == 63) wtot[wid] = inc;
-    __syncthreads();
-    int base = inc - tot;
-    for (int w = 0; w < wid; ++w) base += wtot[w];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      hist[16 * t + j] = base;
-      base += loc[j];
-    }
-    __syncthreads();
-    for (int i = i0; i < i1; ++i) {
-      int k = sk[i];
-      k = k < 0 ? 0 : (k >= vocab ? vocab - 1 : k);
-      const int slot = ((k >> shift) & 15) * SORT_T + t;
-      const int pos = hist[slot];
-      hist[slot] = pos + 1;
-      dk[pos] = k;
-      dp[pos] = (p == 0) ? i : sp[i];
-    }
-    __threadfence_block();
-    __syncthreads();
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) wtot[wid] = inc;
+  __syncthreads();
+  int base = inc - tot;
+  for (int w = 0; w < wid; ++w) base += wtot[w];
+  for (int j = 0; j < PER; j += 4) {
+    int4 v = *(const int4*)(h + j);
+    const int4 o = {base, base + v.x, base + v.x + v.y, base + v.x + v.y + v.z};
+    base += (v.x + v.y) + (v.z + v.w);
+    *(int4*)(h + j) = o;
   }
 }
-extern "C" int64_t dmi_sort_tokens_workspace_bytes(int64_t n) { return 2 * n * 4 + 256; }
+__global__ __launch_bounds__(SORT_BLK) void sort_scatter_kernel(const int* __restrict__ keys, const int* __restrict__ perm_in,
+                                                                int* __restrict__ keys_out, int* __restrict__ perm_out,
+                                                                const int* __restrict__ hist, int n, int vocab, int shift, int cpt) {
+  __shared__ int col[16][SORT_BLK];
+  const int t = threadIdx.x, g = blockIdx.x * SORT_BLK + t;
+#pragma unroll
+  for (int d = 0; d < 16; ++d) col[d][t] = hist[d * SORT_T + g];
+  const int i0 = (int64_t)g * cpt < n ? g * cpt : n;
+  const int i1 = i0 + cpt < n ? i0 + cpt : n;
+  for (int i = i0; i < i1; ++i) {
+    const int k = sort_clamp(keys[i], vocab);
+    const int d = (k >> shift) & 15;
+    const int pos = col[d][t];
+    col[d][t] = pos + 1;
+    keys_out[pos] = k;
+    perm_out[pos] = perm_in ? perm_in[i] : i;
+  }
+}
+extern "C" int64_t dmi_sort_tokens_workspace_bytes(int64_t n) { return 2 * n * 4 + (int64_t)16 * SORT_T * 4 + 256; }
 extern "C" int dmi_sort_tokens(const int32_t* tokens, int32_t* sorted_tokens, int32_t* perm, int64_t n, int vocab,
                                void* workspace, void* stream) {
   DMI_REQUIRE(tokens && sorted_tokens && perm && workspace, "sort_tokens: null pointer");
@@ -149,11 +153,22 @@ extern "C" int dmi_sort_tokens(const int32_t* tokens, int32_t* sorted_tokens, in
   int bits = 1;
   while ((1ll << bits) < vocab) ++bits;
   const int npass = (bits + 3) / 4;
-  static bool attr_done = false;
-  const int shm = 16 * SORT_T * 4 + 64;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)sort_tokens_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm); attr_done = true; }
-  int* tk = (int*)workspace;
-  sort_tokens_kernel<<<dim3(1), dim3(SORT_T), shm, (hipStream_t)stream>>>(tokens, sorted_tokens, perm, tk, tk + n, (int)n, vocab, npass);
+  hipStream_t st = (hipStream_t)stream;
+  int* tk = (int*)workspace;           // [n] keys | [n] perm | [16 * SORT_T] counts
+  int* tp = tk + n;
+  int* hist = (int*)(((uintptr_t)(tp + n) + 15) & ~(uintptr_t)15);      // 16-B aligned (vector loads in the scan)
+  const int cpt = (int)((n + SORT_T - 1) / SORT_T);
+  const dim3 grid(SORT_T / SORT_BLK), blk(SORT_BLK);
+  for (int p = 0; p < npass; ++p) {
+    const bool to_out = ((npass - 1 - p) & 1) == 0;          // the last pass lands in the outputs
+    const int* sk = (p == 0) ? tokens : (to_out ? tk : sorted_tokens);
+    const int* sp = (p == 0) ? nullptr : (to_out ? tp : perm);
+    int* dk = to_out ? sorted_tokens : tk;
+    int* dp = to_out ? perm : tp;
+    sort_count_kernel<<<grid, blk, 0, st>>>(sk, hist, (int)n, vocab, 4 * p, cpt);
+    sort_scan_kernel<<<dim3(1), dim3(1024), 0, st>>>(hist);
+    sort_scatter_kernel<<<grid, blk, 0, st>>>(sk, sp, dk, dp, hist, (int)n, vocab, 4 * p, cpt);
+  }
   DMI_CHECK_LAUNCH("sort_tokens");
   return DMI_OK;
 }

@@ -25,6 +25,10 @@
 
 static int g_opt_nt4 = 1;        // 256x128 NT tile: 0 never, 1 auto (>= 3 residencies and K <= 1024), 2 always (tests)
 static int g_opt_nt8 = 1;        // 256x256 NT tile (8 waves): 0 never, 1 auto (K >= nt8_min_k, whole residencies), 2 always (tests)
+int g_opt_reserve_cus = 0;       // CUs the persistent kernels (256x256 NT, attention) leave free, and which switch the one-tile-per-CU
+                                 // full-row kernel off: a block of those kernels whose CU is held by a concurrent kernel (the RCCL channels
+                                 // of the gradient exchange) starts late and stretches the whole launch -- measured with the token sort as
+                                 // the intruder (layer 0's forward 687 us instead of 410 us).  The engine sets 16 when world_size > 1.
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn8 = 0;        // 256x256 weight-gradient tile (8 waves, still on 32x32x16 MFMAs): 0 never (default since the 128x128 kernel
                                  // moved to 16x16x32: 45 / 76 us vs 60 / 86 us on the 512x512 / 512x1536 gradients), 1 auto (few tiles), 2 always (tests)
@@ -62,6 +66,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "tn8")) return g_opt_tn8;
   if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
+  if (!strcmp(name, "reserve_cus")) return g_opt_reserve_cus;
   return -1;
 }
 extern "C" int dmi_set_option(const char* name, int value) {
@@ -80,6 +85,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
   if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
+  if (!strcmp(name, "reserve_cus")) { if (value < 0) return -1; g_opt_reserve_cus = value; return 0; }
   return -1;
 }
 
@@ -1503,6 +1509,11 @@ static int num_cus() {
   return n;
 }
 
+static int persistent_grid() {    // blocks of a one-per-CU persistent kernel: a multiple of 8 (block id % 8 = XCD)
+  int n = (num_cus() - g_opt_reserve_cus) & ~7;
+  return n < 8 ? 8 : n;
+}
+
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
@@ -1516,7 +1527,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   if constexpr (epi_regs_ok<FLAGS> && !(FLAGS & GEMM_SOFTMAX)) {
     // full-row tiles: N = 512 exactly, one 160-row tile per block
     if (g_opt_ntr && a.N == 512 && nsplit == 1 && a.k_per_split == a.K && a.K % 32 == 0 && (int64_t)a.N * a.ldb < (1 << 30) &&
-        (g_opt_ntr == 2 || (a.M >= 160 * (num_cus() / 2) && a.K <= 4096))) {   // (the head's input gradient, K = 50816: 1.83 ms here vs 1.32 ms on 256x256 tiles)
+        (g_opt_ntr == 2 || (a.M >= 160 * (num_cus() / 2) && a.K <= 4096 && g_opt_reserve_cus == 0))) {   // (the head's input gradient, K = 50816: 1.83 ms here vs 1.32 ms on 256x256 tiles)
       constexpr int RT = 5;
       constexpr int LDSB = 3 * (32 * RT * 64 + 32768);
       static bool attrr = false;
@@ -1536,7 +1547,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
       GemmArgs b = a;
       b.tiles_m = t8m; b.tiles_n = t8n;
       if (g_opt_nt8p_pd == 1) {
-        gemm_nt8p_kernel<FLAGS><<<dim3(num_cus() & ~7), dim3(512), 131072, st>>>(b);
+        gemm_nt8p_kernel<FLAGS><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
       } else {
         static bool attr8q = false;
         if (!attr8q) {
@@ -1544,8 +1555,8 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
           (void)hipFuncSetAttribute((const void*)gemm_nt8q_kernel<FLAGS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
           attr8q = true;
         }
-        if (g_opt_nt8p_pd == 2) gemm_nt8q_kernel<FLAGS, 2><<<dim3(num_cus() & ~7), dim3(512), 131072, st>>>(b);
-        else gemm_nt8q_kernel<FLAGS, 3><<<dim3(num_cus() & ~7), dim3(512), 131072, st>>>(b);
+        if (g_opt_nt8p_pd == 2) gemm_nt8q_kernel<FLAGS, 2><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
+        else gemm_nt8q_kernel<FLAGS, 3><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
       }
       DMI_CHECK_LAUNCH("gemm_nt8p");
       return DMI_OK;

@@ -129,6 +129,11 @@ class DalleEngine:
         self._alloc_activations()
         # gradient exchange: RCCL behind the C ABI when `comm` (dp.init_comm) is given, torch.distributed otherwise
         self.reducer = GradReducer(self.g, world_size, comm=comm, pg=process_group)
+        # The exchange's RCCL channels run beside the BACKWARD: there the persistent kernels leave CUs for them (a block of a
+        # one-block-per-CU kernel whose CU an intruder holds starts when the others have finished: the launch takes twice as long --
+        # measured with the token sort as the intruder).  16 CUs cost 3.7 % of a single-GPU step when applied to
+        # the whole step, so the option is set for the backward only; 0 = off.  Unmeasured on a multi-GPU node.
+        self.dp_reserve_cus = int(os.environ.get("DALLE_DP_RESERVE_CUS", "16")) if world_size > 1 else 0
 
     # ------------------------------------------------------------------ parameter access
     def view(self, buf, name):
@@ -309,13 +314,9 @@ class DalleEngine:
         M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
         assert tokens.shape == (B, S) and tokens.dtype == torch.int32
         self.tokens.copy_(tokens)
-        if need_grad:   # token-id order for the embedding backward: off the critical path
-            main = torch.cuda.current_stream()
-            self.sort_stream.wait_stream(main)
-            with torch.cuda.stream(self.sort_stream):
-                dh.sort_tokens(self.tokens, self.tok_sorted, self.tok_perm, M, self.V, self.sort_ws)
-                self._sort_done = torch.cuda.Event()
-                self._sort_done.record(self.sort_stream)
+        self._sort_done = None
+        if need_grad:   # token-id order for the embedding backward: twelve 3-5 us launches on a side stream (see dmi_sort_tokens)
+            self._launch_sort()
         dh.shift_labels(self.tokens, self.labels, B, S, self.eos)
         dh.embed_fwd(self.tokens, self._w("embedding/wte"), self._w("positional_embedding/wpe"), self.X[0], S, d, self.V)
         for l in range(L):
@@ -567,6 +568,14 @@ class DalleEngine:
             dh.gemm_tn(X, ldx, dY, ldy, dW, M, I, J, self.ws_blk[slot], dbias=dbias, bias_weights=bias_weights,
                        deferred=self.deferred)
 
+    def _launch_sort(self):
+        main = torch.cuda.current_stream()
+        self.sort_stream.wait_stream(main)
+        with torch.cuda.stream(self.sort_stream):
+            dh.sort_tokens(self.tokens, self.tok_sorted, self.tok_perm, self.M, self.V, self.sort_ws)
+            self._sort_done = torch.cuda.Event()
+            self._sort_done.record(self.sort_stream)
+
     def backward(self, allreduce=True):
         """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  With world_size > 1 every finished
         prefix of the buffer is handed to the exchange (src/dp.py: SUM all-reduce in <= 64 MB pieces on the side stream) --
@@ -582,6 +591,10 @@ class DalleEngine:
                 self.reducer.ready(done[0], upto)
             done[0] = upto
 
+        if self._sort_done is None:
+            self._launch_sort()
+        if self.dp_reserve_cus and allreduce:
+            dh.set_option("reserve_cus", self.dp_reserve_cus)     # (read at launch time: applies to the launches enqueued from here on)
         # head: dW = (rowscale * xnf)^T E, dbias = rowscale^T E, dxn = rowscale * (E W^T)
         self._wgrad(self.xs, d, E, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
                     dbias=self._gv("to_logits/linear_out/bias"), bias_weights=self.rowscale_bf)
@@ -639,6 +652,8 @@ class DalleEngine:
         dh.embed_bwd(self.tok_sorted, self.tok_perm, dxa, self._gv("embedding/wte"), self._gv("positional_embedding/wpe"),
                      B, S, d, self.V, self.embed_ws)
         ready(rp[L + 1])
+        if self.dp_reserve_cus and allreduce:
+            dh.set_option("reserve_cus", 0)
 
     def wait_grads(self):
         self.reducer.finish()

@@ -71,8 +71,8 @@ def _sorted(tok_flat, V):
 
 @pytest.mark.parametrize("n,V", [(1, 5), (37, 16), (1024, 17), (5000, 50771), (40960, 50771), (2049, 70000), (4097, 2)])
 def test_sort_tokens_is_stable(n, V):
-    """one-block radix sort: bit-identical to a stable sort (ids and source positions), for 1..5 digit passes, ragged
-    per-thread chunks and heavy duplicates (the padding id)."""
+    """multi-block radix sort (count / scan / scatter per 4-bit digit): bit-identical to a stable sort (ids and source
+    positions), for 1..5 digit passes, ragged and empty per-thread chunks and heavy duplicates (the padding id)."""
     g = torch.Generator().manual_seed(n)
     tok = torch.randint(0, V, (n,), generator=g, dtype=torch.int32)
     tok[n // 3: 2 * n // 3] = V - 1
@@ -729,6 +729,28 @@ def _attention_fwd_bwd(B, H, S):
         scale = float(gref[:, i].abs().max())
         close(got[:, i], gref[:, i], 3e-2, 2e-2 * scale, f"attn bwd d{nm}")
     return dqkv
+
+
+def test_persistent_grids_with_reserved_cus():
+    """[r04] option reserve_cus (set by the engine when world_size > 1: the RCCL channels of the gradient exchange need CUs, and a
+    persistent block whose CU is taken starts late): the persistent kernels run on 240 instead of 256 blocks -- same results,
+    bit for bit (attention forward / backward vs fp32 autograd at a shape with many items per block; persistent 256x256 NT
+    kernel; the full-row kernel steps aside)."""
+    base = _attention_fwd_bwd(8, 4, 640)
+    A, Bt = rnd(6000, 512, seed=1), rnd(5000, 512, scale=0.2, seed=2)
+    C0 = torch.zeros(6000, 5000, dtype=torch.bfloat16, device=DEV)
+    C1 = torch.zeros(6000, 5000, dtype=torch.bfloat16, device=DEV)
+    dh.set_option("nt8p", 2)
+    dh.gemm_nt(A.to(DEV), 512, Bt.to(DEV), 512, C0, 5000, 6000, 5000, 512, 0)
+    dh.set_option("reserve_cus", 16)
+    try:
+        assert dh.get_option("reserve_cus") == 16
+        again = _attention_fwd_bwd(8, 4, 640)
+        dh.gemm_nt(A.to(DEV), 512, Bt.to(DEV), 512, C1, 5000, 6000, 5000, 512, 0)
+    finally:
+        dh.set_option("reserve_cus", 0)
+        dh.set_option("nt8p", 1)
+    assert torch.equal(base, again) and torch.equal(C0, C1)
 
 
 def test_attention_row0_kat():
