@@ -43,8 +43,6 @@ static int g_opt_cstream_min_mb = 256;
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
 static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
                                  // tiles per CU), 2 whenever the shape allows it (tests, tools/kbench.py)
-static int g_opt_nt8p_pd = 1;    // load pipeline of the persistent kernel: 1 = v8p (64-wide k-steps, two buffers, one k-step ahead),
-                                 // 2 / 3 = v8q (32-wide k-steps, four buffers, 2 / 3 k-steps ahead, counted vmcnt)
 static int g_opt_nt8p_max_k = 1024;   // auto mode: K above this keeps the one-tile-per-block kernels (the main loop then dominates a tile)
 static int g_opt_nt4_lds = 49152;   // dynamic LDS requested by the 256x128 NT kernel: 49152 = what it uses (3 blocks / CU); 65536 / 98304
                                     // cap the residency at 2 / 1 blocks per CU (tools/phases.py: a block's phases without co-resident blocks)
@@ -60,7 +58,6 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "cstream")) return g_opt_cstream;
   if (!strcmp(name, "cstream_min_mb")) return g_opt_cstream_min_mb;
   if (!strcmp(name, "nt8p_max_k")) return g_opt_nt8p_max_k;
-  if (!strcmp(name, "nt8p_pd")) return g_opt_nt8p_pd;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
@@ -79,7 +76,6 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "cstream")) { g_opt_cstream = value; return 0; }
   if (!strcmp(name, "cstream_min_mb")) { g_opt_cstream_min_mb = value; return 0; }
   if (!strcmp(name, "nt8p_max_k")) { g_opt_nt8p_max_k = value; return 0; }
-  if (!strcmp(name, "nt8p_pd")) { if (value < 1 || value > 3) return -1; g_opt_nt8p_pd = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
@@ -208,8 +204,8 @@ __device__ __forceinline__ void stage_rows32(const f32x4 (&acc)[2 * MI][4], int 
 // 10 % SLOWER than the LDS form: the co-resident blocks' DMA loads share the memory path with those stores, r04b_kbench_k512.log.)
 // No LDS, no waits, the 2 MI row tiles of a wave are independent chains.  The ReLU mask of the FFN-2 input gradient is applied
 // to the ROUNDED values after the transpose (a select commutes with rounding: bit-identical) from two 16-B loads of the
-// lane's own 16 columns.  The residual epilogues (fp32 add before rounding) keep the LDS form.  bf16 outputs are bit-identical
-// to the LDS form; the softmax row-sum partials add the same 64 fp32 exponentials in a different (fixed) order.
+// lane's own 16 columns; a residual is added in fp32 BEFORE rounding from 8-B pieces in the accumulator layout.  bf16 outputs are
+// bit-identical to the LDS form; the softmax row-sum partials add the same 64 fp32 exponentials in a different (fixed) order.
 // Where it is used: the persistent 256x256 kernel (gemm_nt8p_kernel), whose stage buffers must stay free for the next tile's
 // prefetch.  In the one-tile-per-block kernels it measured equal (vocabulary projection) to 6-18 % SLOWER (QKV, FFN-1, FFN-2
 // input gradient: profiles/r04c_kbench_k512.log, step 16.35 -> 16.50 ms): a lone block's plain epilogue takes 4.8 k cycles in
@@ -960,129 +956,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
   }
 }
 
-// =====================================================================================
-// NT kernel v8q: v8p with a deeper load pipeline -- k-steps of 32 in FOUR 32-KiB buffers (A 256 rows x 64 B | B 256 rows x 64 B,
-// the 64-B-row swizzle of the 256x128 kernel), the load of k-step s + PD issued under k-step s (PD = 2 or 3 k-steps = 2-3 k
-// cycles of cover) and waited for with a COUNTED vmcnt: the pieces of the youngest PD - 1 k-steps stay in flight across the
-// barrier.  v8p loads one 64-wide k-step ahead: where the weight matrix streams from the Infinity Cache / HBM (vocabulary
-// projection: 52 MB) a load does not land within the 2 k cycles of the k-step it hides behind and every k-step ends in a
-// wait (4.0 k cycles per k-step against 3.0 k with an L2-resident weight matrix, tools/phases.py).
-// =====================================================================================
-template <int FLAGS, int PD>
-__global__ __launch_bounds__(512, 2) void gemm_nt8q_kernel(GemmArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 buffers][A 16K | B 16K]
-  constexpr int BUF = 32768;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 2, wn = wid & 3;
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int ns = a.K / 32;   // k-steps per tile, a multiple of 4
-
-  const int c16 = lane & 15, g16 = lane >> 4;
-  const int offa = lds4_off(wm * 128 + c16, g16);            // 16-row tiles are 1024 B apart
-  const int offb = 16384 + lds4_off(wn * 64 + c16, g16);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)(((int64_t)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
-  int voa[2], vob[2];      // per-lane source offsets inside a tile, tile-independent: chunk c = tid + 512 i -> row c / 4, 16-B piece c % 4
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 512 * i, row = c >> 2, pc = c & 3;
-    voa[i] = (row * a.lda + 8 * (pc ^ lds4_swz(row))) * 2;
-    vob[i] = (row * a.ldb + 8 * (pc ^ lds4_swz(row))) * 2;
-  }
-  auto load = [&](int buf, int sa, int sb) {   // a whole k-step at once (first tile only)
-    char* dst = smem + buf * BUF + wid * 1024;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      glds16(ra, dst + i * 8192, voa[i], sa);
-      glds16(rb, dst + 16384 + i * 8192, vob[i], sb);
-    }
-  };
-
-  f32x4 acc[8][4];
-  // k-step in buffer `buf` as 8 groups of 4 MFMAs (A fragment g against the four B fragments); behind groups 0..3 go the four
-  // 1-KB pieces of the load into buffer `nbuf`; order pinned by sched_barrier(0), fragments requested two groups ahead
-  auto compute = [&](int buf, int nbuf, int sa, int sb) {
-    const char* cur = smem + buf * BUF;
-    char* dst = smem + nbuf * BUF + wid * 1024;
-    bf16x8 fb[4], fa[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(cur + offb + j * 1024);
-    fa[0] = *(const bf16x8*)(cur + offa);
-    fa[1] = *(const bf16x8*)(cur + offa + 1024);
-    MFMA_PRIO(1);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g + 2 < 8) fa[g + 2] = *(const bf16x8*)(cur + offa + (g + 2) * 1024);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[g], acc[g][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
-      if (g < 2) glds16(ra, dst + g * 8192, voa[g], sa);
-      else if (g < 4) glds16(rb, dst + 16384 + (g - 2) * 8192, vob[g - 2], sb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    MFMA_PRIO(0);
-  };
-
-  int v = blockIdx.x;
-  if (v >= ntiles) return;
-  int tm, tn;
-  tile_of_block(xcd_remap(v, ntiles), a.tiles_m, a.tiles_n, tm, tn);
-  int m0 = tm * BM8, n0 = tn * BN8;
-#pragma unroll
-  for (int s = 0; s < PD; ++s) load(s, m0 * a.lda * 2 + s * 64, n0 * a.ldb * 2 + s * 64);   // first tile only: k-steps 0 .. PD-1
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  unsigned long long c_main = 0, c_epi = 0, c_first = 0, c_start = 0;   // tools/phases.py: per-block phase totals (a.dbg only)
-  int ntl = 0;
-  if (a.dbg) c_start = __builtin_readcyclecounter();
-  while (true) {
-    // on entry: k-step 0 of this tile has landed in buffer 0; k-steps 1 .. PD-1 are landed or in flight in buffers 1 .. PD-1
-    unsigned long long s0 = 0, s1 = 0, s2 = 0;
-    if (a.dbg) s0 = __builtin_readcyclecounter();
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int vn = v + gridDim.x;
-    const bool has_next = vn < ntiles;       // block-uniform
-    int nm0 = m0, nn0 = n0;                  // the last tile of a block re-loads its own first k-steps into idle buffers: harmless
-    if (has_next) {
-      int tm2, tn2;
-      tile_of_block(xcd_remap(vn, ntiles), a.tiles_m, a.tiles_n, tm2, tn2);
-      nm0 = tm2 * BM8; nn0 = tn2 * BN8;
-    }
-    const int ca = m0 * a.lda * 2, cb = n0 * a.ldb * 2;        // this tile's origin in A / B (bytes)
-    const int na = nm0 * a.lda * 2, nb = nn0 * a.ldb * 2;      // the next tile's
-    for (int s = 0; s < ns; s += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        // k-step s+u in buffer u while k-step s+u+PD (of this tile, or of the next one) loads into buffer (u + PD) % 4
-        const int q = s + u + PD;
-        const bool nxt = q >= ns;
-        const int kq = (nxt ? q - ns : q) * 64;
-        compute(u, (u + PD) & 3, (nxt ? na : ca) + kq, (nxt ? nb : cb) + kq);
-        // the 4 pieces of each of the youngest PD - 1 k-steps may stay in flight: k-step s+u+1 is the oldest of the rest
-        if constexpr (PD == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (PD == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (a.dbg && s == 0 && u == 0) c_first += __builtin_readcyclecounter() - s0;
-      }
-    }
-    if (a.dbg) s1 = __builtin_readcyclecounter();
-    epilogue_regs<FLAGS, 8>(a, acc, lane, m0 + wm * 128, n0 + wn * 64);
-    if (a.dbg) { s2 = __builtin_readcyclecounter(); c_main += s1 - s0; c_epi += s2 - s1; ++ntl; }
-    if (!has_next) break;
-    v = vn; m0 = nm0; n0 = nn0;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the idle re-loads of the last tile
-  if (a.dbg && tid == 0) {   // {life, main loops, epilogues (issue), first k-steps, tiles} of this block
-    unsigned long long* d = a.dbg + (size_t)blockIdx.x * 6;
-    d[0] = __builtin_readcyclecounter() - c_start; d[1] = c_main; d[2] = c_epi; d[3] = c_first; d[4] = (unsigned long long)ntl; d[5] = 0;
-  }
-}
+// (A form of this kernel with a deeper load pipeline -- 32-wide k-steps in four buffers, loads 2 or 3 k-steps ahead with a counted
+// vmcnt: gemm_nt8q_kernel on the branch r04-kernel-variants -- measured the same cycles per k-step on the head, 3915 / 4145 / 4144
+// at depths 1 / 2 / 3, and 2-10 % slower overall (twice the barriers): the load RATE bounds these k-steps, not the load latency.)
 
 // =====================================================================================
 // NT kernel "row" (round 4): FULL-ROW tiles for the products with N = 512 outputs (out-projection, FFN-2, the three input
@@ -1546,18 +1422,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
       if (!attr8p) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8p = true; }
       GemmArgs b = a;
       b.tiles_m = t8m; b.tiles_n = t8n;
-      if (g_opt_nt8p_pd == 1) {
-        gemm_nt8p_kernel<FLAGS><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
-      } else {
-        static bool attr8q = false;
-        if (!attr8q) {
-          (void)hipFuncSetAttribute((const void*)gemm_nt8q_kernel<FLAGS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-          (void)hipFuncSetAttribute((const void*)gemm_nt8q_kernel<FLAGS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-          attr8q = true;
-        }
-        if (g_opt_nt8p_pd == 2) gemm_nt8q_kernel<FLAGS, 2><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
-        else gemm_nt8q_kernel<FLAGS, 3><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
-      }
+      gemm_nt8p_kernel<FLAGS><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
       DMI_CHECK_LAUNCH("gemm_nt8p");
       return DMI_OK;
     }

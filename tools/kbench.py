@@ -51,15 +51,13 @@ def bench_gemm_nt(M, N, K, flags=0, tag="", variants=(("auto", 1),)):
     for name, nt4 in variants:
         dh.set_option("nt4", nt4 if nt4 < 8 else 0)
         dh.set_option("nt8", 2 if nt4 == 8 else 0)
-        dh.set_option("nt8p", 2 if 9 <= nt4 <= 11 else 0)      # 9 / 10 / 11: persistent 256x256 kernel, loads 1 / 2 / 3 k-steps ahead
-        dh.set_option("nt8p_pd", min(3, max(1, nt4 - 8)))
+        dh.set_option("nt8p", 2 if nt4 == 9 else 0)            # 9: persistent 256x256 kernel
         dh.set_option("ntr", 2 if nt4 == 12 else 0)            # 12: full-row 160x512 tiles (N = 512 only)
         t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res, rowscale=rs))
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     dh.set_option("nt4", 1)
     dh.set_option("nt8", 1)
     dh.set_option("nt8p", 1)
-    dh.set_option("nt8p_pd", 1)
     dh.set_option("ntr", 1)
 
 
@@ -168,7 +166,7 @@ if __name__ == "__main__":
         for ns, nt8 in ((2, 0), (4, 0), (4, 2), (8, 2)):
             bench_splitk(M, 512, 50816, ns, nt8)
     if "k512" in what:     # the K = 512 products on every NT tile + the fused softmax head on the 256x128 / 256x256 tiles
-        three = (("nt2", 0), ("nt4", 2), ("nt8", 8), ("nt8p", 9), ("nt8q2", 10), ("nt8q3", 11))
+        three = (("nt2", 0), ("nt4", 2), ("nt8", 8), ("nt8p", 9))
         bench_gemm_nt(M, 3 * d, d, 0, " qkv", three)
         bench_gemm_nt(M, 4 * d, d, 3, " ffn1", three)
         bench_gemm_nt(M, 4 * d, d, 8, " ffn2-dgrad", three)
@@ -177,23 +175,22 @@ if __name__ == "__main__":
         bias = torch.zeros(Vp, device=DEV, dtype=torch.bfloat16)
         part = torch.empty(dh.gemm_nt_softmax_partials(Vp), M, dtype=torch.float32, device=DEV)
         E = torch.empty(M, Vp, dtype=torch.bfloat16, device=DEV)
-        for name, nt4, nt8, nt8p, pd in (("nt4", 2, 0, 0, 1), ("nt8p", 0, 0, 2, 1), ("nt8q2", 0, 0, 2, 2), ("nt8q3", 0, 0, 2, 3),
-                                         ("nt4", 2, 0, 0, 1), ("nt8p", 0, 0, 2, 1), ("nt8q2", 0, 0, 2, 2), ("nt8q3", 0, 0, 2, 3)):
-            dh.set_option("nt4", nt4); dh.set_option("nt8", nt8); dh.set_option("nt8p", nt8p); dh.set_option("nt8p_pd", pd)
+        for name, nt4, nt8, nt8p in (("nt4", 2, 0, 0), ("nt8", 0, 2, 0), ("nt8p", 0, 0, 2), ("nt4", 2, 0, 0), ("nt8", 0, 2, 0), ("nt8p", 0, 0, 2)):
+            dh.set_option("nt4", nt4); dh.set_option("nt8", nt8); dh.set_option("nt8p", nt8p)
             t = timeit(lambda: dh.gemm_nt_softmax(X, d, Wt, d, bias, None, E, Vp, part, M, Vp, d), iters=10)
             print(f"head gemm_nt_softmax (no shift) {name}: {t*1e6:9.1f} us  {2.0*M*d*50771/t/1e12:8.1f} TF/s", flush=True)
-        dh.set_option("nt4", 1); dh.set_option("nt8", 1); dh.set_option("nt8p", 1); dh.set_option("nt8p_pd", 1)
+        dh.set_option("nt4", 1); dh.set_option("nt8", 1); dh.set_option("nt8p", 1)
     if "pmchead" in what:    # the fused-softmax vocabulary GEMM on the 256x128 and the persistent 256x256 kernels (tools/pmc_kernel.sh)
         Vp = 50816
         X, Wt = rb(M, d), rb(Vp, d, scale=0.02)
         bias = torch.zeros(Vp, device=DEV, dtype=torch.bfloat16)
         part = torch.empty(dh.gemm_nt_softmax_partials(Vp), M, dtype=torch.float32, device=DEV)
         E = torch.empty(M, Vp, dtype=torch.bfloat16, device=DEV)
-        for name, nt4, nt8p, pd in (("nt4", 2, 0, 1), ("nt8p", 0, 2, 1), ("nt8q3", 0, 2, 3)):
-            dh.set_option("nt4", nt4); dh.set_option("nt8p", nt8p); dh.set_option("nt8p_pd", pd)
+        for name, nt4, nt8p in (("nt4", 2, 0), ("nt8p", 0, 2)):
+            dh.set_option("nt4", nt4); dh.set_option("nt8p", nt8p)
             t = timeit(lambda: dh.gemm_nt_softmax(X, d, Wt, d, bias, None, E, Vp, part, M, Vp, d), iters=3)
             print(f"head gemm_nt_softmax (no shift) {name}: {t*1e6:9.1f} us", flush=True)
-        dh.set_option("nt4", 1); dh.set_option("nt8p", 1); dh.set_option("nt8p_pd", 1)
+        dh.set_option("nt4", 1); dh.set_option("nt8p", 1)
     if "n512" in what:     # the products with N = 512 outputs: 128x128 tiles vs full-row 160x512 tiles
         two = (("nt2", 0), ("ntr", 12), ("nt2", 0), ("ntr", 12))
         bench_gemm_nt(M, d, d, 5, " attn-out", two)

@@ -54,8 +54,8 @@ def nt_phases(lds):
           f"own MFMA issue / block life = {mfma_ticks/(t4-t0).mean():.3f}")
 
 
-def nt8p_phases(pd):
-    dh.set_option("nt4", 0); dh.set_option("nt8p", 2); dh.set_option("nt8p_pd", pd)
+def nt8p_phases():
+    dh.set_option("nt4", 0); dh.set_option("nt8p", 2)
     for _ in range(3):
         launch()
     dbg = torch.zeros(256, 6, dtype=torch.int64, device="cuda")
@@ -66,11 +66,11 @@ def nt8p_phases(pd):
     dh.set_debug_buffer(dbg)
     e0.record(); launch(); e1.record(); torch.cuda.synchronize()
     dh.set_debug_buffer(None)
-    dh.set_option("nt4", 2); dh.set_option("nt8p", 0); dh.set_option("nt8p_pd", 1)   # (this tool's other sections force the 256x128 kernel)
+    dh.set_option("nt4", 2); dh.set_option("nt8p", 0)   # (this tool's other sections force the 256x128 kernel)
     d = dbg.cpu().numpy().astype(np.float64)
     d = d[d[:, 4] > 0]
     life, main, epi, first, n = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
-    print(f"--- persistent 256x256 (loads {pd} k-step(s) ahead) {MODE} N={N} K={K}: kernel {plain_us:.1f} us plain ({2*M*N*K/plain_us/1e6:.0f} TF/s), {e0.elapsed_time(e1)*1e3:.1f} us stamped; "
+    print(f"--- persistent 256x256 {MODE} N={N} K={K}: kernel {plain_us:.1f} us plain ({2*M*N*K/plain_us/1e6:.0f} TF/s), {e0.elapsed_time(e1)*1e3:.1f} us stamped; "
           f"{len(d)} blocks, {n.mean():.1f} tiles each; ticks/us {life.mean()/(e0.elapsed_time(e1)*1e3):.0f}")
     print(f"per tile: life {np.mean(life/n):.0f}  main loop {np.mean(main/n):.0f} (per k-step(64) {np.mean(main/n)/(K/64):.0f}; first k-step incl. store drain {np.mean(first/n):.0f})  "
           f"epilogue issue {np.mean(epi/n):.0f}; own MFMA issue per wave {K/64*64*16:.0f}")
@@ -78,8 +78,7 @@ def nt8p_phases(pd):
 
 if MODE == "softmax8p" or MODE == "bias8p":
     MODE = MODE[:-2]
-    for pd in (1, 2, 3):
-        nt8p_phases(pd)
+    nt8p_phases()
     sys.exit(0)
 if MODE != "tn":
     for lds in (49152, 65536, 98304):
