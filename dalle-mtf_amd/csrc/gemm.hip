@@ -37,8 +37,9 @@ static int g_opt_nt8_min_k = 2048;   // auto mode of the 256x256 NT tile: minimu
                                      // run 354 -> 339 ms/step (profiles/r03_ab_nt8_min_k.log); K = 1024 measured equal, K = 512 slower
 static int g_opt_skinny = 1;     // M <= 32 products (the decode step) on the weight-streaming kernel: 0 never, 1 auto
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
-static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1): 0 never, 1 auto (outputs >= cstream_min_mb MiB: they cannot be re-read from
-                                 // L2 anyway, and as plain stores they evict the operand panels the co-resident tiles share), 2 always
+static int g_opt_cstream = 1;    // bf16 outputs stored write-through + non-temporal (sc1 nt): 0 never, 1 auto (outputs >= cstream_min_mb MiB: they cannot
+                                 // be re-read from a cache anyway, and as plain stores they evict the operands the concurrent tiles share), 2 always sc1,
+                                 // 3 always sc1 nt, 4 auto with sc1 only (A/B)
 static int g_opt_cstream_min_mb = 256;
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
 static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
@@ -107,7 +108,7 @@ struct GemmArgs {
   int k_per_split;     // multiple of BK
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
-  int cpol;                 // cache policy of the bf16 output stores: 0 plain, 1 sc1 (write-through, the line is not kept in the XCD's L2)
+  int cpol;                 // cache policy of the bf16 output stores: 0 plain, 1 sc1 (write-through, the line is not kept in the XCD's L2), 2 sc1 nt
   // fused LayerNorm of the output rows (dmi_gemm_nt_ln, full-row tiles only): Y = LN(C) * gamma + beta, row statistics
   const bf16_t* ln_gamma;
   const bf16_t* ln_beta;
@@ -161,7 +162,9 @@ __device__ __forceinline__ int lds4_off(int row, int ch) { return row * 64 + ((c
 //   32x32x16: acc[MI][2] (f32x16): lane (r = lane & 31, h = lane >> 5) holds row r, columns j*32 + 8q + 4h + {0..3}
 //   16x16x32: acc[2 MI][4] (f32x4): lane (c = lane & 15, g = lane >> 4) holds row ii*16 + c, columns j*16 + 4g + {0..3}
 // 16-B store of 8 bf16 outputs at element offset `off` of C.  cpol 1: through a buffer descriptor with the sc1 bit -- written
-// through to the memory side, the line is not kept in the XCD's L2.  The 4 GB of softmax numerators the vocabulary projection
+// through to the memory side, the line is not kept in the XCD's L2; cpol 2 (what the auto mode picks): sc1 + nt, non-temporal as
+// well -- the stream does not displace the re-read operands from the Infinity Cache either: vocabulary projection 2505 -> 2125 us
+// (1000 TFLOP/s) on top of the 2500 <- 2535 of sc1 alone, step -0.27 ms (profiles/r04ac_kbench_nt_store.log, r04ad_kbench_nt.log).  The 4 GB of softmax numerators the vocabulary projection
 // writes would otherwise pass through the 4-MiB L2s as dirty lines and evict the A / B panels that the XCD's 32 concurrent tiles
 // share (round 3 measured 2.5 GB fetched per launch against 94 MB of operands).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t c_rsrc(const GemmArgs& a) {
@@ -169,6 +172,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t c_rsrc(const GemmArgs& a) {
 }
 __device__ __forceinline__ void store_c16(const GemmArgs& a, __amdgpu_buffer_rsrc_t rc, int64_t off, u32x4 v) {
   if (a.cpol == 1) __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(unsigned)(off * 2), 0, 16);
+  else if (a.cpol == 2) __builtin_amdgcn_raw_buffer_store_b128(v, rc, (int)(unsigned)(off * 2), 0, 18);   // sc1 nt
   else *(u32x4*)((bf16_t*)a.C + off) = v;
 }
 
@@ -450,6 +454,8 @@ __device__ __forceinline__ void epilogue_bf16(const GemmArgs& a, ACC& acc, float
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, int voff, int soff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
+// (A non-temporal hint on the LOADS of the streamed operand of the head's two gradient products -- the 4-GB softmax numerators -- was
+// measured and dropped: weight gradient 1984 -> 2080 us, input gradient unchanged, step +0.07 ms, profiles/r04ad_kbench_nt.log.)
 
 template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
@@ -1477,7 +1483,10 @@ static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t
   a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
   const int64_t cbytes = ((int64_t)(M - 1) * ldc + N) * 2;     // bf16 outputs (the fp32 forms do not use the policy)
-  a.cpol = (cbytes < (int64_t)0xffffffff && (g_opt_cstream == 2 || (g_opt_cstream == 1 && cbytes >= ((int64_t)g_opt_cstream_min_mb << 20)))) ? 1 : 0;
+  // 1 (default): auto by size, sc1 nt; 2: always sc1; 3: always sc1 nt; 4: auto by size, sc1 only (A/B)
+  const bool big = cbytes >= ((int64_t)g_opt_cstream_min_mb << 20);
+  const int pol = (g_opt_cstream == 1 && big) ? 2 : (g_opt_cstream == 2) ? 1 : (g_opt_cstream == 3) ? 2 : (g_opt_cstream == 4 && big) ? 1 : 0;
+  a.cpol = cbytes < (int64_t)0xffffffff ? pol : 0;
 }
 
 extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc, int M, int N,
