@@ -208,7 +208,7 @@ __device__ __forceinline__ bool attn_item(const AttnSched& s, int r, int& tile, 
 #define QK_STAGE 32768  // K 16384 | V 16384
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                           float* __restrict__ lse, int B, int H, int S, int perxcd) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE (+ 4 x PDS_WAVE)
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int T = (S + 127) / 128;
   const AttnSched sched = attn_sched(T, B * H, perxcd);
@@ -421,51 +421,11 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
 // The kernel also produces delta[q] = sum_d dO[q,d] O[q,d] itself (a lane pair holds the whole dO row of its query as MFMA
 // fragments; O is read in the same layout) and publishes the (lse, delta) pairs the dK/dV kernel streams in -- the
 // separate delta pass (17 us per layer) is gone.
-// PDS (the two-pass backward, see attn_bwd_dkv2_kernel): the kernel also WRITES what it computes on the way -- P = softmax
-// probabilities and dS = P (dP - delta), bf16, as the row-major matrices P[bh][q][key], dS[bh][q][key] (row pitch S; S % 128 == 0)
-// -- for every key of the 128-key blocks up to and including the diagonal one (zeros above the diagonal), so that the dK / dV
-// pass is two products over streamed operands instead of four with a softmax in between.
-// A lane holds 4 consecutive keys of ITS query row per accumulator group: stored from there, an instruction writes 8 bytes to
-// 32 different rows -- measured 405 us for the backward instead of 270 (and 905 / 1820 us with the write-through policies, which
-// send every 8-byte piece to memory on its own; profiles/r04ag_kbench_attn.log).  So a 32 x 32 sub-tile goes through a
-// wave-private 2.5-KB LDS block (rows padded to 80 B: the 8-byte writes of 32 rows conflict 2-way, the 16-byte reads land
-// 4 rows x 64 B per quarter-wave) and leaves as 16 bytes per lane, 16 rows x 64 contiguous bytes per instruction; P and dS use
-// the block one after the other (a wave's LDS operations execute in order: no wait between the reads of one and the writes of the
-// next).  Cache policy POL (0 plain, 1 sc1, 2 sc1 nt) is compile-time: a run-time choice around every store tore the schedule
-// of the loop apart.
-#define PDS_PITCH 80
-#define PDS_WAVE (32 * PDS_PITCH)
-template <int POL>
-__device__ __forceinline__ void pds_store16(__amdgpu_buffer_rsrc_t rs, u32x4 v, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, POL == 2 ? 18 : POL == 1 ? 16 : 0);
-}
-// pieces pc[g] = this lane's keys 8g + 4h + {0..3}; wa = row-major write address of (row r, key 4h), ra = read address of
-// (row lane >> 2, keys 8 (lane & 3)); the lane then stores rows (lane >> 2) and 16 + (lane >> 2)
-template <int POL>
-__device__ __forceinline__ void pds_out(__amdgpu_buffer_rsrc_t rs, u32x2 p0, u32x2 p1, u32x2 p2, u32x2 p3, unsigned wa, unsigned ra,
-                                        int voff, int soff, int soff16) {
-  u32x4 x0, x1;
-  asm volatile(
-      "ds_write_b64 %2, %4\n\t"
-      "ds_write_b64 %2, %5 offset:16\n\t"
-      "ds_write_b64 %2, %6 offset:32\n\t"
-      "ds_write_b64 %2, %7 offset:48\n\t"
-      "ds_read_b128 %0, %3\n\t"
-      "ds_read_b128 %1, %3 offset:1280\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(x0), "=&v"(x1)
-      : "v"(wa), "v"(ra), "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-      : "memory");
-  pds_store16<POL>(rs, x0, voff, soff);
-  pds_store16<POL>(rs, x1, voff, soff16);
-}
-template <bool PDS, int POL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, float* __restrict__ stats,
-                                                             bf16_t* __restrict__ dqkv, bf16_t* __restrict__ pds,
-                                                             int B, int H, int S, int perxcd) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE (+ 4 x PDS_WAVE)
+                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int T = (S + 127) / 128;
   const AttnSched sched = attn_sched(T, B * H, perxcd);
@@ -487,16 +447,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const int nbytes = (int)(((int64_t)(S - 1) * ld3 + HD) * 2);
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + d), 0, nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 2 * d), 0, nbytes, 0x00020000);
-  __amdgpu_buffer_rsrc_t rp, rds;   // PDS: this (batch, head)'s P and dS matrices
-  int pvo = 0;                      //      byte offset of the 16-byte piece this lane stores (after the LDS transpose)
-  if constexpr (PDS) {
-    const int64_t mat = (int64_t)S * S;
-    rp = __builtin_amdgcn_make_buffer_rsrc((void*)(pds + (int64_t)bh * mat), 0, (int)(mat * 2), 0x00020000);
-    rds = __builtin_amdgcn_make_buffer_rsrc((void*)(pds + ((int64_t)B * H + bh) * mat), 0, (int)(mat * 2), 0x00020000);
-    pvo = ((q0 + wid * 32 + (lane >> 2)) * S + 8 * (lane & 3)) * 2;   // rows (lane >> 2) [+ 16] of the wave, keys 8 (lane & 3) ..
-  }
-  [[maybe_unused]] const unsigned pwa = lds0 + 2 * QK_STAGE + wid * PDS_WAVE + r * PDS_PITCH + 8 * h;
-  [[maybe_unused]] const unsigned pra = lds0 + 2 * QK_STAGE + wid * PDS_WAVE + (lane >> 2) * PDS_PITCH + 16 * (lane & 3);
 
   bf16x8 qf[8], dof[8];
 #pragma unroll
@@ -546,7 +496,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const int rr = l16 >> 2;
   // transposed-fragment offsets of d-tile 0; d-tile dt is the same offset with bits 6..7 XORed by dt (the chunk index dt * 4 + c,
   // c < 4, enters through an XOR swizzle).  Only these two stay in registers: the eight per-d-tile offsets did not fit next to
-  // the accumulators and were spilled -- and a scratch reload waits with vmcnt(0), i.e. for every LDS-DMA (and store) in flight.
+  // the accumulators and were spilled (19 VGPRs, reloaded inside the loop; a scratch reload waits with vmcnt(0), i.e. for every LDS-DMA in flight).
+  // 256 VGPRs + 80 B of scratch -> 213 VGPRs, no scratch; the kernel time did not change (profiles/r04ag_kbench_attn.log).
   unsigned oft0[2];
 #pragma unroll
   for (int w2 = 0; w2 < 2; ++w2) {
@@ -587,27 +538,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       const unsigned t0 = ob + oft0[0], t1 = ob + oft0[1];   // (tile base + offset) ^ (dt << 6): the base is a multiple of 4096
       tr2_issue(tk[0], lds0 + t0, lds0 + t1, lds0 + (t0 ^ 64u), lds0 + (t1 ^ 64u));
       float ds[16];
-      [[maybe_unused]] float pe4[4];
-      [[maybe_unused]] u32x2 pp[4];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int key = 64 * j + kt2 * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         const float pe = __builtin_amdgcn_exp2f((key > qrow) ? -INFINITY : __builtin_fmaf(s[e], LOG2E_F, -lse2_q));  // unconditional exp: no per-element branches
         ds[e] = pe * (dp[e] - delta_q);
-        if constexpr (PDS) {
-          pe4[e & 3] = pe;
-          if ((e & 3) == 3) pp[e >> 2] = u32x2{pack2bf(pe4[0], pe4[1]), pack2bf(pe4[2], pe4[3])};   // keys 8g + 4h + {0..3}, g = e >> 2
-        }
       }
       bf16x8 dsb[2];
       dsb[0] = pack_bf8(ds);
       dsb[1] = pack_bf8(ds + 8);
-      if constexpr (PDS) {
-        const int so = (64 * j + 32 * kt2) * 2, so16 = so + 16 * S * 2;
-        pds_out<POL>(rp, pp[0], pp[1], pp[2], pp[3], pwa, pra, pvo, so, so16);
-        const u32x4 w0 = __builtin_bit_cast(u32x4, dsb[0]), w1 = __builtin_bit_cast(u32x4, dsb[1]);
-        pds_out<POL>(rds, u32x2{w0[0], w0[1]}, u32x2{w0[2], w0[3]}, u32x2{w1[0], w1[1]}, u32x2{w1[2], w1[3]}, pwa, pra, pvo, so, so16);
-      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int s2 = q >> 1, dp2 = (q & 1) * 2;  // d-tiles dp2, dp2+1
@@ -640,18 +579,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
   if (j < nsteps) compute(0, j);
 
-  if constexpr (PDS) {
-    // the one tile compute() skips inside the diagonal block: its second 64 keys for the waves whose queries all lie in the
-    // first 64 (waves 0 and 1).  The dK / dV pass reads whole 128-key blocks: zeros there.
-    if (wid < 2) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {   // (32-key sub-tile, rows +0 / +16)
-        const int so = (q0 + 64 + 32 * (i >> 1)) * 2 + (i & 1) * 16 * S * 2;
-        pds_store16<POL>(rp, u32x4{0u, 0u, 0u, 0u}, pvo, so);
-        pds_store16<POL>(rds, u32x4{0u, 0u, 0u, 0u}, pvo, so);
-      }
-    }
-  }
   if (qrow < S) {
     bf16_t* op = dqkv + ((int64_t)b * S + qrow) * ld3 + hh * HD;
 #pragma unroll
@@ -983,242 +910,40 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   }   // items
 }
 
-// ---- dK/dV kernel of the two-pass backward ---------------------------------------------------------------------------
-// With P and dS on hand (written by attn_bwd_dq_kernel<true>) the pass is two products per query tile and no softmax:
-//   dV^T[d][key] += dO^T[d][q] P[q][key]        dK^T[d][key] += Q^T[d][q] dS[q][key]
-// Block = 128 keys (4 waves x 32 keys, every wave all 128 d), 32-query tiles from the diagonal down.  Four natural [32][128]
-// bf16 tiles stream per step by LDS-DMA into a 4-slot ring -- Q, dO (rows = queries, columns = d) and P, dS (rows = queries,
-// columns = this block's keys): the SAME shape, swizzle and hardware-transpose read serve all four, the A operands with the
-// d-tile index where the B operands have the wave's key-tile index, so the contraction-slot -> query mapping of A and B agree
-// by construction.  No V, no K, no statistics; 128 accumulator registers.  The kernel streams 32 KB per 16 MFMAs per wave:
-// it is bound by the P / dS bytes (2 x 2 B per (query, key) pair of the causal half), not by the matrix pipe.
-#define DKV2_STAGE 32768  // Q 8192 | dO 8192 | P 8192 | dS 8192
-#define DKV2_NSTAGE 4
-struct TrB {
-  u32x2 p0, p1, s0, s1;   // P and dS fragments {queries +0..3, +8..11} of one 16-query half
-};
-template <int OFF>
-__device__ __forceinline__ void trb_issue_off(TrB& f, unsigned lo, unsigned hi) {
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %4 offset:%6\n\t"
-      "ds_read_b64_tr_b16 %1, %5 offset:%6\n\t"
-      "ds_read_b64_tr_b16 %2, %4 offset:%7\n\t"
-      "ds_read_b64_tr_b16 %3, %5 offset:%7"
-      : "=&v"(f.p0), "=&v"(f.p1), "=&v"(f.s0), "=&v"(f.s1)
-      : "v"(lo), "v"(hi), "i"(16384 + OFF), "i"(24576 + OFF)
-      : "memory");
-}
-__device__ __forceinline__ void dkv2_wait_all(TrB& b0, TrB& b1, Tr4& x, Tr4& y) {
-  asm volatile("s_waitcnt lgkmcnt(0)"
-               : "+v"(b0.p0), "+v"(b0.p1), "+v"(b0.s0), "+v"(b0.s1), "+v"(b1.p0), "+v"(b1.p1), "+v"(b1.s0), "+v"(b1.s1),
-                 "+v"(x.a0), "+v"(x.a1), "+v"(x.b0), "+v"(x.b1), "+v"(x.c0), "+v"(x.c1), "+v"(x.d0), "+v"(x.d1),
-                 "+v"(y.a0), "+v"(y.a1), "+v"(y.b0), "+v"(y.b1), "+v"(y.c0), "+v"(y.c1), "+v"(y.d0), "+v"(y.d1)
-               :
-               : "memory");
-}
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
-                                                                const bf16_t* __restrict__ pds, bf16_t* __restrict__ dqkv,
-                                                                int B, int H, int S, int perxcd) {
-  extern __shared__ __attribute__((aligned(16))) char sm[];  // 4 x DKV2_STAGE
-  const int d = H * HD, ld3 = 3 * d;
-  const AttnSched sched = attn_sched(S / 128, B * H, perxcd);
-  int ktile, bh;
-  for (int round = 0; attn_item(sched, round, ktile, bh); ++round) {   // every step ends with a barrier: the next item may overwrite the LDS
-  const int b = bh / H, hh = bh % H;
-  const int key0 = ktile * 128;
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));   // opaque per item (see attn_bwd_dkv_kernel)
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
-  const int krow = key0 + wid * 32 + r;
-  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
-  const bf16_t* dob = d_o + (int64_t)b * S * d + hh * HD;
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
-  const int64_t mat = (int64_t)S * S;
-
-  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)qb, 0, (int)(((int64_t)(S - 1) * ld3 + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdo = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(((int64_t)(S - 1) * d + HD) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(pds + (int64_t)bh * mat), 0, (int)(mat * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rds = __builtin_amdgcn_make_buffer_rsrc((void*)(pds + ((int64_t)B * H + bh) * mat), 0, (int)(mat * 2), 0x00020000);
-
-  int voq[2], vod[2], vop[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
-    voq[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
-    vod[i] = (row * d + 8 * (pc ^ swz(row))) * 2;
-    vop[i] = (row * S + key0 + 8 * (pc ^ swz(row))) * 2;
-  }
-  auto stage_qd = [&](int st, int q0, int i) {   // half of a stage's Q + dO chunks
-    char* base = sm + st * DKV2_STAGE;
-    dma16(rq, base + (wid * 64 + 256 * i) * 16, voq[i] + q0 * ld3 * 2);
-    dma16(rdo, base + 8192 + (wid * 64 + 256 * i) * 16, vod[i] + q0 * d * 2);
-  };
-  auto stage_ps = [&](int st, int q0, int i) {   // half of a stage's P + dS chunks
-    char* base = sm + st * DKV2_STAGE;
-    dma16(rp, base + 16384 + (wid * 64 + 256 * i) * 16, vop[i] + q0 * S * 2);
-    dma16(rds, base + 24576 + (wid * 64 + 256 * i) * 16, vop[i] + q0 * S * 2);
-  };
-  auto stage = [&](int st, int q0) {
-    stage_qd(st, q0, 0); stage_qd(st, q0, 1); stage_ps(st, q0, 0); stage_ps(st, q0, 1);
-  };
-  const int rr = l16 >> 2;
-  unsigned oft[4][2], ofb[2];
-#pragma unroll
-  for (int w2 = 0; w2 < 2; ++w2) {
-    const int row = 4 * h + rr + 8 * w2;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int chunk = dt * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);
-      oft[dt][w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
-    }
-    const int chunkb = wid * 4 + 2 * (g4 & 1) + ((l16 & 3) >> 1);   // the wave's 32 keys: columns 32 wid .. 32 wid + 31 of the P / dS tiles
-    ofb[w2] = row * 256 + ((chunkb ^ swz(row)) << 4) + 8 * (l16 & 1);
-  }
-
-  f32x16 dv[4], dk[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) dv[i][e] = dk[i][e] = 0.f;
-
-  const int qi0 = key0 / 32;
-  const int nsteps = S / 32 - qi0;
-
-  Tr4 tdo, tq;
-  TrB b0, b1;
-  auto body = [&](int st, int qi, int t) {
-    const unsigned lb = lds0 + st * DKV2_STAGE;
-    const unsigned ta[8] = {lb + oft[0][0], lb + oft[0][1], lb + oft[1][0], lb + oft[1][1], lb + oft[2][0], lb + oft[2][1], lb + oft[3][0], lb + oft[3][1]};
-    trb_issue_off<0>(b0, lb + ofb[0], lb + ofb[1]);
-    tr4_issue_off<8192>(tdo, ta);
-    tr4_issue_off<0>(tq, ta);
-    trb_issue_off<4096>(b1, lb + ofb[0], lb + ofb[1]);
-    const bool do_dma = t + 3 < nsteps;
-    const int st3 = (st + 3) & 3, q3 = 32 * (qi + 3);
-    Tr4 t2;
-    dkv2_wait_all(b0, b1, tdo, tq);
-    tr4_issue_off<8192 + 4096>(t2, ta);   // dO^T, second 16 queries
-    const bf16x8 pb0 = cat2(b0.p0, b0.p1), sb0 = cat2(b0.s0, b0.s1), pb1 = cat2(b1.p0, b1.p1), sb1 = cat2(b1.s0, b1.s1);
-    dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.a0, tdo.a1), pb0, dv[0], 0, 0, 0);   // dV^T[d][key]
-    dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.b0, tdo.b1), pb0, dv[1], 0, 0, 0);
-    if (do_dma) stage_qd(st3, q3, 0);
-    dv[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.c0, tdo.c1), pb0, dv[2], 0, 0, 0);
-    dv[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.d0, tdo.d1), pb0, dv[3], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    tr4_issue_off<4096>(tdo, ta);   // Q^T, second 16 (tdo's first-16 consumers are above)
-    dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.a0, tq.a1), sb0, dk[0], 0, 0, 0);    // dK^T[d][key]
-    dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.b0, tq.b1), sb0, dk[1], 0, 0, 0);
-    if (do_dma) stage_qd(st3, q3, 1);
-    dk[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.c0, tq.c1), sb0, dk[2], 0, 0, 0);
-    dk[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tq.d0, tq.d1), sb0, dk[3], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    tr4_wait8(t2, tq);   // t2 (older) is in, the 8 reads of the new tdo may still be in flight
-    dv[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(t2.a0, t2.a1), pb1, dv[0], 0, 0, 0);
-    dv[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(t2.b0, t2.b1), pb1, dv[1], 0, 0, 0);
-    if (do_dma) stage_ps(st3, q3, 0);
-    dv[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(t2.c0, t2.c1), pb1, dv[2], 0, 0, 0);
-    dv[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(t2.d0, t2.d1), pb1, dv[3], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    tr4_wait(tdo);       // Q^T of the second 16
-    dk[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.a0, tdo.a1), sb1, dk[0], 0, 0, 0);
-    dk[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.b0, tdo.b1), sb1, dk[1], 0, 0, 0);
-    if (do_dma) stage_ps(st3, q3, 1);
-    dk[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.c0, tdo.c1), sb1, dk[2], 0, 0, 0);
-    dk[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(tdo.d0, tdo.d1), sb1, dk[3], 0, 0, 0);
-  };
-
-  // Ring: at the barrier that opens step t tile t has landed, tiles t+1 and t+2 are in flight; step t issues tile t+3 into the
-  // slot of tile t-1, whose last reader is behind the barrier.  A stage is 8 DMA instructions per lane.
-#define DKV2_WAIT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
-#define DKV2_BARRIER()                                 \
-  do {                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_s_barrier();                      \
-  } while (0)
-  stage(0, 32 * qi0);
-  if (nsteps > 1) stage(1, 32 * (qi0 + 1));
-  if (nsteps > 2) stage(2, 32 * (qi0 + 2));
-  if (nsteps > 2) DKV2_WAIT(16); else if (nsteps == 2) DKV2_WAIT(8); else DKV2_WAIT(0);
-  DKV2_BARRIER();
-  for (int t = 0; t < nsteps; ++t) {
-    body(t & 3, qi0 + t, t);
-    const int rem = nsteps - 1 - t;   // tiles after this one: tile t+1 must have landed when the next step opens
-    if (rem >= 3) DKV2_WAIT(16); else if (rem == 2) DKV2_WAIT(8); else DKV2_WAIT(0);
-    DKV2_BARRIER();
-  }
-#undef DKV2_WAIT
-#undef DKV2_BARRIER
-
-  {
-    bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
-    bf16_t* ovp = okp + d;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int dd = dt * 32 + 8 * q4 + 4 * h;
-        *(u32x2*)(okp + dd) = u32x2{pack2bf(dk[dt][4 * q4], dk[dt][4 * q4 + 1]), pack2bf(dk[dt][4 * q4 + 2], dk[dt][4 * q4 + 3])};
-        *(u32x2*)(ovp + dd) = u32x2{pack2bf(dv[dt][4 * q4], dv[dt][4 * q4 + 1]), pack2bf(dv[dt][4 * q4 + 2], dv[dt][4 * q4 + 3])};
-      }
-  }
-  }   // items
-}
-
-// Two-pass form: with a caller-owned workspace of dmi_attention_bwd_workspace_bytes(B, H, S) the dQ kernel also writes P and dS
-// (bf16, [2][B*H][S][S]; only the causal half is touched) and the dK / dV pass streams them (attn_bwd_dkv2_kernel) instead of
-// recomputing S, dP and the softmax.  Needs S % 128 == 0; without a workspace (or for other S) the recomputing kernels run.
-extern int g_opt_attn_pds_pol;
-extern "C" int64_t dmi_attention_bwd_workspace_bytes(int B, int H, int S) {
-  if (B <= 0 || H <= 0 || S <= 0 || S % 128 != 0) return 0;
-  return (int64_t)2 * B * H * S * S * 2;
-}
-extern "C" int dmi_attention_bwd_ws(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta,
-                                    uint16_t* dqkv, void* workspace, int B, int H, int S, void* stream) {
+// A two-pass form -- the dQ pass also writes P and dS (bf16, causal half of [2][B*H][S][S]) and the dK / dV pass streams them: two
+// products per tile instead of four and a softmax -- was built, passed the same parity tests and measured SLOWER: 360 us against
+// 268 us per layer at (32, 4, 1280), step 15.42 -> 15.78 ms (profiles/r04ah_kbench_attn.log, r04ah_ab_two_pass.log; with the P / dS
+// pieces stored as the accumulators hold them, 8 bytes to 32 rows per instruction, 405 us, and 905 / 1820 us with write-through
+// stores: r04ag_*).  The pair moves 0.84 GB per layer through HBM; recomputing S and dP on the matrix cores costs less than that
+// traffic.  The code is on the git branch `r04-attn-two-pass`.
+extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta,
+                                 uint16_t* dqkv, int B, int H, int S, void* stream) {
   DMI_REQUIRE(qkv && o && d_o && lse && delta && dqkv, "attention_bwd: null pointer");
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_bwd: S must be a multiple of 8 (S=%d)", S);
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_bwd: sequence too long for 32-bit buffer offsets");
   hipStream_t st = (hipStream_t)stream;
   float* stats = delta + (int64_t)B * H * S;  // delta scratch is [3][B,H,S]: delta | (lse, delta) pairs
-  const bool two_pass = workspace != nullptr && S % 128 == 0 && (int64_t)S * S * 2 < 0x7fffffff;
   static bool attr_done = false;
   const int shm = 32768 + DKV_NSTAGE * DKV_STAGE;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE + 4 * PDS_WAVE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE + 4 * PDS_WAVE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE + 4 * PDS_WAVE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DKV2_NSTAGE * DKV2_STAGE);
     attr_done = true;
   }
   const int items = ((S + 127) / 128) * B * H;
   {
     const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    bf16_t* ws = (bf16_t*)workspace;
-    const dim3 g(grid), t(256);
-    if (!two_pass) attn_bwd_dq_kernel<false, 0><<<g, t, 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, nullptr, B, H, S, perxcd);
-    else if (g_opt_attn_pds_pol == 2) attn_bwd_dq_kernel<true, 2><<<g, t, 2 * QK_STAGE + 4 * PDS_WAVE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, ws, B, H, S, perxcd);
-    else if (g_opt_attn_pds_pol == 1) attn_bwd_dq_kernel<true, 1><<<g, t, 2 * QK_STAGE + 4 * PDS_WAVE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, ws, B, H, S, perxcd);
-    else attn_bwd_dq_kernel<true, 0><<<g, t, 2 * QK_STAGE + 4 * PDS_WAVE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, ws, B, H, S, perxcd);
+    attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd);
   }
   DMI_CHECK_LAUNCH("attention_bwd_dq");
   {
     const int grid = items < attn_num_cus() ? items : attn_num_cus();   // one persistent block per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    if (two_pass)
-      attn_bwd_dkv2_kernel<<<dim3(grid), dim3(256), DKV2_NSTAGE * DKV2_STAGE, st>>>(qkv, d_o, (const bf16_t*)workspace, dqkv, B, H, S, perxcd);
-    else
-      attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd);
+    attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd);
   }
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
-}
-extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* delta,
-                                 uint16_t* dqkv, int B, int H, int S, void* stream) {
-  return dmi_attention_bwd_ws(qkv, o, d_o, lse, delta, dqkv, nullptr, B, H, S, stream);
 }
 
 // =====================================================================================

@@ -75,8 +75,6 @@ def _declare(L):
         "dmi_transpose_bf16": (I, [P, P, I, I, I, P]),
         "dmi_attention_fwd": (I, [P, P, P, I, I, I, P]),
         "dmi_attention_bwd": (I, [P, P, P, P, P, P, I, I, I, P]),
-        "dmi_attention_bwd_workspace_bytes": (L64, [I, I, I]),
-        "dmi_attention_bwd_ws": (I, [P, P, P, P, P, P, P, I, I, I, P]),
         "dmi_attention_decode": (I, [P, P, P, I, I, I, I, P, P]),
         "dmi_label_logit": (I, [P, I, P, I, P, P, P, P, L64, I, I, P]),
         "dmi_gemm_nt_softmax_partials": (L64, [I]),
@@ -316,22 +314,9 @@ def attention_fwd(qkv, o, lse, B, H, S):
     _check(lib().dmi_attention_fwd(_p(qkv), _p(o), _p(lse), B, H, S, _stream()), "attention_fwd")
 
 
-def attention_bwd_workspace_bytes(B, H, S):
-    """bytes of the P / dS workspace of the two-pass backward; 0 = the shape has no two-pass form"""
-    return int(lib().dmi_attention_bwd_workspace_bytes(B, H, S))
-
-
-def attention_bwd(qkv, o, d_o, lse, scratch, dqkv, B, H, S, workspace=None):
-    """workspace (uint8 / any dtype, >= attention_bwd_workspace_bytes): the two-pass form; None: the recomputing kernels"""
+def attention_bwd(qkv, o, d_o, lse, scratch, dqkv, B, H, S):
     _dev(qkv, o, d_o, lse, scratch, dqkv)
-    if workspace is None:
-        _check(lib().dmi_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(scratch), _p(dqkv), B, H, S, _stream()), "attention_bwd")
-        return
-    _dev(workspace)
-    need = attention_bwd_workspace_bytes(B, H, S)
-    assert need > 0 and workspace.numel() * workspace.element_size() >= need, "attention_bwd: workspace too small for the two-pass form"
-    _check(lib().dmi_attention_bwd_ws(_p(qkv), _p(o), _p(d_o), _p(lse), _p(scratch), _p(dqkv), _p(workspace), B, H, S, _stream()),
-           "attention_bwd_ws")
+    _check(lib().dmi_attention_bwd(_p(qkv), _p(o), _p(d_o), _p(lse), _p(scratch), _p(dqkv), B, H, S, _stream()), "attention_bwd")
 
 
 def shift_labels(tokens, labels, B, S, eos):

@@ -277,14 +277,6 @@ class DalleEngine:
         self.dqkv = torch.empty(M, 3 * d, **b16)
         self.d_o = torch.empty(M, d, **b16)
         self.delta = torch.empty(3, B, H, S, **f32)   # delta | (lse, delta) pairs for the dK/dV kernel's DMA
-        # two-pass attention backward (dmi_attention_bwd_ws): the dQ pass writes P and dS, the dK / dV pass streams them.
-        # One workspace ([2][B*H][S][S] bf16, 0.84 GB at the dalle_example batch) serves every layer.  STATUS: built and
-        # compile-checked in round 4, not yet run on a GPU -- off unless hparams["attn_two_pass"] / DALLE_ATTN_TWO_PASS=1.
-        self.attn_ws = None
-        if bool(self.hp.get("attn_two_pass", os.environ.get("DALLE_ATTN_TWO_PASS", "0") != "0")):
-            nb = dh.attention_bwd_workspace_bytes(B, H, S)
-            if nb > 0:
-                self.attn_ws = torch.empty(nb, dtype=torch.uint8, device=self.dev)
         wsz = max(dh.gemm_tn_workspace_bytes(M, d, Vp), dh.gemm_tn_workspace_bytes(M, 4 * d, d),
                   dh.gemm_tn_workspace_bytes(M, d, 4 * d), dh.gemm_tn_workspace_bytes(M, d, 3 * d),
                   dh.gemm_tn_workspace_bytes(M, d, d), dh.layernorm_bwd_workspace_bytes(M, d),
@@ -647,7 +639,7 @@ class DalleEngine:
             self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
                         dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
-            dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S, workspace=self.attn_ws)
+            dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
             self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
             dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,

@@ -124,13 +124,6 @@ int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, int B, int H
  * dqkv [B*S, 3*H*128] bf16 in the qkv layout (what the QKV dgrad/wgrad GEMMs consume). */
 int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* scratch,
                       uint16_t* dqkv, int B, int H, int S, void* stream);
-/* The same backward with a caller-owned workspace (models.py:292-299): the dQ pass also writes the softmax probabilities P and
- * dS = P (dP - delta) (bf16, [2][B*H][S][S], causal half only) and the dK / dV pass streams them -- two products per tile instead
- * of four and a softmax.  dmi_attention_bwd_workspace_bytes returns 0 when the shape has no two-pass form (S % 128 != 0);
- * workspace == NULL (or such a shape) runs the recomputing kernels of dmi_attention_bwd. */
-int64_t dmi_attention_bwd_workspace_bytes(int B, int H, int S);
-int dmi_attention_bwd_ws(const uint16_t* qkv, const uint16_t* o, const uint16_t* d_o, const float* lse, float* scratch,
-                         uint16_t* dqkv, void* workspace, int B, int H, int S, void* stream);
 
 /* Incremental decode (the reference's unfinished is_incremental_inference path, src/dalle_mtf/models.py:246-254,281-285):
  * one query position `pos` against the key/value cache.  qkv = the forward pass's projection buffer [B*S, 3*H*128] used as the

@@ -102,14 +102,6 @@ def bench_attention(B, H, S):
     print(f"attention_fwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {fl/t/1e12:7.1f} TF/s dense-equivalent ({fl/2/t/1e12:.1f} executed)", flush=True)
     t = timeit(lambda: dh.attention_bwd(qkv, o, d_o, lse, delta, dqkv, B, H, S))
     print(f"attention_bwd B={B} H={H} S={S}: {t*1e6:9.1f} us  {2.5*fl/t/1e12:7.1f} TF/s dense-equivalent ({2.5*fl/2/t/1e12:.1f} executed)", flush=True)
-    nb = dh.attention_bwd_workspace_bytes(B, H, S)
-    if nb > 0 and os.environ.get("KBENCH_ATTN_TWO_PASS", "1") != "0":   # the two-pass form (P / dS written by the dQ pass), per store policy
-        w2 = torch.empty(nb, dtype=torch.uint8, device=DEV)
-        for pol in (1, 2, 0):
-            dh.set_option("attn_pds_pol", pol)
-            t = timeit(lambda: dh.attention_bwd(qkv, o, d_o, lse, delta, dqkv, B, H, S, workspace=w2))
-            print(f"attention_bwd two-pass pol={pol} B={B} H={H} S={S}: {t*1e6:9.1f} us", flush=True)
-        dh.set_option("attn_pds_pol", 1)
 
 
 def bench_head(M, K, V):
