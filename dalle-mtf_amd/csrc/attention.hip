@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   // transposed-fragment offsets of d-tile 0; d-tile dt is the same offset with bits 6..7 XORed by dt (the chunk index dt * 4 + c,
   // c < 4, enters through an XOR swizzle).  Only these two stay in registers: the eight per-d-tile offsets did not fit next to
   // the accumulators and were spilled (19 VGPRs, reloaded inside the loop; a scratch reload waits with vmcnt(0), i.e. for every LDS-DMA in flight).
-  // 256 VGPRs + 80 B of scratch -> 213 VGPRs, no scratch; the kernel time did not change (profiles/r04ag_kbench_attn.log).
+  // 256 VGPRs + 80 B of scratch -> 213 VGPRs, no scratch; the same time in isolation (profiles/r04ag_kbench_attn.log), 128 -> 113 us per layer inside the step (profiles/r04_step_breakdown.txt).
   unsigned oft0[2];
 #pragma unroll
   for (int w2 = 0; w2 < 2; ++w2) {
