@@ -37,10 +37,11 @@ static int g_opt_nt8_min_k = 2048;   // auto mode of the 256x256 NT tile: minimu
                                      // run 354 -> 339 ms/step (profiles/r03_ab_nt8_min_k.log); K = 1024 measured equal, K = 512 slower
 static int g_opt_skinny = 1;     // M <= 32 products (the decode step) on the weight-streaming kernel: 0 never, 1 auto
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
-static int g_opt_cstream = 1;    // bf16 outputs stored write-through + non-temporal (sc1 nt): 0 never, 1 auto (outputs >= cstream_min_mb MiB: they cannot
-                                 // be re-read from a cache anyway, and as plain stores they evict the operands the concurrent tiles share), 2 always sc1,
-                                 // 3 always sc1 nt, 4 auto with sc1 only (A/B)
+static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1; + non-temporal from cstream_nt_min_mb MiB): 0 never, 1 auto (outputs >=
+                                 // cstream_min_mb MiB: they cannot be re-read from L2 anyway, and as plain stores they evict the operands the concurrent
+                                 // tiles share), 2 always sc1, 3 always sc1 nt, 4 auto with sc1 only (A/B)
 static int g_opt_cstream_min_mb = 256;
+static int g_opt_cstream_nt_min_mb = 1024;
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
 static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
                                  // tiles per CU), 2 whenever the shape allows it (tests, tools/kbench.py)
@@ -58,6 +59,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "ntr")) return g_opt_ntr;
   if (!strcmp(name, "cstream")) return g_opt_cstream;
   if (!strcmp(name, "cstream_min_mb")) return g_opt_cstream_min_mb;
+  if (!strcmp(name, "cstream_nt_min_mb")) return g_opt_cstream_nt_min_mb;
   if (!strcmp(name, "nt8p_max_k")) return g_opt_nt8p_max_k;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
@@ -76,6 +78,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "ntr")) { g_opt_ntr = value; return 0; }
   if (!strcmp(name, "cstream")) { g_opt_cstream = value; return 0; }
   if (!strcmp(name, "cstream_min_mb")) { g_opt_cstream_min_mb = value; return 0; }
+  if (!strcmp(name, "cstream_nt_min_mb")) { g_opt_cstream_nt_min_mb = value; return 0; }
   if (!strcmp(name, "nt8p_max_k")) { g_opt_nt8p_max_k = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
@@ -1483,9 +1486,11 @@ static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t
   a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
   const int64_t cbytes = ((int64_t)(M - 1) * ldc + N) * 2;     // bf16 outputs (the fp32 forms do not use the policy)
-  // 1 (default): auto by size, sc1 nt; 2: always sc1; 3: always sc1 nt; 4: auto by size, sc1 only (A/B)
-  const bool big = cbytes >= ((int64_t)g_opt_cstream_min_mb << 20);
-  const int pol = (g_opt_cstream == 1 && big) ? 2 : (g_opt_cstream == 2) ? 1 : (g_opt_cstream == 3) ? 2 : (g_opt_cstream == 4 && big) ? 1 : 0;
+  // 1 (default): auto by size -- sc1 from cstream_min_mb, sc1 nt from cstream_nt_min_mb (a stream far larger than the 256-MB
+  // Infinity Cache: the 4-GB softmax numerators; outputs of a few hundred MB that the next kernel re-reads were measured with
+  // sc1 only and keep it); 2: always sc1; 3: always sc1 nt; 4: auto by size, sc1 only (A/B)
+  const bool big = cbytes >= ((int64_t)g_opt_cstream_min_mb << 20), huge = cbytes >= ((int64_t)g_opt_cstream_nt_min_mb << 20);
+  const int pol = (g_opt_cstream == 1 && big) ? (huge ? 2 : 1) : (g_opt_cstream == 2) ? 1 : (g_opt_cstream == 3) ? 2 : (g_opt_cstream == 4 && big) ? 1 : 0;
   a.cpol = cbytes < (int64_t)0xffffffff ? pol : 0;
 }
 
