@@ -1,0 +1,311 @@
+"""tfshim -- the handful of `tensorflow.compat.v1` names the reference's model / optimizer files touch, over PyTorch-CPU.
+
+TEST INFRASTRUCTURE ONLY (see oracle/refshim/__init__.py).  TensorFlow 2.4.0 (requirements.txt:1) is not installable here; this
+module restates the published behaviour of exactly the calls the reference makes on its train path:
+
+  tf.variable_scope / tf.get_variable_scope / tf.name_scope        variable names = "/".join(scopes) + "/" + name
+  tf.random_normal_initializer / constant_initializer / zeros_initializer   recorded, not sampled (weights are injected)
+  tf.float32 / bfloat16 / int32 / int64 / bool                      dtype objects with is_integer / is_floating
+  tf.constant, tf.cast, tf.pad                                       eager, on torch tensors
+  tf.train.get_or_create_global_step, cosine_decay, polynomial_decay
+  tf.logging.info / warning                                          no-ops
+  tf.layers.conv2d / conv2d_transpose, tf.get_variable, tf.matmul, tf.nn.relu / softmax, tf.random_uniform (injected),
+  tf.argmax / one_hot / stop_gradient / reduce_mean / square / space_to_depth / depth_to_space    the discrete VAE's calls (A.8)
+
+"tf tensors" are plain torch tensors (0-dim for the scalars of src/optimizers.py:19-76)."""
+import contextlib
+import math
+import types
+
+import torch
+
+
+class DType:
+    def __init__(self, name, torch_dtype, is_integer=False, is_floating=False, is_bool=False):
+        self.name, self.torch, self.is_integer, self.is_floating, self.is_bool = name, torch_dtype, is_integer, is_floating, is_bool
+
+    def __repr__(self):
+        return f"tf.{self.name}"
+
+
+float32 = DType("float32", torch.float32, is_floating=True)
+float64 = DType("float64", torch.float64, is_floating=True)
+bfloat16 = DType("bfloat16", torch.bfloat16, is_floating=True)
+float16 = DType("float16", torch.float16, is_floating=True)
+int32 = DType("int32", torch.int32, is_integer=True)
+int64 = DType("int64", torch.int64, is_integer=True)
+bool = DType("bool", torch.bool, is_bool=True)     # noqa: A001  (the reference spells it tf.bool)
+
+AUTO_REUSE = object()
+
+# ---- variable scopes ---------------------------------------------------------------------------------------------------
+_scopes = []
+
+
+class _Scope:
+    @property
+    def name(self):
+        return "/".join(_scopes)
+
+
+def get_variable_scope():
+    return _Scope()
+
+
+_default_name_count = {}
+
+
+@contextlib.contextmanager
+def variable_scope(name_or_scope=None, default_name=None, reuse=None, **_kw):
+    """tf.variable_scope(name): pushes `name` (which may itself contain '/'); name None -> default_name, made unique per
+    enclosing scope the way TF does ("dense", "dense_1", ...)."""
+    name = name_or_scope
+    if name is None:
+        key = ("/".join(_scopes), default_name)
+        n = _default_name_count.get(key, 0)
+        _default_name_count[key] = n + 1
+        name = default_name if n == 0 else f"{default_name}_{n}"
+    _scopes.append(str(name))
+    try:
+        yield _Scope()
+    finally:
+        _scopes.pop()
+
+
+@contextlib.contextmanager
+def name_scope(name=None, default_name=None, values=None):
+    yield
+
+
+def reset():
+    del _scopes[:]
+    _default_name_count.clear()
+    _state["global_step"] = torch.zeros((), dtype=torch.int64)
+    _variables.clear()
+
+
+# ---- initialisers (recorded so that the harness can check them against the oracle's parameter table) -----------------------
+class _Init:
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.__dict__.update(kw)
+
+    def __repr__(self):
+        return f"{self.kind}({ {k: v for k, v in self.__dict__.items() if k != 'kind'} })"
+
+
+def random_normal_initializer(mean=0.0, stddev=1.0, seed=None, dtype=None):
+    return _Init("normal", mean=mean, stddev=stddev)
+
+
+def constant_initializer(value=0, dtype=None):
+    return _Init("constant", value=value)
+
+
+def zeros_initializer(dtype=None):
+    return _Init("constant", value=0)
+
+
+def ones_initializer(dtype=None):
+    return _Init("constant", value=1)
+
+
+# ---- eager ops ---------------------------------------------------------------------------------------------------------
+def constant(value, dtype=None, shape=None, name=None):
+    t = torch.as_tensor(value, dtype=dtype.torch if dtype is not None else None)
+    if shape is not None:
+        t = t.expand(tuple(shape)).clone() if t.dim() == 0 else t.reshape(tuple(shape))
+    return t
+
+
+def cast(x, dtype, name=None):
+    return torch.as_tensor(x).to(dtype.torch)
+
+
+def pad(tensor, paddings, mode="CONSTANT", name=None, constant_values=0):
+    """tf.pad: paddings[i] = [before, after] for axis i."""
+    flat = []
+    for before, after in reversed(list(paddings)):
+        flat += [int(before), int(after)]
+    return torch.nn.functional.pad(tensor, flat, mode="constant", value=constant_values)
+
+
+_state = {"global_step": torch.zeros((), dtype=torch.int64)}
+
+
+def set_global_step(step):
+    _state["global_step"] = torch.as_tensor(int(step), dtype=torch.int64)
+
+
+def _get_or_create_global_step():
+    return _state["global_step"]
+
+
+def _cosine_decay(learning_rate, global_step, decay_steps, alpha=0.0, name=None):
+    """tf.train.cosine_decay (Appendix A.8): lr * ((1 - alpha) * 0.5 * (1 + cos(pi * min(step, T) / T)) + alpha), in lr's dtype."""
+    lr = torch.as_tensor(learning_rate)
+    step = torch.minimum(torch.as_tensor(global_step).to(lr.dtype), torch.as_tensor(float(decay_steps), dtype=lr.dtype))
+    completed = step / torch.as_tensor(float(decay_steps), dtype=lr.dtype)
+    cosine_decayed = 0.5 * (1.0 + torch.cos(torch.as_tensor(math.pi, dtype=lr.dtype) * completed))
+    return lr * ((1 - alpha) * cosine_decayed + alpha)
+
+
+def _polynomial_decay(learning_rate, global_step, decay_steps, end_learning_rate=0.0001, power=1.0, cycle=False, name=None):
+    """tf.train.polynomial_decay, cycle=False: (lr - end) * (1 - min(step, T) / T) ** power + end."""
+    assert not cycle
+    lr = torch.as_tensor(learning_rate)
+    step = torch.minimum(torch.as_tensor(global_step).to(lr.dtype), torch.as_tensor(float(decay_steps), dtype=lr.dtype))
+    p = step / torch.as_tensor(float(decay_steps), dtype=lr.dtype)
+    return (lr - end_learning_rate) * torch.pow(1 - p, power) + end_learning_rate
+
+
+train = types.SimpleNamespace(get_or_create_global_step=_get_or_create_global_step, cosine_decay=_cosine_decay,
+                              polynomial_decay=_polynomial_decay)
+logging = types.SimpleNamespace(info=lambda *a, **k: None, warning=lambda *a, **k: None, warn=lambda *a, **k: None)
+
+
+# ---- the plain-TF calls of the discrete VAE (src/vae_tf/models.py, layers.py; semantics: SURVEY.md Appendix A.8) --------------
+# tf tensors are torch tensors in the reference's NHWC layout; dtypes below may be this module's DType objects or torch dtypes.
+_variables = {}        # full name -> leaf torch tensor (requires_grad), in creation order
+_injected = {}
+_uniforms = []         # queue of arrays tf.random_uniform hands out (TF's own streams cannot be reproduced)
+
+
+def inject_variables(values, uniforms=()):
+    _variables.clear()
+    _injected.clear()
+    _injected.update(values)
+    del _uniforms[:]
+    _uniforms.extend(uniforms)
+
+
+def created_variables():
+    return dict(_variables)
+
+
+def _torch_dtype(d):
+    return d.torch if isinstance(d, DType) else d
+
+
+def cast(x, dtype, name=None):     # noqa: F811  (extends the scalar version above to torch dtypes)
+    td = _torch_dtype(dtype)
+    x = torch.as_tensor(x)
+    if td is torch.bfloat16 and x.is_floating_point():
+        return x.to(torch.bfloat16).to(torch.float32)     # bf16 values are held in float32 (see mtfshim)
+    return x.to(td)
+
+
+def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True, **_kw):
+    """tf.get_variable: full name = variable scope + "/" + name; an existing name is returned again (reuse)"""
+    scope = get_variable_scope().name
+    full = scope + "/" + name if scope else name
+    if full in _variables:
+        return _variables[full]
+    if full not in _injected:
+        raise KeyError("refshim: no value injected for tf variable %r %s" % (full, shape))
+    v = torch.as_tensor(_injected[full], dtype=torch.float32).clone()
+    if shape is not None and tuple(v.shape) != tuple(int(s) for s in shape):
+        raise ValueError("variable %s: injected shape %s, requested %s" % (full, tuple(v.shape), tuple(shape)))
+    _variables[full] = v.requires_grad_(trainable)
+    return _variables[full]
+
+
+def _same_pad(n, k, s):
+    """TF "SAME": out = ceil(n / s); total padding = max((out - 1) s + k - n, 0), the smaller half in front"""
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return total // 2, total - total // 2
+
+
+def _conv2d(inputs, filters, kernel_size, strides=(1, 1), padding="valid", name=None, use_bias=True, **_kw):
+    """tf.layers.conv2d: NHWC, kernel [kh, kw, Cin, Cout] and bias [Cout] under scope `name` (default "conv2d", made unique)"""
+    kh, kw = kernel_size
+    sh, sw = strides
+    with variable_scope(name, default_name="conv2d"):
+        w = get_variable("kernel", [kh, kw, int(inputs.shape[-1]), filters])
+        b = get_variable("bias", [filters]) if use_bias else None
+    x = inputs.permute(0, 3, 1, 2)
+    if padding.upper() == "SAME":
+        (pt, pb), (pl, pr) = _same_pad(x.shape[2], kh, sh), _same_pad(x.shape[3], kw, sw)
+        x = torch.nn.functional.pad(x, (pl, pr, pt, pb))
+    y = torch.nn.functional.conv2d(x, w.permute(3, 2, 0, 1), b, stride=(sh, sw))
+    return y.permute(0, 2, 3, 1)
+
+
+def _conv2d_transpose(inputs, filters, kernel_size, strides=(1, 1), padding="valid", name=None, use_bias=True, **_kw):
+    """tf.layers.conv2d_transpose, SAME: output = input * stride; kernel [kh, kw, Cout, Cin]; the gradient of the SAME strided
+    convolution with respect to its input (which pads (k - s) / 2 on each side for the even sizes the reference uses)"""
+    kh, kw = kernel_size
+    sh, sw = strides
+    assert padding.upper() == "SAME" and (kh - sh) % 2 == 0 and (kw - sw) % 2 == 0
+    with variable_scope(name, default_name="conv2d_transpose"):
+        w = get_variable("kernel", [kh, kw, filters, int(inputs.shape[-1])])
+        b = get_variable("bias", [filters]) if use_bias else None
+    y = torch.nn.functional.conv_transpose2d(inputs.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, stride=(sh, sw),
+                                             padding=((kh - sh) // 2, (kw - sw) // 2))
+    return y.permute(0, 2, 3, 1)
+
+
+def _unsupported(*_a, **_k):
+    raise NotImplementedError("refshim: this tf.layers call is not on the reference's train path")
+
+
+layers = types.SimpleNamespace(conv2d=_conv2d, conv2d_transpose=_conv2d_transpose, dense=_unsupported, batch_normalization=_unsupported)
+nn = types.SimpleNamespace(relu=lambda x, name=None: torch.relu(x),
+                           softmax=lambda x, axis=-1, name=None: torch.softmax(x, dim=axis))
+
+
+def matmul(a, b, transpose_a=False, transpose_b=False, name=None):
+    a = a.transpose(-1, -2) if transpose_a else a
+    b = b.transpose(-1, -2) if transpose_b else b
+    return a @ b
+
+
+def space_to_depth(x, block_size, name=None):
+    """NHWC: output channel index = (dy * block + dx) * C + c"""
+    B, H, W, C = x.shape
+    r = block_size
+    return x.reshape(B, H // r, r, W // r, r, C).permute(0, 1, 3, 2, 4, 5).reshape(B, H // r, W // r, r * r * C)
+
+
+def depth_to_space(x, block_size, name=None):
+    B, H, W, C = x.shape
+    r = block_size
+    return x.reshape(B, H, W, r, r, C // (r * r)).permute(0, 1, 3, 2, 4, 5).reshape(B, H * r, W * r, C // (r * r))
+
+
+def random_uniform(shape, minval=0, maxval=None, dtype=None, seed=None, name=None):
+    u = torch.as_tensor(_uniforms.pop(0), dtype=torch.float32)
+    assert tuple(u.shape) == tuple(int(s) for s in shape), (tuple(u.shape), tuple(shape))
+    return u
+
+
+def log(x, name=None):
+    return torch.log(x)
+
+
+def argmax(x, axis=None, name=None, output_type=None):
+    return torch.argmax(x, dim=axis)          # first maximum among ties, as tf.math.argmax
+
+
+def one_hot(indices, depth, on_value=None, off_value=None, axis=None, dtype=None, name=None):
+    v = torch.nn.functional.one_hot(indices, int(depth)).to(torch.float32)
+    return v if axis in (None, -1, v.dim() - 1) else v.movedim(-1, axis)
+
+
+def stop_gradient(x, name=None):
+    return x.detach()
+
+
+def reduce_mean(x, axis=None, name=None):
+    return x.mean() if axis is None else x.mean(dim=axis)
+
+
+def square(x, name=None):
+    return x * x
+
+
+def custom_gradient(f):
+    def wrapper(*a, **k):
+        raise NotImplementedError("refshim: tf.custom_gradient (the VAE's recompute_grad path, src/vae_tf/models.py:8-43) is not emulated")
+    return wrapper

@@ -1,9 +1,10 @@
 """CPU oracle for the discrete-VAE path.
 
-TEST INFRASTRUCTURE ONLY (see oracle/dalle_oracle.py header).  PARITY UNPINNED: restated from the
-reference's call sites (src/vae_tf/models.py, src/vae_tf/layers.py, src/model_fns_tf.py) plus the
+TEST INFRASTRUCTURE ONLY (see oracle/dalle_oracle.py header).  PARITY: CALL GRAPH PINNED, THIRD-PARTY PRIMITIVES
+UNPINNED: restated from the reference's call sites (src/vae_tf/models.py, src/vae_tf/layers.py, src/model_fns_tf.py) plus the
 published semantics of tf.layers.conv2d / conv2d_transpose / tf.train.AdamOptimizer
-(SURVEY.md Appendix A.8); TensorFlow 2.4.0 is not installable here.
+(SURVEY.md Appendix A.8); TensorFlow 2.4.0 is not installable here.  Round 4: checked against the reference's own
+src/vae_tf files executed over a TF shim (oracle/refshim, tests/test_reference_callsite.py).
 
 Tensors are NHWC at the API (as the reference, vae_tf/models.py:171 comment) and kernels are in the
 TF layouts of Appendix B ([kh,kw,Cin,Cout]; transpose conv [kh,kw,Cout,Cin]).

@@ -1,0 +1,172 @@
+"""The oracle against the REFERENCE'S OWN CODE: tests/golden/ref_callsite_dalle.npz holds what the
+reference's src/dalle_mtf/models.py + layers.py + ops.py + src/optimizers.py compute when executed, unmodified, over the
+tensorflow / mesh-tensorflow shims of oracle/refshim (tests/golden/make_ref_callsite_golden.py).  The oracle must reproduce every
+number of it from the same weights and tokens: logits, per-position loss, loss, the gradient of every variable, the learning
+rate, the clip, the Adam update -- i.e. its restatement of the reference's call graph is checked against the call graph itself.
+(The shims restate the third-party primitives, SURVEY.md Appendix A: those stay unpinned, and DESIGN.md §2 says so.)
+
+CPU only; where the reference checkout exists (the authoring container) the fixture is also regenerated and compared."""
+import importlib.util
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dalle_oracle as do
+from oracle import refshim
+from oracle import vae_oracle as vo
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIXTURE = os.path.join(HERE, "golden", "ref_callsite_dalle.npz")
+FIXTURE_VAE = os.path.join(HERE, "golden", "ref_callsite_vae.npz")
+
+_spec = importlib.util.spec_from_file_location("make_ref_callsite_golden", os.path.join(HERE, "golden", "make_ref_callsite_golden.py"))
+gen = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(gen)
+
+
+@pytest.fixture(scope="module")
+def blob():
+    z = np.load(FIXTURE)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="module")
+def vblob():
+    z = np.load(FIXTURE_VAE)
+    return {k: z[k] for k in z.files}
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-300))
+
+
+def test_fixture_cases_are_the_generator_cases(blob):
+    assert json.loads(str(blob["cases"])) == json.loads(json.dumps(gen.CASES))
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_variable_table_is_the_references(blob, name):
+    """names, creation order, shapes and initialiser constants of the variables the reference's code creates (mtf.get_variable /
+    mtf.layers.dense / attention_params_simple call sites) == oracle.param_specs"""
+    case = gen.CASES[name]
+    cfg, _, _ = gen.case_inputs(case)
+    ref = json.loads(str(blob[name + "/variables"]))
+    spec = do.param_specs(cfg)
+    assert list(ref.keys()) == list(spec.keys())
+    for n, (shape, kind, std) in spec.items():
+        rshape, rkind, rconst = ref[n]
+        assert tuple(rshape) == tuple(shape), n
+        if kind == "normal":
+            assert rkind == "normal" and rconst == pytest.approx(std, rel=1e-12), (n, rconst, std)
+        else:
+            assert rkind == "constant" and rconst == (1.0 if kind == "ones" else 0.0), n
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_oracle_reproduces_the_reference_step(blob, name):
+    """fp32: forward, gradients, schedule, clip and Adam of the oracle == the reference's, to fp32 summation-order noise"""
+    case = gen.CASES[name]
+    hp = case["hp"]
+    cfg, weights, tokens = gen.case_inputs(case)
+    g = lambda k: blob[name + "/" + k]   # noqa: E731
+    P = {n: torch.tensor(a) for n, a in weights.items()}
+    loss, loss_batch, logits = do.forward(P, tokens, cfg, return_logits=True)
+    assert _rel(logits.numpy(), g("logits")) < 5e-6
+    assert np.abs(loss_batch.numpy() - g("loss_batch")).max() < 2e-5
+    assert abs(float(loss) - float(g("loss"))) < 5e-6 * abs(float(g("loss")))
+    loss2, grads = do.loss_and_grads(weights, tokens, cfg)
+    for n, gr in grads.items():
+        assert _rel(gr, g("grad:" + n)) < 2e-5, (n, _rel(gr, g("grad:" + n)))
+    # one optimizer step at the case's global step
+    params = {n: a.copy() for n, a in weights.items()}
+    m = {n: np.zeros_like(a) for n, a in weights.items()}
+    v = {n: np.zeros_like(a) for n, a in weights.items()}
+    _, gnorm, lr = do.train_step(params, m, v, tokens, cfg, case["step"], hp)
+    assert lr == pytest.approx(float(g("lr")), rel=2e-6)
+    clipped, _ = do.clip_by_global_norm(grads, hp["gradient_clipping"])
+    np.testing.assert_allclose([np.linalg.norm(c.astype(np.float64)) for c in clipped.values()], g("clipped_norms"), rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose([np.linalg.norm(params[n].astype(np.float64)) for n in grads], g("after_norms"), rtol=1e-6)
+    for k in gen.FULL:
+        k = k.format(last=hp["n_layers"] - 1)
+        assert _rel(clipped[k], g("clipped:" + k)) < 2e-5, k
+        # the update is lr * m' / (sqrt(v') + eps) [+ decay]: compare the STEP, not the parameter it is a small part of
+        step_o, step_r = params[k] - weights[k], g("after:" + k) - weights[k]
+        assert _rel(step_o, step_r) < 2e-4, (k, _rel(step_o, step_r))
+        assert _rel(m[k], g("after:" + k + "/adam_m")) < 2e-5 and _rel(v[k], g("after:" + k + "/adam_v")) < 4e-5, k
+    if hp.get("weight_decay"):    # the decayed / not decayed split of exclude_from_weight_decay = ["norm", "bias"] was exercised
+        assert do.use_weight_decay("layer_0/attn/q", hp["weight_decay"]) and not do.use_weight_decay("layer_0/norm_1/g", hp["weight_decay"])
+
+
+def test_bf16_reference_sits_within_the_bf16_band(blob):
+    """case c: the reference with "bf_16": true over shims that round EVERY mtf op's output to bfloat16, against the oracle's bf16
+    mode (which rounds at tensor boundaries and keeps e.g. the LayerNorm arithmetic in fp32).  Two different bf16 evaluations of
+    one graph: the test bounds their distance (loss 2e-3, logits 3e-2 relative) -- informational, it pins no arithmetic."""
+    case = gen.CASES["c"]
+    cfg, weights, tokens = gen.case_inputs(case)
+    P = {n: torch.tensor(a) for n, a in weights.items()}
+    loss, _, logits = do.forward(P, tokens, cfg, bf16=True, return_logits=True)
+    assert abs(float(loss) - float(blob["c/loss"])) < 2e-3 * float(blob["c/loss"])
+    assert _rel(logits.numpy(), blob["c/logits"]) < 3e-2
+
+
+@pytest.mark.parametrize("name", ["v1", "v2"])
+def test_vae_oracle_reproduces_the_reference(vblob, name):
+    """src/vae_tf/models.py + layers.py executed over the TF shim (tf.layers.conv2d / conv2d_transpose SAME, tf.get_variable scopes,
+    the tied codebook, Gumbel noise from injected uniforms) vs oracle/vae_oracle.py: variable names / order / shapes, encoder
+    logits, reconstruction, loss and the gradient of every variable; hard (straight-through) and soft Gumbel, stack_factor 1 / 2."""
+    case = gen.VAE_CASES[name]
+    cfg, weights, img, u = gen.vae_case_inputs(case)
+    g = lambda k: vblob[name + "/" + k]   # noqa: E731
+    ref_vars = json.loads(str(g("variables")))
+    assert list(ref_vars.keys()) == list(vo.param_specs(cfg).keys())
+    for n, shape in vo.param_specs(cfg).items():
+        assert tuple(ref_vars[n]) == tuple(shape), n
+    P = {n: torch.tensor(a) for n, a in weights.items()}
+    logits = vo.forward(P, torch.tensor(img), cfg, return_logits=True)
+    assert _rel(logits.numpy(), g("logits")) < 5e-6
+    loss, out = vo.forward(P, torch.tensor(img), cfg, torch.tensor(u), return_recon_loss=True, hard_gumbel=case["hard"],
+                           temperature=case["temperature"])
+    assert _rel(out.numpy(), g("reconstruction")) < 5e-6 and abs(float(loss) - float(g("loss"))) < 5e-6 * float(g("loss"))
+    _, grads = vo.loss_and_grads(weights, img, u, cfg, hard=case["hard"], temp=case["temperature"])[:2]
+    for n, gr in grads.items():
+        assert _rel(gr, g("grad:" + n)) < 2e-5, (n, _rel(gr, g("grad:" + n)))
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+@pytest.mark.parametrize("name", ["v1", "v2"])
+def test_vae_fixture_is_what_the_reference_computes_here(vblob, name):
+    out = gen.run_vae_case(gen.VAE_CASES[name])
+    for k, a in out.items():
+        ref = vblob[name + "/" + k]
+        if a.dtype.kind in "US":
+            assert str(a) == str(ref), k
+        else:
+            np.testing.assert_allclose(a, ref, rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine (it never is on the GPU box)")
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_fixture_is_what_the_reference_computes_here(blob, name):
+    """re-executes the reference's files over the shims and compares with the committed fixture"""
+    out = gen.run_case(gen.CASES[name])
+    for k, a in out.items():
+        ref = blob[name + "/" + k]
+        if a.dtype.kind in "US":
+            assert str(a) == str(ref), k
+        else:
+            np.testing.assert_allclose(a, ref, rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_shims_leave_sys_modules_clean():
+    import sys
+    before = {k for k in sys.modules if k.split(".")[0] in ("tensorflow", "mesh_tensorflow", "_dalle_mtf_reference")}
+    with refshim.installed():
+        m = refshim.reference_module("dalle_mtf.models")
+        assert m.__file__.startswith(refshim.DEFAULT_ROOT)
+    after = {k for k in sys.modules if k.split(".")[0] in ("tensorflow", "mesh_tensorflow", "_dalle_mtf_reference")}
+    assert before == after

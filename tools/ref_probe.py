@@ -3,8 +3,8 @@
 
 The reference (EleutherAI/DALLE-mtf) is Python on tensorflow==2.4.0 + mesh_tensorflow==0.1.18 (requirements.txt:1-2).  Neither
 is installable in the authoring container or on the GPU box (no network, no Python-3.10 wheel for TF 2.4), so the oracle under
-oracle/ is "parity unpinned" and every golden vector under tests/golden/ is oracle-generated.  This script is the other half of
-that statement: on any machine where `import tensorflow, mesh_tensorflow` works AND a checkout of the reference is available
+oracle/ is unpinned at the level of the third-party primitives (round 4 pins its CALL GRAPH by executing the reference's own files
+over shims, oracle/refshim + tests/test_reference_callsite.py).  This script is the other half of that statement: on any machine where `import tensorflow, mesh_tensorflow` works AND a checkout of the reference is available
 (DALLE_REFERENCE_ROOT, default /root/reference) it
 
   dump   builds the UNMODIFIED reference model class (src/dalle_mtf/models.py:141-416, `DALLE`) on `mesh_shape data:1`,
