@@ -11,6 +11,7 @@ module restates the published behaviour of exactly the calls the reference makes
   tf.logging.info / warning                                          no-ops
   tf.layers.conv2d / conv2d_transpose, tf.get_variable, tf.matmul, tf.nn.relu / softmax, tf.random_uniform (injected),
   tf.argmax / one_hot / stop_gradient / reduce_mean / square / space_to_depth / depth_to_space    the discrete VAE's calls (A.8)
+  tf.shape / maximum / expand_dims / squeeze / gather / range / reshape, tf.image.crop_and_resize / decode_jpeg (PIL)   src/input_fns.py:4-38
 
 "tf tensors" are plain torch tensors (0-dim for the scalars of src/optimizers.py:19-76)."""
 import contextlib
@@ -309,3 +310,76 @@ def custom_gradient(f):
     def wrapper(*a, **k):
         raise NotImplementedError("refshim: tf.custom_gradient (the VAE's recompute_grad path, src/vae_tf/models.py:8-43) is not emulated")
     return wrapper
+
+
+# ---- the tf calls of the reference's input helpers (src/input_fns.py:4-38) ----------------------------------------------------
+def shape(x, name=None):
+    return torch.as_tensor(list(x.shape), dtype=torch.int32)
+
+
+def maximum(a, b, name=None):
+    return torch.maximum(torch.as_tensor(a), torch.as_tensor(b))
+
+
+def minimum(a, b, name=None):
+    return torch.minimum(torch.as_tensor(a), torch.as_tensor(b))
+
+
+def expand_dims(x, axis, name=None):
+    return torch.as_tensor(x).unsqueeze(axis)
+
+
+def squeeze(x, axis=None, name=None):
+    return x.squeeze() if axis is None else x.squeeze(axis)
+
+
+def gather(params, indices, name=None, axis=0):
+    return torch.index_select(params, axis, torch.as_tensor(indices).to(torch.int64).reshape(-1))
+
+
+def range(start, limit=None, delta=1, dtype=None, name=None):     # noqa: A001
+    return torch.arange(int(start)) if limit is None else torch.arange(int(start), int(limit), int(delta))
+
+
+def reshape(x, shape, name=None):      # noqa: F811
+    return x.reshape(tuple(int(s) for s in shape))
+
+
+def _crop_and_resize(image, boxes, box_indices, crop_size, method="bilinear", extrapolation_value=0.0, name=None):
+    """tf.image.crop_and_resize (documented behaviour): box [y1, x1, y2, x2] in normalised coordinates; output pixel (i, j) samples
+    y = y1 (H-1) + i (y2-y1)(H-1)/(ch-1) (centre of the box when ch == 1), likewise x; bilinear between the four neighbours; a
+    sample outside [0, H-1] x [0, W-1] yields extrapolation_value."""
+    image = torch.as_tensor(image).to(torch.float32)
+    N, H, W, C = image.shape
+    ch, cw = int(crop_size[0]), int(crop_size[1])
+    out = []
+    for box, bi in zip(boxes, box_indices):
+        y1, x1, y2, x2 = [torch.as_tensor(float(v), dtype=torch.float32) for v in box]
+        img = image[int(bi)]
+        f = lambda v: torch.as_tensor(float(v), dtype=torch.float32)       # noqa: E731
+        ii, jj = torch.arange(ch, dtype=torch.float32), torch.arange(cw, dtype=torch.float32)
+        ys = y1 * f(H - 1) + ii * ((y2 - y1) * f(H - 1) / f(ch - 1)) if ch > 1 else (0.5 * (y1 + y2) * f(H - 1)).reshape(1)
+        xs = x1 * f(W - 1) + jj * ((x2 - x1) * f(W - 1) / f(cw - 1)) if cw > 1 else (0.5 * (x1 + x2) * f(W - 1)).reshape(1)
+        oky, okx = (ys >= 0) & (ys <= H - 1), (xs >= 0) & (xs <= W - 1)
+        cy, cx = ys.clamp(0, H - 1), xs.clamp(0, W - 1)
+        top, bot, lef, rig = cy.floor().long(), cy.ceil().long(), cx.floor().long(), cx.ceil().long()
+        ly, lx = (cy - top.float())[:, None, None], (cx - lef.float())[None, :, None]
+        t = img[top][:, lef] + (img[top][:, rig] - img[top][:, lef]) * lx
+        b = img[bot][:, lef] + (img[bot][:, rig] - img[bot][:, lef]) * lx
+        v = t + (b - t) * ly
+        mask = (oky[:, None, None] & okx[None, :, None])
+        out.append(torch.where(mask, v, torch.as_tensor(float(extrapolation_value))))
+    return torch.stack(out)
+
+
+def _decode_jpeg(contents, channels=0, name=None):
+    import io
+    import numpy as _np
+    from PIL import Image
+    im = Image.open(io.BytesIO(contents))
+    im = im.convert({1: "L", 3: "RGB"}[channels]) if channels else im
+    a = _np.array(im)
+    return torch.as_tensor(a if a.ndim == 3 else a[:, :, None])
+
+
+image = types.SimpleNamespace(crop_and_resize=_crop_and_resize, decode_jpeg=_decode_jpeg)

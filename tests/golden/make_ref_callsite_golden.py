@@ -15,9 +15,15 @@ Cases:
       weight decay 0.01 (exclude_from_weight_decay ["norm", "bias"], optimizers.py:82-89), clip 0.5
   c   case a with "bf_16": true -- every mtf op's output rounded to bfloat16 (master weights bf16): informational, compared with
       the oracle's coarser bf16 emulation under a loose bound.
+  h   the exact `dalle_example` architecture of BASELINE.json (d 512, 6 layers, 4 heads, S = 256 + 1024, V = 50 771), B = 1, fp32,
+      step 1500 of the 3000-step warm-up: a digest (loss, per-position loss, the logits of three positions and every position's
+      arg-max / max, the norm of every gradient, the small gradients in full) in ref_callsite_dalle_headline.npz; 70 s and 14 GB
+      to generate, so only regenerated with --headline
 VAE cases (16x16 images, two stride-2 stages with residual stacks, 32 codebook tokens; Gumbel uniforms injected):
   v1  hard Gumbel (straight-through), temperature 0.7
-  v2  stack_factor 2 (space_to_depth / depth_to_space), soft Gumbel, temperature 1.0"""
+  v2  stack_factor 2 (space_to_depth / depth_to_space), soft Gumbel, temperature 1.0
+  vh  the exact `vae_example` architecture (32x32 images, convblocks [[3,64],[3,128],[3,256]], 512 tokens), B = 2, hard Gumbel:
+      encoder logits, reconstruction and loss in full, the norm of every gradient, the small gradients in full"""
 import json
 import os
 import sys
@@ -33,6 +39,33 @@ from oracle.refshim import available, harness  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "ref_callsite_dalle.npz")
 OUT_VAE = os.path.join(HERE, "ref_callsite_vae.npz")
+OUT_HEADLINE = os.path.join(HERE, "ref_callsite_dalle_headline.npz")
+HEADLINE = dict(hp=dict(n_embd=512, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256, image_seq_len=1024, n_layers=6, n_heads=4,
+                        bf_16=False, lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0),
+                batch=1, step=1500, seeds=(1234, 1, 2))
+HEADLINE_POSITIONS = (0, 255, 1279)
+
+
+def headline_digest(loss, loss_batch, logits, grads, lr=None):
+    """the compact form both sides are reduced to (the test applies it to the oracle's outputs)"""
+    out = {"loss": np.float32(loss), "loss_batch": np.asarray(loss_batch, np.float32)}
+    logits = np.asarray(logits)
+    out["logits_rows"] = logits[:, list(HEADLINE_POSITIONS), :].astype(np.float32)
+    out["logits_argmax"] = logits.argmax(-1).astype(np.int32)
+    out["logits_max"] = logits.max(-1).astype(np.float32)
+    out["grad_norms"] = np.array([np.linalg.norm(np.asarray(g, np.float64)) for g in grads.values()], np.float64)
+    for k, g in grads.items():
+        if g.size <= 2048:
+            out["grad:" + k] = np.asarray(g, np.float32)
+    if lr is not None:
+        out["lr"] = np.float32(lr)
+    return out
+
+
+def run_headline():
+    cfg, weights, tokens = case_inputs(HEADLINE)
+    r = harness.run_dalle_step(HEADLINE["hp"], weights, tokens, global_step=HEADLINE["step"])
+    return headline_digest(r["loss"], r["loss_batch"], r["logits"], r["grads"], r["lr"])
 
 CASES = {
     "a": dict(hp=dict(n_embd=32, text_vocab_size=40, image_vocab_size=16, text_seq_len=6, image_seq_len=10, n_layers=2, n_heads=2,
@@ -93,6 +126,10 @@ VAE_CASES = {
 }
 
 
+VAE_HEADLINE = dict(hp=dict(num_tokens=512, n_embd=512, hidden_dim=64, convblocks=[[3, 64], [3, 128], [3, 256]], stack_factor=1), size=32,
+                    batch=2, hard=True, temperature=1.0, seeds=(4321, 0, 7))
+
+
 def vae_case_inputs(case):
     hp = case["hp"]
     cfg = vo.VaeConfig(hp["num_tokens"], case["size"], hp["convblocks"], stack_factor=hp["stack_factor"])
@@ -113,6 +150,22 @@ def run_vae_case(case):
     return out
 
 
+def vae_digest(loss, reconstruction, logits, grads):
+    out = {"loss": np.float32(loss), "reconstruction": np.asarray(reconstruction, np.float32), "logits": np.asarray(logits, np.float32)}
+    out["grad_norms"] = np.array([np.linalg.norm(np.asarray(g, np.float64)) for g in grads.values()], np.float64)
+    for k, g in grads.items():
+        if g.size <= 4096:
+            out["grad:" + k] = np.asarray(g, np.float32)
+    return out
+
+
+def run_vae_headline():
+    case = VAE_HEADLINE
+    cfg, weights, img, u = vae_case_inputs(case)
+    r = harness.run_vae_step(case["hp"], weights, img, u, hard_gumbel=case["hard"], temperature=case["temperature"])
+    return vae_digest(r["loss"], r["reconstruction"], r["logits"], r["grads"])
+
+
 def main():
     if not available():
         raise SystemExit("the reference checkout is not here (DALLE_REFERENCE_ROOT / /root/reference): nothing to execute")
@@ -130,8 +183,16 @@ def main():
         for k, a in out.items():
             blob[name + "/" + k] = a
         print("case %s: loss %.6f  %d arrays" % (name, float(out["loss"]), len(out)))
+    out = run_vae_headline()
+    for k, a in out.items():
+        blob["vh/" + k] = a
+    print("case vh: loss %.6f  %d arrays" % (float(out["loss"]), len(out)))
     np.savez_compressed(OUT_VAE, **blob)
     print(OUT_VAE, os.path.getsize(OUT_VAE), "bytes")
+    if "--headline" in sys.argv:
+        out = run_headline()
+        np.savez_compressed(OUT_HEADLINE, case=np.array(json.dumps(HEADLINE)), **out)
+        print("headline: loss %.6f  lr %.6e" % (float(out["loss"]), float(out["lr"])), OUT_HEADLINE, os.path.getsize(OUT_HEADLINE), "bytes")
 
 
 if __name__ == "__main__":

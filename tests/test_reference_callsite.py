@@ -136,6 +136,31 @@ def test_vae_oracle_reproduces_the_reference(vblob, name):
         assert _rel(gr, g("grad:" + n)) < 2e-5, (n, _rel(gr, g("grad:" + n)))
 
 
+def test_vae_oracle_reproduces_the_reference_at_the_vae_example_architecture(vblob):
+    """configs/vae_example.json's network (three stride-2 stages of 64 / 128 / 256 channels with two residual layers each, 512 tokens,
+    32x32 images), B = 2: digest of the reference's run vs the same digest of the oracle's"""
+    case = gen.VAE_HEADLINE
+    cfg, weights, img, u = gen.vae_case_inputs(case)
+    P = {n: torch.tensor(a, requires_grad=True) for n, a in weights.items()}
+    logits = vo.forward(P, torch.tensor(img), cfg, return_logits=True)
+    loss, out = vo.forward(P, torch.tensor(img), cfg, torch.tensor(u), return_recon_loss=True, hard_gumbel=True, temperature=1.0)
+    loss.backward()
+    d = gen.vae_digest(loss.detach().numpy(), out.detach().numpy(), logits.detach().numpy(), {n: p.grad.numpy() for n, p in P.items()})
+    g = lambda k: vblob["vh/" + k]   # noqa: E731
+    assert _rel(d["logits"], g("logits")) < 5e-6 and _rel(d["reconstruction"], g("reconstruction")) < 5e-6
+    assert abs(float(d["loss"]) - float(g("loss"))) < 5e-6 * float(g("loss"))
+    np.testing.assert_allclose(d["grad_norms"], g("grad_norms"), rtol=2e-5)
+    for k in d:
+        if k.startswith("grad:"):
+            assert _rel(d[k], g(k)) < 5e-5, k
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_vae_headline_fixture_is_what_the_reference_computes_here(vblob):
+    for k, a in gen.run_vae_headline().items():
+        np.testing.assert_allclose(a, vblob["vh/" + k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
 @pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
 @pytest.mark.parametrize("name", ["v1", "v2"])
 def test_vae_fixture_is_what_the_reference_computes_here(vblob, name):
@@ -170,3 +195,89 @@ def test_shims_leave_sys_modules_clean():
         assert m.__file__.startswith(refshim.DEFAULT_ROOT)
     after = {k for k in sys.modules if k.split(".")[0] in ("tensorflow", "mesh_tensorflow", "_dalle_mtf_reference")}
     assert before == after
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_input_helpers_are_the_references():
+    """src/input_fns.py:4-38 executed over the TF shim against the product's numpy restatement (dalle-mtf_amd/src/input_fns.py):
+    crop_center_and_resize -- including the reference's swapped w / h names and its box [(1-wn)/2, (1-hn)/2, wn, hn] --,
+    decode_img's normalisation, truncate_or_pad_label (pad by text_seq_len, keep the first text_seq_len ids)."""
+    import io
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "dalle-mtf_amd"))
+    from src import input_fns as prod
+    rng = np.random.default_rng(0)
+    with refshim.installed():
+        ref = refshim.reference_module("input_fns")
+        for (H, W) in ((40, 40), (48, 30), (21, 64), (16, 16)):
+            img = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)
+            np.testing.assert_array_equal(ref.crop_center_and_resize(torch.as_tensor(img), 16).numpy(), prod.crop_center_and_resize(img, 16))
+        for n in (0, 3, 8, 20):
+            lab = rng.integers(0, 100, size=n)
+            params = {"text_seq_len": 8, "padding_id": 99}
+            np.testing.assert_array_equal(ref.truncate_or_pad_label(torch.as_tensor(lab), params).numpy(), prod.truncate_or_pad_label(lab, params))
+        buf = io.BytesIO()
+        Image.fromarray(rng.integers(0, 256, size=(24, 36, 3), dtype=np.uint8)).save(buf, format="JPEG", quality=90)
+        np.testing.assert_allclose(ref.decode_img(buf.getvalue(), 16, channels=3).numpy(), prod.decode_img(buf.getvalue(), 16, channels=3), atol=1e-5)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_product_api_extends_the_references_signatures():
+    """the drop-in boundary, mechanically: every parameter of the reference's DALLE / DiscreteVAE constructors and forward methods,
+    of its input functions and config loader exists in the product's counterpart at the same position with the same default
+    (the product appends device / process-group arguments)"""
+    import inspect
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "dalle-mtf_amd"))
+    import src.dalle_mtf.models as pm
+    import src.input_fns as pi
+    import src.utils.utils as pu
+    import src.vae_tf.models as pv
+    with refshim.installed():
+        rm, rv = refshim.reference_module("dalle_mtf.models"), refshim.reference_module("vae_tf.models")
+        ri, ru = refshim.reference_module("input_fns"), refshim.reference_module("utils.utils")
+        pairs = [(rm.DALLE.__init__, pm.DALLE.__init__), (rm.DALLE.forward, pm.DALLE.forward),
+                 (rv.DiscreteVAE.__init__, pv.DiscreteVAE.__init__), (rv.DiscreteVAE.forward, pv.DiscreteVAE.forward),
+                 (ri.dalle_input_fn, pi.dalle_input_fn), (ri.vae_input_fn, pi.vae_input_fn),
+                 (ri.truncate_or_pad_label, pi.truncate_or_pad_label), (ri.read_labeled_tfrecord, pi.read_labeled_tfrecord),
+                 (ri.read_tfrecord, pi.read_tfrecord), (ru.fetch_model_params, pu.fetch_model_params)]
+        for r, p in pairs:
+            rp, pp = list(inspect.signature(r).parameters.values()), list(inspect.signature(p).parameters.values())
+            assert len(pp) >= len(rp), (r.__qualname__, rp, pp)
+            for a, b in zip(rp, pp):
+                assert (a.name, a.default, a.kind) == (b.name, b.default, b.kind), (r.__qualname__, a, b)
+
+
+def test_oracle_reproduces_the_reference_at_the_headline_shape():
+    """the exact `dalle_example` architecture of BASELINE.json (d = 512, 6 layers, 4 heads, S = 256 + 1024, V = 50 771), B = 1, fp32:
+    tests/golden/ref_callsite_dalle_headline.npz is a digest of what the reference's files compute over the shims (generated once:
+    70 s, 14 GB); the oracle's forward / backward reduced to the same digest must agree -- the shape the GPU parity tests
+    (tests/test_headline_parity_gpu.py) compare the HIP engine with this oracle at."""
+    z = np.load(os.path.join(HERE, "golden", "ref_callsite_dalle_headline.npz"))
+    assert json.loads(str(z["case"])) == json.loads(json.dumps(gen.HEADLINE))
+    cfg, weights, tokens = gen.case_inputs(gen.HEADLINE)
+    P = {n: torch.tensor(a, requires_grad=True) for n, a in weights.items()}
+    loss, loss_batch, logits = do.forward(P, tokens, cfg, return_logits=True)
+    loss.backward()
+    grads = {n: p.grad.numpy() for n, p in P.items()}
+    d = gen.headline_digest(loss.detach().numpy(), loss_batch.detach().numpy(), logits.detach().numpy(), grads)
+    assert abs(float(d["loss"]) - float(z["loss"])) < 5e-6 * float(z["loss"])
+    assert np.abs(d["loss_batch"] - z["loss_batch"]).max() < 5e-5
+    assert _rel(d["logits_rows"], z["logits_rows"]) < 5e-6 and _rel(d["logits_max"], z["logits_max"]) < 5e-6
+    assert (d["logits_argmax"] != z["logits_argmax"]).mean() < 0.002      # ties within fp32 noise only
+    np.testing.assert_allclose(d["grad_norms"], z["grad_norms"], rtol=2e-5)
+    for k in z.files:
+        if k.startswith("grad:"):
+            assert _rel(d[k], z[k]) < 5e-5, (k, _rel(d[k], z[k]))
+    lr = do.learning_rate(gen.HEADLINE["step"], 1e-3, 100000, 3000)
+    assert lr == pytest.approx(float(z["lr"]), rel=2e-6)
+
+
+@pytest.mark.skipif(not (refshim.available() and os.environ.get("DALLE_REFSHIM_HEADLINE", "0") != "0"),
+                    reason="re-executing the reference at the headline shape takes 70 s and 14 GB: DALLE_REFSHIM_HEADLINE=1")
+def test_headline_fixture_is_what_the_reference_computes_here():
+    z = np.load(os.path.join(HERE, "golden", "ref_callsite_dalle_headline.npz"))
+    out = gen.run_headline()
+    for k, a in out.items():
+        np.testing.assert_allclose(a, z[k], rtol=1e-5, atol=1e-6, err_msg=k)
