@@ -30,7 +30,8 @@ from . import mtfshim, tfshim
 
 DEFAULT_ROOT = os.environ.get("DALLE_REFERENCE_ROOT", "/root/reference")
 _ALIAS = "_dalle_mtf_reference"          # the reference's `src` directory, imported as a package under this name
-_SHIMMED = ("tensorflow", "tensorflow.compat", "tensorflow.compat.v1", "tensorflow.compat.v2", "mesh_tensorflow",
+_SHIMMED = ("tensorflow", "tensorflow.compat", "tensorflow.compat.v1", "tensorflow.compat.v2", "tensorflow.python",
+            "tensorflow.python.tpu", "tensorflow.python.tpu.tpu_estimator", "mesh_tensorflow",
             "mesh_tensorflow.ops", "mesh_tensorflow.transformer", "mesh_tensorflow.transformer.attention",
             "mesh_tensorflow.layers", "mesh_tensorflow.optimize", "mesh_tensorflow.utils")
 
@@ -60,6 +61,7 @@ def installed(root=DEFAULT_ROOT):
     tr = types.ModuleType("mesh_tensorflow.transformer")
     att = _module("mesh_tensorflow.transformer.attention", mtfshim.transformer.attention)
     tr.attention = att
+    tr.utils = mtfshim.transformer.utils
     mtf.transformer = tr
     mtf.ops = ops
     mods = {"tensorflow": tf_root, "tensorflow.compat": compat, "tensorflow.compat.v1": tf1, "tensorflow.compat.v2": tf1,
@@ -67,6 +69,11 @@ def installed(root=DEFAULT_ROOT):
             "mesh_tensorflow.transformer.attention": att, "mesh_tensorflow.layers": _module("mesh_tensorflow.layers", mtfshim.layers),
             "mesh_tensorflow.optimize": _module("mesh_tensorflow.optimize", mtfshim.optimize),
             "mesh_tensorflow.utils": _module("mesh_tensorflow.utils", mtfshim.utils)}
+    tpu_est = types.ModuleType("tensorflow.python.tpu.tpu_estimator")
+    tpu_est.TPUEstimatorSpec = tfshim.TPUEstimatorSpec
+    py, py_tpu = types.ModuleType("tensorflow.python"), types.ModuleType("tensorflow.python.tpu")
+    py.tpu, py_tpu.tpu_estimator, tf_root.python = py_tpu, tpu_est, py
+    mods.update({"tensorflow.python": py, "tensorflow.python.tpu": py_tpu, "tensorflow.python.tpu.tpu_estimator": tpu_est})
     pkg = types.ModuleType(_ALIAS)
     pkg.__path__ = [os.path.join(root, "src")]
     mods[_ALIAS] = pkg

@@ -115,3 +115,65 @@ def run_vae_step(hparams, weights, images, uniforms, hard_gumbel=True, temperatu
         out["grads"] = OrderedDict((k[len("vae/"):], (g if g is not None else torch.zeros_like(v)).numpy().copy())
                                    for (k, v), g in zip(variables.items(), gs))
         return out
+
+
+def run_vae_model_fn(params, weights, images, uniforms, global_step=0, adam_state=None, mode="train", root=None):
+    """Calls the reference's `vae_model_fn(features, labels, mode, params)` (src/model_fns_tf.py:9-114) itself: it builds the VAE
+    from the config keys, picks the Gumbel flavour for the mode, anneals the temperature from the global step, runs the forward
+    under scope "vae" and hands the loss to tf.train.AdamOptimizer / CrossShardOptimizer.  Returns the loss, the temperature-
+    dependent reconstruction digest and what the optimizer's minimize() produced (gradients, Adam slots, updated variables)."""
+    kw = {} if root is None else {"root": root}
+    with installed(**kw):
+        fns = reference_module("model_fns_tf")
+        p = defaultdict(lambda: None, dict(params))
+        tfshim.inject_variables({"vae/" + k: np.asarray(v) for k, v in weights.items()}, uniforms=[np.asarray(uniforms)])
+        tfshim.set_global_step(global_step)
+        if adam_state:
+            tfshim.adam_state.update(adam_state)
+        feats = torch.as_tensor(np.asarray(images, dtype=np.float32))
+        spec = fns.vae_model_fn(feats, feats, {"train": tfshim.estimator.ModeKeys.TRAIN, "eval": tfshim.estimator.ModeKeys.EVAL}[mode], p)
+        out = OrderedDict(loss=spec.loss.detach().numpy().copy())
+        reconstruction = spec.eval_metrics[1][3]
+        out["reconstruction"] = reconstruction.detach().numpy().copy()
+        strip = lambda d: OrderedDict((k[len("vae/"):], v.detach().numpy().copy()) for k, v in d.items())   # noqa: E731
+        out["grads"], out["updated"] = strip(spec.train_op["grads"]), strip(spec.train_op["updated"])
+        out["m"], out["v"], out["t"] = strip(spec.train_op["m"]), strip(spec.train_op["v"]), spec.train_op["t"]
+        return out
+
+
+def run_dalle_model_fn(params, vae_weights, dalle_weights, images, text, global_step=0, mode="train", root=None):
+    """Calls the reference's `dalle_model_fn(features, labels, mode, params)` (src/model_fns.py:55-236) itself -- features = images,
+    labels = caption ids: it builds the VAE from params["vae_params"], tokenises the images (arg-max of the encoder logits, reshape,
+    + text_vocab_size, concat with the text: :72-77,118-119), derives image_seq_len (:68), builds the mtf graph / mesh, the DALLE
+    model, the loss, the optimizer and the update ops.  Returns the loss, the tokens it assembled, the updated variables and what
+    it asked tf.train.init_from_checkpoint to restore."""
+    kw = {} if root is None else {"root": root}
+    with installed(**kw):
+        fns = reference_module("model_fns")
+        p = defaultdict(lambda: None, dict(params))
+        tfshim.inject_variables({"vae/" + k: np.asarray(v) for k, v in vae_weights.items()})
+        mtfshim.inject_variables({k: np.asarray(v) for k, v in dalle_weights.items()})
+        tfshim.set_global_step(global_step)
+        captured = {}
+        real_import = mtfshim.import_fully_replicated
+
+        def spy_import(mesh, tf_tensor, shape, name=None):      # the tokens the model_fn assembled, as it hands them to mtf
+            captured[name] = torch.as_tensor(tf_tensor).clone()
+            return real_import(mesh, tf_tensor, shape, name=name)
+
+        import sys
+        sys.modules["mesh_tensorflow"].import_fully_replicated = spy_import
+        spec = fns.dalle_model_fn(torch.as_tensor(np.asarray(images, dtype=np.float32)), torch.as_tensor(np.asarray(text, dtype=np.int32)),
+                                  {"train": tfshim.estimator.ModeKeys.TRAIN, "eval": tfshim.estimator.ModeKeys.EVAL}[mode], p)
+        out = OrderedDict(loss=torch.as_tensor(spec.loss).detach().numpy().copy())
+        out["tokens"] = captured["text_inputs"].numpy().copy()
+        out["restore_requests"] = list(tfshim.restore_requests)
+        if spec.train_op is not None:
+            upd = OrderedDict()
+            for op in spec.train_op:
+                if hasattr(op, "variable"):
+                    upd[op.variable.name] = op.new_value.numpy().copy()
+                else:
+                    out["next_global_step"] = int(op.new_value)
+            out["updated"] = upd
+        return out

@@ -115,7 +115,16 @@ def convert_to_shape(x):
         return x
     if isinstance(x, Dimension):
         return Shape([x])
+    if isinstance(x, str):       # "data:16,model:2" (mesh shapes, src/model_fns.py:81)
+        return Shape([Dimension(p.split(":")[0].strip(), int(p.split(":")[1])) for p in x.replace(";", ",").split(",") if p.strip()])
     return Shape(list(x))
+
+
+def convert_to_layout_rules(x):
+    """ "batch_dim:data" -> [("batch_dim", "data")]  (src/model_fns.py:82)"""
+    if isinstance(x, str):
+        return [tuple(q.strip() for q in p.split(":")) for p in x.replace(";", ",").split(",") if p.strip()]
+    return list(x)
 
 
 class VariableDType:
@@ -883,3 +892,62 @@ class AdamWeightDecayOptimizer(Optimizer):
 
 optimize = types.SimpleNamespace(Optimizer=Optimizer, AdamWeightDecayOptimizer=AdamWeightDecayOptimizer)
 utils = types.SimpleNamespace(SCALAR_SUMMARIES_COLLECTION_KEY="mtf_scalar_summaries")
+
+
+# ---- control-plane names of src/model_fns.py (mesh implementation, lowering, hooks): one device, nothing to lower ------------------
+class _PlacementMeshImpl:
+    def __init__(self, shape, layout, devices):
+        self.shape, self.layout_rules, self.devices = convert_to_shape(shape), convert_to_layout_rules(layout), devices
+
+
+placement_mesh_impl = types.SimpleNamespace(PlacementMeshImpl=_PlacementMeshImpl)
+
+
+class Lowering:
+    """mtf.Lowering(graph, {mesh: mesh_impl}): here the tensors already hold their values"""
+
+    def __init__(self, graph, mesh_to_impl, autostack=True, log_file=None):
+        self.graph, self.mesh_to_impl = graph, mesh_to_impl
+
+    def export_to_tf_tensor(self, x):
+        return x.value
+
+    def lowered_operation(self, op):
+        return op
+
+
+class MtfRestoreHook:
+    def __init__(self, lowering):
+        self.lowering = lowering
+
+
+class MtfCheckpointSaverListener:
+    def __init__(self, lowering):
+        self.lowering = lowering
+
+
+import contextlib as _contextlib   # noqa: E402
+
+utils.remove_summaries = lambda: None
+utils.outside_all_rewrites = _contextlib.nullcontext
+
+
+def _serialize_num_microbatches(batch_dim, sequence_length, mesh_shape, layout_rules, tokens_per_microbatch_per_replica=None):
+    """mesh_tensorflow/transformer/utils.py serialize_num_microbatches (Appendix A.7): no token budget -> 1; otherwise the batch
+    per replica is cut so that a micro-batch holds at most that many tokens (rounded to a divisor of the per-replica batch)."""
+    if not tokens_per_microbatch_per_replica:
+        return 1
+    mesh_shape, rules = convert_to_shape(mesh_shape), convert_to_layout_rules(layout_rules)
+    replicas = 1
+    for dim_name, axis in rules:
+        if dim_name == batch_dim.name:
+            replicas = mesh_shape.get_dim_by_name(axis).size
+    batch_per_replica = batch_dim.size // replicas
+    num = (batch_per_replica * sequence_length) // tokens_per_microbatch_per_replica
+    num = max(1, min(batch_per_replica, num))
+    while batch_per_replica % num:
+        num -= 1
+    return num
+
+
+transformer.utils = types.SimpleNamespace(serialize_num_microbatches=_serialize_num_microbatches)

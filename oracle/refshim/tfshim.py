@@ -15,7 +15,7 @@ module restates the published behaviour of exactly the calls the reference makes
 
 "tf tensors" are plain torch tensors (0-dim for the scalars of src/optimizers.py:19-76)."""
 import contextlib
-import math
+import math as _pymath
 import types
 
 import torch
@@ -83,6 +83,9 @@ def reset():
     _default_name_count.clear()
     _state["global_step"] = torch.zeros((), dtype=torch.int64)
     _variables.clear()
+    _collections.clear()
+    del restore_requests[:]
+    adam_state.clear()
 
 
 # ---- initialisers (recorded so that the harness can check them against the oracle's parameter table) -----------------------
@@ -147,7 +150,7 @@ def _cosine_decay(learning_rate, global_step, decay_steps, alpha=0.0, name=None)
     lr = torch.as_tensor(learning_rate)
     step = torch.minimum(torch.as_tensor(global_step).to(lr.dtype), torch.as_tensor(float(decay_steps), dtype=lr.dtype))
     completed = step / torch.as_tensor(float(decay_steps), dtype=lr.dtype)
-    cosine_decayed = 0.5 * (1.0 + torch.cos(torch.as_tensor(math.pi, dtype=lr.dtype) * completed))
+    cosine_decayed = 0.5 * (1.0 + torch.cos(torch.as_tensor(_pymath.pi, dtype=lr.dtype) * completed))
     return lr * ((1 - alpha) * cosine_decayed + alpha)
 
 
@@ -383,3 +386,112 @@ def _decode_jpeg(contents, channels=0, name=None):
 
 
 image = types.SimpleNamespace(crop_and_resize=_crop_and_resize, decode_jpeg=_decode_jpeg)
+
+
+# ---- control-plane names the reference's model_fns touch (src/model_fns.py:55-236, src/model_fns_tf.py:9-114) ------------------
+# TPUEstimator, savers, hooks, summaries: recorded or ignored -- they carry no arithmetic.  The two pieces that do are restated:
+# tf.train.AdamOptimizer (Appendix A.8) and tf.tpu.CrossShardOptimizer (mean over shards; one shard here).
+estimator = types.SimpleNamespace(ModeKeys=types.SimpleNamespace(TRAIN="train", EVAL="eval", PREDICT="infer"))
+GraphKeys = types.SimpleNamespace(GLOBAL_VARIABLES="variables", UPDATE_OPS="update_ops", SAVERS="savers")
+_collections = {}
+restore_requests = []     # (checkpoint path, names asked for) of every tf.train.init_from_checkpoint call
+
+
+class _VarHandle:
+    def __init__(self, name, t):
+        self.name, self.tensor = name + ":0", t
+
+
+def get_collection(key, scope=None):
+    if key == GraphKeys.GLOBAL_VARIABLES:
+        return [_VarHandle(n, t) for n, t in _variables.items() if scope is None or n.startswith(scope)]
+    return list(_collections.get(key, []))
+
+
+def add_to_collection(key, value):
+    _collections.setdefault(key, []).append(value)
+
+
+def global_variables():
+    return get_collection(GraphKeys.GLOBAL_VARIABLES)
+
+
+@contextlib.contextmanager
+def control_dependencies(_ops):
+    yield
+
+
+def group(*ops, **_kw):
+    flat = []
+    for o in ops:
+        flat.extend(o if isinstance(o, (list, tuple)) else [o])
+    return flat
+
+
+class _AssignAdd:
+    def __init__(self, new_value):
+        self.new_value = new_value
+
+
+def assign_add(ref, value, **_kw):
+    return _AssignAdd(torch.as_tensor(ref) + value)
+
+
+def concat(values, axis, name=None):
+    return torch.cat([torch.as_tensor(v) for v in values], dim=axis)
+
+
+def to_int32(x, name=None):
+    return torch.as_tensor(x).to(torch.int32)
+
+
+def no_op(name=None):
+    return None
+
+
+def get_default_graph():
+    return types.SimpleNamespace(get_collection=lambda key: list(_collections.get(key, [])), get_name_scope=lambda: "")
+
+
+class AdamOptimizer:
+    """tf.train.AdamOptimizer (Appendix A.8): lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); m, v zero-initialised slots;
+    p -= lr_t m / (sqrt(v) + eps); eps 1e-8.  minimize() differentiates the loss w.r.t. every variable created so far."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, **_kw):
+        self.lr, self.b1, self.b2, self.eps = learning_rate, beta1, beta2, epsilon
+
+    def minimize(self, loss, global_step=None, var_list=None, **_kw):
+        names = list(_variables)
+        grads = torch.autograd.grad(loss, [_variables[n] for n in names], allow_unused=True, retain_graph=True)
+        t = adam_state.get("t", 0) + 1
+        lr_t = float(self.lr) * _pymath.sqrt(1.0 - self.b2 ** t) / (1.0 - self.b1 ** t)
+        out = {"t": t, "grads": {}, "updated": {}, "m": {}, "v": {}}
+        for n, g in zip(names, grads):
+            p = _variables[n].detach()
+            g = torch.zeros_like(p) if g is None else g
+            m = self.b1 * adam_state.get("m", {}).get(n, torch.zeros_like(p)) + (1 - self.b1) * g
+            v = self.b2 * adam_state.get("v", {}).get(n, torch.zeros_like(p)) + (1 - self.b2) * g * g
+            out["grads"][n], out["m"][n], out["v"][n] = g, m, v
+            out["updated"][n] = p - lr_t * m / (torch.sqrt(v) + self.eps)
+        return out
+
+
+adam_state = {}     # {"t": steps taken, "m": {...}, "v": {...}} carried in by the harness
+train.get_global_step = _get_or_create_global_step
+train.AdamOptimizer = AdamOptimizer
+train.latest_checkpoint = lambda path: None
+train.list_variables = lambda path: [(n, tuple(v.shape)) for n, v in _injected.items()]
+train.init_from_checkpoint = lambda path, assignment_map: restore_requests.append((path, sorted(assignment_map)))
+train.Saver = lambda *a, **k: types.SimpleNamespace(args=a, kwargs=k)
+train.CheckpointSaverHook = lambda *a, **k: types.SimpleNamespace(args=a, kwargs=k)
+tpu = types.SimpleNamespace(bfloat16_scope=contextlib.nullcontext, CrossShardOptimizer=lambda opt, **_k: opt)
+math = types.SimpleNamespace(argmax=argmax, reduce_mean=reduce_mean)     # tf.math
+
+
+class TPUEstimatorSpec:
+    """tensorflow.python.tpu.tpu_estimator.TPUEstimatorSpec: the record a model_fn returns"""
+
+    def __init__(self, mode=None, loss=None, train_op=None, host_call=None, eval_metrics=None, training_hooks=None,
+                 evaluation_hooks=None, **kw):
+        self.mode, self.loss, self.train_op, self.host_call, self.eval_metrics = mode, loss, train_op, host_call, eval_metrics
+        self.training_hooks, self.evaluation_hooks = training_hooks, evaluation_hooks

@@ -19,6 +19,13 @@ Cases:
       step 1500 of the 3000-step warm-up: a digest (loss, per-position loss, the logits of three positions and every position's
       arg-max / max, the norm of every gradient, the small gradients in full) in ref_callsite_dalle_headline.npz; 70 s and 14 GB
       to generate, so only regenerated with --headline
+model_fn cases (ref_callsite_model_fns.npz): the reference's `vae_model_fn` and `dalle_model_fn` THEMSELVES are called
+(src/model_fns_tf.py:9-114, src/model_fns.py:55-236; TPUEstimator / saver / hook objects are inert records):
+  fv  vae_model_fn, TRAIN, global step 30 of a 100-step temperature anneal 1.0 -> 0.5, train_gumbel_hard false: loss, every
+      gradient, the variables after tf.train.AdamOptimizer's first step
+  fd  dalle_model_fn, TRAIN, global step 40: the VAE built from params["vae_params"], images tokenised (arg-max, + text_vocab_size,
+      concat: :72-77,118-119), image_seq_len (:68), loss, the variables after the update ops, the next global step -- and the
+      (empty) variable list the reference hands to tf.train.init_from_checkpoint, because it restores BEFORE it builds the VAE
 VAE cases (16x16 images, two stride-2 stages with residual stacks, 32 codebook tokens; Gumbel uniforms injected):
   v1  hard Gumbel (straight-through), temperature 0.7
   v2  stack_factor 2 (space_to_depth / depth_to_space), soft Gumbel, temperature 1.0
@@ -40,6 +47,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "ref_callsite_dalle.npz")
 OUT_VAE = os.path.join(HERE, "ref_callsite_vae.npz")
 OUT_HEADLINE = os.path.join(HERE, "ref_callsite_dalle_headline.npz")
+OUT_FNS = os.path.join(HERE, "ref_callsite_model_fns.npz")
 HEADLINE = dict(hp=dict(n_embd=512, text_vocab_size=50258, image_vocab_size=512, text_seq_len=256, image_seq_len=1024, n_layers=6, n_heads=4,
                         bf_16=False, lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0),
                 batch=1, step=1500, seeds=(1234, 1, 2))
@@ -166,6 +174,59 @@ def run_vae_headline():
     return vae_digest(r["loss"], r["reconstruction"], r["logits"], r["grads"])
 
 
+_FN_VAE = dict(num_tokens=32, dim=64, hidden_dim=16, convblocks=[[2, 16], [3, 24]], stack_factor=1, model_path="runs/vae")
+FN_CASES = {
+    "fv": dict(params=dict(num_tokens=32, n_embd=64, hidden_dim=16, convblocks=[[2, 16], [3, 24]], stack_factor=1, lr=1e-3,
+                           dataset={"image_size": 16}, train_batch_size=2, eval_batch_size=2, temp_start=1.0, temp=0.5,
+                           temp_anneal_steps=100, train_gumbel_hard=False, eval_gumbel_hard=True, model_path="runs/vae"),
+               step=30, batch=2, seeds=(5, 3, 9)),
+    "fd": dict(params=dict(n_embd=32, text_vocab_size=40, image_vocab_size=32, text_seq_len=6, n_layers=2, n_heads=2, bf_16=False, lr=3e-4,
+                           train_steps=1000, warmup_steps=100, gradient_clipping=1.0, dataset={"image_size": 16}, train_batch_size=3,
+                           eval_batch_size=3, vae_params=_FN_VAE, vae_checkpoint_path="runs/vae/model.ckpt-10", mesh_shape="data:1",
+                           layout="batch_dim:data", use_tpu=False, gpu_ids=["device:CPU:0"], model_path="runs/dalle",
+                           steps_per_checkpoint=100),
+               step=40, batch=3, seeds=(5, 3, 7, 1)),
+}
+
+
+def fn_vae_inputs(case):
+    p = case["params"]
+    cfg = vo.VaeConfig(p["num_tokens"], p["dataset"]["image_size"], p["convblocks"], stack_factor=p["stack_factor"])
+    ws, is_, us = case["seeds"]
+    return (cfg, vo.init_params(cfg, seed=ws, bias_perturb=0.05), vo.synthetic_images(case["batch"], p["dataset"]["image_size"], seed=is_),
+            vo.synthetic_uniforms((case["batch"], cfg.grid, cfg.grid, cfg.num_tokens), seed=us))
+
+
+def fn_dalle_inputs(case):
+    p = case["params"]
+    vp = p["vae_params"]
+    vcfg = vo.VaeConfig(vp["num_tokens"], p["dataset"]["image_size"], vp["convblocks"], stack_factor=vp["stack_factor"])
+    vs, is_, ds, ts = case["seeds"]
+    cfg = do.DalleConfig(p["n_embd"], p["text_vocab_size"], p["image_vocab_size"], p["text_seq_len"], vcfg.grid ** 2, p["n_layers"], p["n_heads"])
+    return (vcfg, vo.init_params(vcfg, seed=vs, bias_perturb=0.05), cfg, do.init_params(cfg, seed=ds, perturb=0.05),
+            vo.synthetic_images(case["batch"], p["dataset"]["image_size"], seed=is_),
+            do.synthetic_captions(case["batch"], p["text_seq_len"], p["text_vocab_size"], seed=ts))
+
+
+def run_fn_cases():
+    out = {}
+    c = FN_CASES["fv"]
+    cfg, w, img, u = fn_vae_inputs(c)
+    r = harness.run_vae_model_fn(c["params"], w, img, u, global_step=c["step"])
+    out["fv/loss"], out["fv/reconstruction"], out["fv/t"] = r["loss"], r["reconstruction"], np.int32(r["t"])
+    for k in r["grads"]:
+        out["fv/grad:" + k], out["fv/after:" + k] = r["grads"][k], r["updated"][k]
+    c = FN_CASES["fd"]
+    vcfg, vw, cfg, dw, img, text = fn_dalle_inputs(c)
+    r = harness.run_dalle_model_fn(c["params"], vw, dw, img, text, global_step=c["step"])
+    out["fd/loss"], out["fd/tokens"], out["fd/next_global_step"] = r["loss"], r["tokens"], np.int32(r["next_global_step"])
+    out["fd/restore_requests"] = np.array(json.dumps(r["restore_requests"]))
+    for k, a in r["updated"].items():
+        if not k.endswith(("/adam_m", "/adam_v")):
+            out["fd/after:" + k] = a
+    return out
+
+
 def main():
     if not available():
         raise SystemExit("the reference checkout is not here (DALLE_REFERENCE_ROOT / /root/reference): nothing to execute")
@@ -189,6 +250,9 @@ def main():
     print("case vh: loss %.6f  %d arrays" % (float(out["loss"]), len(out)))
     np.savez_compressed(OUT_VAE, **blob)
     print(OUT_VAE, os.path.getsize(OUT_VAE), "bytes")
+    out = run_fn_cases()
+    np.savez_compressed(OUT_FNS, cases=np.array(json.dumps(FN_CASES)), **out)
+    print("model_fn cases: vae loss %.6f, dalle loss %.6f" % (float(out["fv/loss"]), float(out["fd/loss"])), OUT_FNS, os.path.getsize(OUT_FNS), "bytes")
     if "--headline" in sys.argv:
         out = run_headline()
         np.savez_compressed(OUT_HEADLINE, case=np.array(json.dumps(HEADLINE)), **out)

@@ -281,3 +281,62 @@ def test_headline_fixture_is_what_the_reference_computes_here():
     out = gen.run_headline()
     for k, a in out.items():
         np.testing.assert_allclose(a, z[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.fixture(scope="module")
+def fblob():
+    z = np.load(os.path.join(HERE, "golden", "ref_callsite_model_fns.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def test_oracle_reproduces_the_references_vae_model_fn(fblob):
+    """the reference's `vae_model_fn` (src/model_fns_tf.py:9-114) called itself: temperature anneal from the global step (:40-45),
+    train_gumbel_hard, scope "vae", tf.train.AdamOptimizer(lr) -- vs oracle.temperature / loss_and_grads / tf_adam_step (row v6)"""
+    assert json.loads(str(fblob["cases"])) == json.loads(json.dumps(gen.FN_CASES))
+    c = gen.FN_CASES["fv"]
+    p = c["params"]
+    cfg, w, img, u = gen.fn_vae_inputs(c)
+    temp = vo.temperature(c["step"], p)
+    assert temp == pytest.approx(1.0 - 0.3 * 0.5, rel=1e-6)
+    loss, grads = vo.loss_and_grads(w, img, u, cfg, hard=p["train_gumbel_hard"], temp=temp)[:2]
+    assert abs(float(loss) - float(fblob["fv/loss"])) < 5e-6 * float(fblob["fv/loss"])
+    m, v = {n: np.zeros_like(a) for n, a in w.items()}, {n: np.zeros_like(a) for n, a in w.items()}
+    after = {n: a.copy() for n, a in w.items()}
+    vo.tf_adam_step(after, grads, m, v, int(fblob["fv/t"]), p["lr"])
+    for n in w:
+        assert _rel(grads[n], fblob["fv/grad:" + n]) < 2e-5, n
+        assert _rel(after[n] - w[n], fblob["fv/after:" + n] - w[n]) < 2e-4, n
+
+
+def test_oracle_reproduces_the_references_dalle_model_fn(fblob):
+    """the reference's `dalle_model_fn` (src/model_fns.py:55-236) called itself with images and caption ids: the tokens it assembles
+    (VAE encoder arg-max, reshape, + text_vocab_size, concat with the text: rows a1 / a2), image_seq_len, the loss, the variables
+    after its update ops and the global-step increment -- vs the oracle's pipeline of the same steps.  Also records what the
+    reference restores: nothing -- initialize_vae_weights (:66) collects the variables under "vae" BEFORE vae.forward (:73)
+    creates them (the product restores the VAE checkpoint for real)."""
+    c = gen.FN_CASES["fd"]
+    p = c["params"]
+    vcfg, vw, cfg, dw, img, text = gen.fn_dalle_inputs(c)
+    logits = vo.forward({n: torch.tensor(a) for n, a in vw.items()}, torch.tensor(img), vcfg, return_logits=True)
+    tokens = do.assemble_tokens(text, do.image_tokens_from_logits(logits.numpy()), p["text_vocab_size"])
+    np.testing.assert_array_equal(tokens, fblob["fd/tokens"])
+    assert fblob["fd/tokens"].dtype == np.int32 and cfg.image_seq_len == vcfg.grid ** 2
+    P2 = {n: a.copy() for n, a in dw.items()}
+    m, v = {n: np.zeros_like(a) for n, a in dw.items()}, {n: np.zeros_like(a) for n, a in dw.items()}
+    loss, _, _ = do.train_step(P2, m, v, tokens, cfg, c["step"], p)
+    assert abs(loss - float(fblob["fd/loss"])) < 5e-6 * float(fblob["fd/loss"])
+    for n in dw:
+        assert _rel(P2[n] - dw[n], fblob["fd/after:" + n] - dw[n]) < 2e-4, n
+    assert int(fblob["fd/next_global_step"]) == c["step"] + 1
+    assert json.loads(str(fblob["fd/restore_requests"])) == [[p["vae_checkpoint_path"], []]]
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_model_fn_fixture_is_what_the_reference_computes_here(fblob, capsys):
+    out = gen.run_fn_cases()
+    capsys.readouterr()      # the reference prints its parameter count and dimension names
+    for k, a in out.items():
+        if a.dtype.kind in "US":
+            assert str(a) == str(fblob[k]), k
+        else:
+            np.testing.assert_allclose(a, fblob[k], rtol=1e-5, atol=1e-7, err_msg=k)
