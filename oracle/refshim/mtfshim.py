@@ -14,6 +14,7 @@ Tensors hold torch values eagerly (float32 for floating tensors -- a bfloat16 te
 int64 for integers); gradients are torch autograd's.  A subclass of `Operation` defined OUTSIDE this module (the reference's
 CustomPadOperation, ScalarSummaryOperation) is evaluated lazily through its own `lower()` with a one-device lowering stub."""
 import collections
+import contextlib
 import math
 import string
 import types
@@ -926,10 +927,8 @@ class MtfCheckpointSaverListener:
         self.lowering = lowering
 
 
-import contextlib as _contextlib   # noqa: E402
-
 utils.remove_summaries = lambda: None
-utils.outside_all_rewrites = _contextlib.nullcontext
+utils.outside_all_rewrites = contextlib.nullcontext
 
 
 def _serialize_num_microbatches(batch_dim, sequence_length, mesh_shape, layout_rules, tokens_per_microbatch_per_replica=None):
