@@ -122,10 +122,6 @@ def constant(value, dtype=None, shape=None, name=None):
     return t
 
 
-def cast(x, dtype, name=None):
-    return torch.as_tensor(x).to(dtype.torch)
-
-
 def pad(tensor, paddings, mode="CONSTANT", name=None, constant_values=0):
     """tf.pad: paddings[i] = [before, after] for axis i."""
     flat = []
@@ -191,7 +187,8 @@ def _torch_dtype(d):
     return d.torch if isinstance(d, DType) else d
 
 
-def cast(x, dtype, name=None):     # noqa: F811  (extends the scalar version above to torch dtypes)
+def cast(x, dtype, name=None):
+    """tf.cast for this module's DType objects and for torch dtypes (`out.dtype` of a shim tensor)"""
     td = _torch_dtype(dtype)
     x = torch.as_tensor(x)
     if td is torch.bfloat16 and x.is_floating_point():
