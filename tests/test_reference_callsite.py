@@ -340,3 +340,43 @@ def test_model_fn_fixture_is_what_the_reference_computes_here(fblob, capsys):
             assert str(a) == str(fblob[k]), k
         else:
             np.testing.assert_allclose(a, fblob[k], rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_the_gpu_goldens_are_what_the_reference_computes():
+    """tests/golden/dalle_small.npz and vae_small.npz were generated from the ORACLE (tests/golden/make_golden.py) and are what the
+    GPU tests compare the HIP path with (tests/test_golden.py::test_hip_matches_*_golden).  Here the reference's own files are run
+    on the same configurations, weights and inputs: the committed goldens must be what the reference computes -- which makes
+    those GPU tests comparisons against the reference's call graph."""
+    from oracle.refshim import harness
+    _s = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(_s)
+    _s.loader.exec_module(mg)
+    # DALL-E: n_embd 128, one head (head dim 128: the engine's), 2 layers, 24 + 40 positions
+    z = np.load(os.path.join(HERE, "golden", "dalle_small.npz"))
+    cfg = do.DalleConfig(**mg.DALLE_SMALL)
+    P = do.init_params(cfg, seed=77, perturb=0.05)
+    tokens = do.assemble_tokens(do.synthetic_captions(2, cfg.text_seq_len, cfg.text_vocab_size, seed=5),
+                                do.synthetic_image_tokens(2, cfg.image_seq_len, cfg.image_vocab_size, seed=6), cfg.text_vocab_size)
+    np.testing.assert_array_equal(tokens, z["tokens"])
+    hp = dict(mg.DALLE_SMALL, bf_16=False, **mg.HP)
+    r = harness.run_dalle_step(hp, P, tokens, global_step=1)
+    assert _rel(r["logits"], z["logits"]) < 5e-6 and np.abs(r["loss_batch"] - z["loss_batch"]).max() < 2e-5
+    assert abs(float(r["loss"]) - float(z["loss"])) < 5e-6 * float(z["loss"]) and float(r["lr"]) == pytest.approx(float(z["lr"]), rel=2e-6)
+    for k in z.files:
+        if k.startswith("grad:"):
+            assert _rel(r["grads"][k[5:]], z[k]) < 2e-5, k
+        if k.startswith("after:"):
+            assert _rel(r["updated"][k[6:]] - P[k[6:]], z[k] - P[k[6:]]) < 2e-4, k
+    # VAE: 16x16 images, two stages, 64 tokens; hard and soft Gumbel from the same injected uniforms
+    z = np.load(os.path.join(HERE, "golden", "vae_small.npz"))
+    vcfg = vo.VaeConfig(**mg.VAE_SMALL)
+    VP = vo.init_params(vcfg, seed=11, bias_perturb=0.02)
+    hpv = dict(num_tokens=mg.VAE_SMALL["num_tokens"], n_embd=512, hidden_dim=64, convblocks=mg.VAE_SMALL["convblocks"], stack_factor=1)
+    for tag, hard, temp in (("hard", True, 1.0), ("soft", False, 0.7)):
+        rv = harness.run_vae_step(hpv, VP, z["img"], z["u"], hard_gumbel=hard, temperature=temp)
+        assert _rel(rv["logits"], z["logits"]) < 5e-6 and _rel(rv["reconstruction"], z["recon_" + tag]) < 5e-6
+        assert abs(float(rv["loss"]) - float(z["loss_" + tag])) < 5e-6 * float(z["loss_" + tag])
+        for n, g in rv["grads"].items():
+            assert _rel(g, z["grad_%s:%s" % (tag, n)]) < 2e-5, (tag, n)
+    np.testing.assert_array_equal(np.argmax(rv["logits"], -1).reshape(2, -1).astype(np.int32), z["tokens"])
