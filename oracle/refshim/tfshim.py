@@ -184,7 +184,37 @@ def created_variables():
 
 
 def _torch_dtype(d):
-    return d.torch if isinstance(d, DType) else d
+    return d.torch if hasattr(d, "torch") else d
+
+
+class _DTypeView:
+    """what `tensor.dtype` must look like to the reference's code (`a.dtype.is_floating`, src/vae_tf/models.py:23)"""
+
+    def __init__(self, td):
+        self.torch = td
+
+    is_floating = property(lambda self: self.torch.is_floating_point)
+    is_integer = property(lambda self: not self.torch.is_floating_point and self.torch is not torch.bool)
+
+    def __getattr__(self, name):          # everything torch's own Python code asks a dtype (is_floating_point, is_complex, ...)
+        return getattr(self.torch, name)
+
+    def __eq__(self, other):
+        return _torch_dtype(other) == self.torch
+
+    def __hash__(self):
+        return hash(self.torch)
+
+    def __repr__(self):
+        return repr(self.torch)
+
+
+class _TFTensor(torch.Tensor):
+    """a torch tensor whose .dtype carries TensorFlow's dtype attributes (values of ops on it are _TFTensors again)"""
+
+    @property
+    def dtype(self):
+        return _DTypeView(torch._C.TensorBase.dtype.__get__(self))
 
 
 def cast(x, dtype, name=None):
@@ -201,6 +231,8 @@ def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True,
     scope = get_variable_scope().name
     full = scope + "/" + name if scope else name
     if full in _variables:
+        for w in _watchers:
+            w.append(_variables[full])
         return _variables[full]
     if full not in _injected:
         raise KeyError("refshim: no value injected for tf variable %r %s" % (full, shape))
@@ -208,6 +240,8 @@ def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True,
     if shape is not None and tuple(v.shape) != tuple(int(s) for s in shape):
         raise ValueError("variable %s: injected shape %s, requested %s" % (full, tuple(v.shape), tuple(shape)))
     _variables[full] = v.requires_grad_(trainable)
+    for w in _watchers:
+        w.append(_variables[full])
     return _variables[full]
 
 
@@ -306,10 +340,60 @@ def square(x, name=None):
     return x * x
 
 
+_watchers = []      # lists that collect the variables tf.get_variable hands out (tf.custom_gradient's variable watcher)
+
+
+class _CustomGradientBridge(torch.autograd.Function):
+    """value = the function's (stop-gradient) result; backward = the user's grad function, called with the upstream gradient and
+    the variables the forward touched, exactly as tf.custom_gradient does"""
+
+    @staticmethod
+    def forward(ctx, result, grad_fn, n_args, *inputs):
+        ctx.grad_fn, ctx.n_args, ctx.n_vars = grad_fn, n_args, len(inputs) - n_args
+        ctx.variables = inputs[n_args:]
+        return result.clone()
+
+    @staticmethod
+    def backward(ctx, dresult):
+        with torch.enable_grad():
+            r = ctx.grad_fn(dresult, variables=list(ctx.variables)) if ctx.n_vars else ctx.grad_fn(dresult)
+        arg_grads, var_grads = (r if ctx.n_vars else (r, []))
+        return (None, None, None) + tuple(arg_grads) + tuple(var_grads)
+
+
 def custom_gradient(f):
-    def wrapper(*a, **k):
-        raise NotImplementedError("refshim: tf.custom_gradient (the VAE's recompute_grad path, src/vae_tf/models.py:8-43) is not emulated")
+    """tf.custom_gradient: f(*args) -> (result, grad_fn); the result's gradient is whatever grad_fn(dresult[, variables]) returns
+    for (args, variables touched by f).  The reference's VAE uses it for its recompute_grad (src/vae_tf/models.py:8-43)."""
+    def wrapper(*args, **kwargs):
+        # what grad_fn's closure will hold: leaves that require grad, typed so that `a.dtype.is_floating` works
+        leaf_args = [a.detach().as_subclass(_TFTensor).requires_grad_(a.is_floating_point()) for a in args]
+        watched = []
+        _watchers.append(watched)
+        try:
+            result, grad_fn = f(*leaf_args, **kwargs)
+        finally:
+            _watchers.pop()
+        variables = list(dict.fromkeys(watched))
+        return _CustomGradientBridge.apply(result.detach(), grad_fn, len(args), *args, *variables)
     return wrapper
+
+
+class GradientTape:
+    """the subset the reference uses: watch(), gradient(target, sources, output_gradients)"""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def watch(self, tensors):
+        pass      # sources are leaves that already require grad (see custom_gradient)
+
+    def gradient(self, target, sources, output_gradients=None):
+        go = output_gradients[0] if isinstance(output_gradients, (list, tuple)) else output_gradients
+        gs = torch.autograd.grad(target, list(sources), grad_outputs=go, allow_unused=True)
+        return [torch.zeros_like(s) if g is None else g for g, s in zip(gs, sources)]
 
 
 # ---- the tf calls of the reference's input helpers (src/input_fns.py:4-38) ----------------------------------------------------
@@ -447,7 +531,8 @@ def no_op(name=None):
 
 
 def get_default_graph():
-    return types.SimpleNamespace(get_collection=lambda key: list(_collections.get(key, [])), get_name_scope=lambda: "")
+    # name scopes mirror the variable scopes here (every tf.variable_scope opens a name scope of the same name)
+    return types.SimpleNamespace(get_collection=lambda key: list(_collections.get(key, [])), get_name_scope=lambda: "/".join(_scopes))
 
 
 class AdamOptimizer:

@@ -29,6 +29,8 @@ model_fn cases (ref_callsite_model_fns.npz): the reference's `vae_model_fn` and 
 VAE cases (16x16 images, two stride-2 stages with residual stacks, 32 codebook tokens; Gumbel uniforms injected):
   v1  hard Gumbel (straight-through), temperature 0.7
   v2  stack_factor 2 (space_to_depth / depth_to_space), soft Gumbel, temperature 1.0
+  v3  v1 with "recompute_grad": true -- the reference's tf.custom_gradient / GradientTape recompute hack (src/vae_tf/models.py:8-43,
+      100,148) executed; same numbers as v1 by construction, which the test asserts
   vh  the exact `vae_example` architecture (32x32 images, convblocks [[3,64],[3,128],[3,256]], 512 tokens), B = 2, hard Gumbel:
       encoder logits, reconstruction and loss in full, the norm of every gradient, the small gradients in full"""
 import json
@@ -131,6 +133,8 @@ VAE_CASES = {
                hard=True, temperature=0.7, seeds=(5, 3, 9)),
     "v2": dict(hp=dict(num_tokens=32, n_embd=64, hidden_dim=16, convblocks=[[2, 16], [3, 24]], stack_factor=2), size=16, batch=2,
                hard=False, temperature=1.0, seeds=(6, 4, 10)),
+    "v3": dict(hp=dict(num_tokens=32, n_embd=64, hidden_dim=16, convblocks=[[2, 16], [3, 24]], stack_factor=1, recompute_grad=True),
+               size=16, batch=2, hard=True, temperature=0.7, seeds=(5, 3, 9)),
 }
 
 

@@ -113,7 +113,7 @@ def test_bf16_reference_sits_within_the_bf16_band(blob):
     assert _rel(logits.numpy(), blob["c/logits"]) < 3e-2
 
 
-@pytest.mark.parametrize("name", ["v1", "v2"])
+@pytest.mark.parametrize("name", ["v1", "v2", "v3"])
 def test_vae_oracle_reproduces_the_reference(vblob, name):
     """src/vae_tf/models.py + layers.py executed over the TF shim (tf.layers.conv2d / conv2d_transpose SAME, tf.get_variable scopes,
     the tied codebook, Gumbel noise from injected uniforms) vs oracle/vae_oracle.py: variable names / order / shapes, encoder
@@ -162,7 +162,14 @@ def test_vae_headline_fixture_is_what_the_reference_computes_here(vblob):
 
 
 @pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
-@pytest.mark.parametrize("name", ["v1", "v2"])
+def test_the_references_recompute_grad_changes_no_number(vblob):
+    """v3 = v1 with recompute_grad: the reference's custom-gradient recompute (row v5) must reproduce v1 bit for bit"""
+    for k in vblob:
+        if k.startswith("v1/") and not k.endswith("variables"):
+            np.testing.assert_array_equal(vblob[k], vblob["v3/" + k[3:]], err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["v1", "v2", "v3"])
 def test_vae_fixture_is_what_the_reference_computes_here(vblob, name):
     out = gen.run_vae_case(gen.VAE_CASES[name])
     for k, a in out.items():
