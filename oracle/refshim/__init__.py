@@ -7,7 +7,8 @@ Why: the oracle (oracle/dalle_oracle.py) is a restatement, and "parity unpinned"
 mesh_tensorflow==0.1.18 (requirements.txt:1-2) can be neither vendored nor installed and the reference ships no tests or golden
 vectors.  The reference's files are nevertheless plain Python over ~60 library calls.  This package provides those calls
 (tfshim.py, mtfshim.py: eager PyTorch-CPU restatements of the published semantics) under the module names
-`tensorflow.compat.v1` / `mesh_tensorflow`, imports the reference's files FROM WHERE THEY LIE (nothing is copied) and executes
+`tensorflow.compat.v1` / `mesh_tensorflow`, imports the reference's files FROM WHERE THEY LIE (nothing is copied, nothing is written
+there: byte-code caching is off while they are imported) and executes
 them: `DALLE.__init__` / `DALLE.forward` (src/dalle_mtf/models.py:141-416) with its `layers.norm`, its `ops.pad` (an
 mtf.Operation subclass, lowered through its own `lower()`), `get_optimizer` / `clip_by_global_norm` (src/optimizers.py:11-104).
 
@@ -79,9 +80,12 @@ def installed(root=DEFAULT_ROOT):
     mods[_ALIAS] = pkg
     sys.modules.update(mods)
     tfshim.reset()
+    write_bytecode = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True        # importing must not leave __pycache__ directories in the (read-only) reference tree
     try:
         yield
     finally:
+        sys.dont_write_bytecode = write_bytecode
         for k in list(sys.modules):
             if k == _ALIAS or k.startswith(_ALIAS + "."):
                 del sys.modules[k]

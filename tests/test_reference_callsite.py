@@ -202,6 +202,9 @@ def test_shims_leave_sys_modules_clean():
         assert m.__file__.startswith(refshim.DEFAULT_ROOT)
     after = {k for k in sys.modules if k.split(".")[0] in ("tensorflow", "mesh_tensorflow", "_dalle_mtf_reference")}
     assert before == after
+    # the reference tree is read-only for this build: importing it must not drop byte-code caches into it
+    for sub in ("", "dalle_mtf", "vae_tf", "utils"):
+        assert not os.path.exists(os.path.join(refshim.DEFAULT_ROOT, "src", sub, "__pycache__")), sub
 
 
 @pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
