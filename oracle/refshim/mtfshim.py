@@ -703,15 +703,17 @@ class _Assign(Operation):
 
 
 def assign(var, new_val, assign_fn=None, name=None):
+    """mtf.assign updates the per-device SLICES (slice dtype, fp32 under both dtype policies of the reference); the master copy
+    (bf16 under "bf_16": true) is only refreshed from them when a checkpoint is written"""
     if isinstance(var, Tensor):
         var = var.operation
-    return _Assign(var, _round_to(new_val.value.detach().to(torch.float32), var.master_dtype))
+    return _Assign(var, _round_to(new_val.value.detach().to(torch.float32), var.slice_dtype))
 
 
 def assign_sub(var, delta, name=None):
     if isinstance(var, Tensor):
         var = var.operation
-    return _Assign(var, _round_to((var.master.detach() - delta.value.detach()).to(torch.float32), var.master_dtype))
+    return _Assign(var, _round_to((var.master.detach() - delta.value.detach()).to(torch.float32), var.slice_dtype))
 
 
 def gradients(ys, xs, grad_ys=None):
