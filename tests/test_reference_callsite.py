@@ -429,3 +429,29 @@ def test_oracle_equals_the_reference_on_random_small_configurations():
             # the step m' / (sqrt(v') + eps) of an entry whose gradient is at the fp32 noise of the backward is ill-conditioned
             # (eps 1e-8), and the step is recovered from the rounded parameter: compare the tensors in L2
             assert _rel(a, b) < 1e-3 or np.abs(a - b).max() <= 4 * np.spacing(np.abs(w[n]).max()), (trial, n, _rel(a, b), hp, step)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_vae_oracle_equals_the_reference_on_random_small_configurations():
+    """eight random VAE configurations (1-3 stages, 1-3 layers per stage incl. stages without residual layers, channel widths,
+    codebook size, stack_factor 1 / 2 / 4, hard / soft Gumbel, temperature, recompute_grad), live"""
+    from oracle.refshim import harness
+    rng = np.random.default_rng(77)
+    for trial in range(8):
+        nst = int(rng.integers(1, 4))
+        blocks = [[int(rng.integers(1, 4)), int(rng.choice([8, 16, 24]))] for _ in range(nst)]
+        sf = int(rng.choice([1, 2, 4]))
+        size = (2 ** nst) * sf * int(rng.integers(1, 3))
+        hp = dict(num_tokens=int(rng.choice([16, 40])), n_embd=64, hidden_dim=16, convblocks=blocks, stack_factor=sf,
+                  recompute_grad=bool(rng.integers(0, 2)))
+        hard, temp, batch = bool(rng.integers(0, 2)), float(rng.choice([0.5, 1.0, 2.0])), int(rng.integers(1, 3))
+        cfg = vo.VaeConfig(hp["num_tokens"], size, blocks, stack_factor=sf)
+        w = vo.init_params(cfg, seed=trial, bias_perturb=0.05)
+        img = vo.synthetic_images(batch, size, seed=trial + 1)
+        u = vo.synthetic_uniforms((batch, cfg.grid, cfg.grid, cfg.num_tokens), seed=trial + 2)
+        r = harness.run_vae_step(hp, w, img, u, hard_gumbel=hard, temperature=temp)
+        assert list(r["variables"]) == list(vo.param_specs(cfg)), (trial, hp)
+        loss, grads = vo.loss_and_grads(w, img, u, cfg, hard=hard, temp=temp)[:2]
+        assert abs(float(loss) - float(r["loss"])) < 5e-6 * float(r["loss"]), (trial, hp)
+        for n in w:
+            assert _rel(grads[n], r["grads"][n]) < 2e-5, (trial, n, hp)
