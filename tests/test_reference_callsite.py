@@ -455,3 +455,20 @@ def test_vae_oracle_equals_the_reference_on_random_small_configurations():
         assert abs(float(loss) - float(r["loss"])) < 5e-6 * float(r["loss"]), (trial, hp)
         for n in w:
             assert _rel(grads[n], r["grads"][n]) < 2e-5, (trial, n, hp)
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_fetch_model_params_is_the_references():
+    """src/utils/utils.py:13-17 executed on every shipped config: same keys and values, missing key -> None, as the product's"""
+    import glob
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "dalle-mtf_amd"))
+    import src.utils.utils as pu
+    with refshim.installed():
+        ru = refshim.reference_module("utils.utils")
+        files = sorted(glob.glob(os.path.join(os.path.dirname(HERE), "configs", "*.json"))) + \
+            sorted(glob.glob(os.path.join(refshim.DEFAULT_ROOT, "configs", "*.json")))
+        assert len(files) >= 8
+        for f in files:
+            a, b = ru.fetch_model_params(f), pu.fetch_model_params(f)
+            assert dict(a) == dict(b) and a["no_such_key"] is None and b["no_such_key"] is None, f
