@@ -33,6 +33,33 @@ def timeit(fn, iters=int(os.environ.get('KB_ITERS', '20')), warm_ms=float(os.env
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+_FLUSH = {}
+
+
+def timeit_cold(fn, warm=None, flush_mb=int(os.environ.get("KB_FLUSH_MB", "768")), iters=int(os.environ.get('KB_ITERS', '20'))):
+    """KB_COLD=1: every timed call starts with cold caches -- a KB_FLUSH_MB buffer (three times the 256-MB Infinity Cache) is
+    rewritten before it, and `warm()` (optional) then re-touches what WOULD be warm inside the step (e.g. the operand the previous
+    kernel has just written).  Times each call with its own event pair; the flush is outside the timed region.  For kernels whose
+    in-step time differs from the hot-loop time (the residual-adding N = 512 products: 77 us in the step, 56 us in a hot loop)."""
+    if "buf" not in _FLUSH or _FLUSH["buf"].numel() != flush_mb << 18:
+        _FLUSH["buf"] = torch.empty(flush_mb << 18, dtype=torch.float32, device=DEV)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    total = 0.0
+    for i in range(iters):
+        _FLUSH["buf"].fill_(float(i))
+        if warm is not None:
+            warm()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        total += e0.elapsed_time(e1)
+    return total / iters * 1e-3
+
+
 def rb(*shape, scale=1.0):
     if os.environ.get("KB_ZERO") == "1":      # zero-filled operands: the package draws less power and clocks higher (DVFS check)
         return torch.zeros(*shape, device=DEV, dtype=torch.bfloat16)
@@ -53,7 +80,14 @@ def bench_gemm_nt(M, N, K, flags=0, tag="", variants=(("auto", 1),)):
         dh.set_option("nt8", 2 if nt4 == 8 else 0)
         dh.set_option("nt8p", 2 if nt4 == 9 else 0)            # 9: persistent 256x256 kernel
         dh.set_option("ntr", 2 if nt4 == 12 else 0)            # 12: full-row 160x512 tiles (N = 512 only)
-        t = timeit(lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res, rowscale=rs))
+        run = lambda: dh.gemm_nt(A, K, Bt, K, C, N, M, N, K, flags, bias=bias, residual=res, relu_src=res, rowscale=rs)   # noqa: E731
+        if os.environ.get("KB_COLD") == "1":
+            # cold caches, A re-touched (the kernel before has just written it), weights re-touched (hot in every step): what is
+            # cold is what the step leaves cold -- the residual / mask source and the output
+            t = timeit_cold(run, warm=lambda: (A.add_(0), Bt.add_(0)))
+            name = name + "/cold"
+        else:
+            t = timeit(run)
         print(f"gemm_nt{tag} M={M} N={N} K={K} flags={flags} {name:8s}: {t*1e6:9.1f} us  {2*M*N*K/t/1e12:8.1f} TF/s", flush=True)
     dh.set_option("nt4", 1)
     dh.set_option("nt8", 1)
