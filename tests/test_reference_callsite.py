@@ -472,3 +472,33 @@ def test_fetch_model_params_is_the_references():
         for f in files:
             a, b = ru.fetch_model_params(f), pu.fetch_model_params(f)
             assert dict(a) == dict(b) and a["no_such_key"] is None and b["no_such_key"] is None, f
+
+
+@pytest.mark.skipif(not refshim.available(), reason="the reference checkout is not on this machine")
+def test_the_references_eval_paths(capsys):
+    """mode = EVAL of both model_fns (src/model_fns.py:231-236, src/model_fns_tf.py:37-38): the VAE switches to eval_gumbel_hard,
+    DALL-E returns the loss of the same forward without an optimizer -- vs the oracle"""
+    from oracle.refshim import harness
+    c = gen.FN_CASES["fv"]
+    cfg, w, img, u = gen.fn_vae_inputs(c)
+    with refshim.installed():
+        from oracle.refshim import tfshim
+        fns = refshim.reference_module("model_fns_tf")
+        from collections import defaultdict
+        tfshim.inject_variables({"vae/" + k: v for k, v in w.items()}, uniforms=[u])
+        tfshim.set_global_step(c["step"])
+        feats = torch.as_tensor(img)
+        spec = fns.vae_model_fn(feats, feats, tfshim.estimator.ModeKeys.EVAL, defaultdict(lambda: None, dict(c["params"])))
+        loss_eval = float(spec.loss.detach())
+    p = c["params"]
+    loss, _ = vo.loss_and_grads(w, img, u, cfg, hard=p["eval_gumbel_hard"], temp=vo.temperature(c["step"], p))[:2]
+    assert abs(float(loss) - loss_eval) < 5e-6 * loss_eval
+    c = gen.FN_CASES["fd"]
+    vcfg, vw, cfg, dw, img, text = gen.fn_dalle_inputs(c)
+    r = harness.run_dalle_model_fn(c["params"], vw, dw, img, text, global_step=c["step"], mode="eval")
+    capsys.readouterr()
+    assert "updated" not in r
+    logits = vo.forward({n: torch.tensor(a) for n, a in vw.items()}, torch.tensor(img), vcfg, return_logits=True)
+    tokens = do.assemble_tokens(text, do.image_tokens_from_logits(logits.numpy()), c["params"]["text_vocab_size"])
+    loss, _ = do.loss_and_grads(dw, tokens, cfg)
+    assert abs(loss - float(r["loss"])) < 5e-6 * float(r["loss"])
