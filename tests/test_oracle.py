@@ -275,3 +275,87 @@ def test_bf16_oracle_rounds_gradients_and_teacher_forcing_is_consistent():
     sites2["layer_1/h"] = sites["layer_1/h"] * 1.5
     _, g5 = do.loss_and_grads(P, tok, cfg, bf16=True, force=sites2)
     assert not np.array_equal(g5["layer_1/mlp/mlp_linear_2/kernel"], g1["layer_1/mlp/mlp_linear_2/kernel"])
+
+
+def test_tf_adam_restatement_against_torch_adam():
+    """tf.train.AdamOptimizer as the VAE oracle (and oracle/refshim) restate it (lr_t = lr sqrt(1 - b2^t) /
+    (1 - b1^t); p -= lr_t m / (sqrt(v) + eps)) against torch.optim.Adam, an independent implementation of the same algorithm: the
+    two differ only in where eps enters (torch: eps / sqrt(1 - b2^t) in TF's terms), i.e. by O(eps / |g|) -- five steps agree to 1e-5."""
+    from oracle import vae_oracle as vo
+    rng = np.random.default_rng(0)
+    p0 = {"w": rng.standard_normal((7, 5)).astype(np.float32), "b": rng.standard_normal(5).astype(np.float32)}
+    # gradients bounded away from zero: where |g| is comparable to eps / sqrt(1 - b2) the two eps conventions differ by design
+    grads = [{k: (rng.uniform(0.05, 0.15, v.shape) * rng.choice([-1.0, 1.0], v.shape)).astype(np.float32) for k, v in p0.items()}
+             for _ in range(5)]
+    p = {k: v.copy() for k, v in p0.items()}
+    m, v = {k: np.zeros_like(a) for k, a in p0.items()}, {k: np.zeros_like(a) for k, a in p0.items()}
+    for t, g in enumerate(grads, 1):
+        vo.tf_adam_step(p, g, m, v, t, 1e-2)
+    tp = {k: torch.tensor(a.copy(), requires_grad=True) for k, a in p0.items()}
+    opt = torch.optim.Adam(list(tp.values()), lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    for g in grads:
+        for k in tp:
+            tp[k].grad = torch.tensor(g[k])
+        opt.step()
+    for k in p0:
+        step_o, step_t = p[k] - p0[k], tp[k].detach().numpy() - p0[k]
+        assert np.abs(step_o - step_t).max() <= 1e-5 * np.abs(step_t).max(), k
+
+
+def test_crop_and_resize_restatement_against_torch_interpolate():
+    """the product's crop_center_and_resize (tf.image.crop_and_resize restated: sample y = y1 (H-1) + i (y2-y1)(H-1)/(size-1),
+    bilinear) on a SQUARE image uses the identity box, which is exactly bilinear resizing with aligned corners: compared with
+    torch.nn.functional.interpolate(mode="bilinear", align_corners=True), an independent implementation."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dalle-mtf_amd"))
+    from src import input_fns as prod
+    rng = np.random.default_rng(1)
+    for n, size in ((40, 16), (17, 32), (64, 64)):
+        img = rng.integers(0, 256, size=(n, n, 3), dtype=np.uint8)
+        got = prod.crop_center_and_resize(img, size)
+        ref = torch.nn.functional.interpolate(torch.tensor(img).float().permute(2, 0, 1)[None], size=(size, size), mode="bilinear",
+                                              align_corners=True)[0].permute(1, 2, 0).numpy()
+        assert np.abs(got - ref).max() < 2e-3, (n, size, np.abs(got - ref).max())
+
+
+def test_mtf_primitive_restatements_against_torch_builtins():
+    """the mesh-tensorflow primitives as oracle/refshim restates them against independent PyTorch built-ins:
+    softmax = exp(x - logsumexp) with a detached max shift vs torch.softmax incl. its gradient; softmax_cross_entropy_with_logits
+    (one-hot targets) vs F.cross_entropy; gather as a one-hot einsum vs indexing incl. the scatter-add gradient; named-dimension
+    einsum / broadcast vs torch.einsum; reduce_mean = sum * (1 / n) vs torch.mean."""
+    from oracle.refshim import mtfshim as mtf, tfshim as tf
+    g = mtf.Graph()
+    mesh = mtf.Mesh(g, "m")
+    B, S, V, D = mtf.Dimension("b", 3), mtf.Dimension("s", 5), mtf.Dimension("v", 11), mtf.Dimension("d", 4)
+    rng = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 11, generator=rng, requires_grad=True)
+    xt = mtf.import_tf_tensor(mesh, x, mtf.Shape([B, S, V]))
+    xt._value = x                                                    # keep the autograd leaf
+    sm = mtf.softmax(xt, V)
+    ref = torch.softmax(x, -1)
+    assert torch.allclose(sm.value, ref, atol=1e-6)
+    w = torch.randn(3, 5, 11, generator=rng)
+    g1, = torch.autograd.grad((sm.value * w).sum(), x, retain_graph=True)
+    g2, = torch.autograd.grad((ref * w).sum(), x)
+    assert torch.allclose(g1, g2, atol=1e-6)
+    labels = torch.randint(0, 11, (3, 5), generator=rng)
+    lt = mtf.import_tf_tensor(mesh, labels.to(torch.int32), mtf.Shape([B, S]))
+    ce = mtf.layers.softmax_cross_entropy_with_logits(xt, lt, V)
+    assert torch.allclose(ce.value, torch.nn.functional.cross_entropy(x.reshape(-1, 11), labels.reshape(-1), reduction="none").reshape(3, 5),
+                          atol=1e-5)
+    assert torch.allclose(mtf.reduce_mean(ce).value, ce.value.mean(), atol=1e-6)
+    tab = torch.randn(11, 4, generator=rng, requires_grad=True)
+    tt = mtf.import_tf_tensor(mesh, tab, mtf.Shape([V, D]))
+    tt._value = tab
+    got = mtf.gather(tt, lt, V)
+    assert got.shape.dimension_names == ["b", "s", "d"] and torch.equal(got.value, tab[labels])
+    gg, = torch.autograd.grad(got.value.pow(2).sum(), tab)
+    ref_g = torch.zeros(11, 4).index_add_(0, labels.reshape(-1), 2 * tab[labels].detach().reshape(-1, 4))
+    assert torch.allclose(gg, ref_g, atol=1e-6)
+    e = mtf.einsum([xt, tt], output_shape=mtf.Shape([S, D, B]))     # contraction over v, output dims reordered by name
+    assert torch.allclose(e.value, torch.einsum("bsv,vd->sdb", x, tab), atol=1e-5)
+    bias = mtf.import_tf_tensor(mesh, torch.arange(5.0), mtf.Shape([S]))
+    y = xt + bias                                                     # broadcast by dimension NAME, not by position
+    assert torch.allclose(y.value, x + torch.arange(5.0)[None, :, None])
+    assert tf.float32.is_floating and tf.int32.is_integer
