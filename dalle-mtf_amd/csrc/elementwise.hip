@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finish_kernel(const float* __restr
 extern "C" int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, const float* mean,
                                  const float* rstd, const uint16_t* dres, uint16_t* dx, float* dg, float* db,
                                  void* workspace, int64_t rows, int d, void* stream) {
-  DMI_REQUIRE(dy && x && g && mean && rstd && dx && dg && db && workspace, "layernorm_bwd: null pointer");
+  DMI_REQUIRE(dy && x && g && mean && rstd && dx && workspace && ((dg && db) || (!dg && !db)), "layernorm_bwd: null pointer");
   DMI_REQUIRE(d % 8 == 0 && d <= 2048 && rows > 0, "layernorm_bwd: unsupported d=%d (need d%%8==0, d<=2048)", d);
   hipStream_t st = (hipStream_t)stream;
   const int P = (int)cdiv64(rows, LN_BWD_RPB);
@@ -550,8 +550,69 @@ extern "C" int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const ui
   else if (d <= 1024) ln_bwd_kernel<2><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
   else ln_bwd_kernel<4><<<grid, blk, shm, st>>>(dy, x, g, mean, rstd, dres, dx, part, rows, d);
   DMI_CHECK_LAUNCH("layernorm_bwd");
+  if (dg == nullptr && db == nullptr) return DMI_OK;   // deferred: the caller reduces the partials with dmi_layernorm_bwd_finish_batch
   ln_bwd_finish_kernel<<<dim3((2 * d + 15) / 16), blk, 0, st>>>(part, dg, db, P, d);
   DMI_CHECK_LAUNCH("layernorm_bwd_finish");
+  return DMI_OK;
+}
+
+// The gain / bias gradients of several LayerNorms reduced in ONE launch: blockIdx.y = the LayerNorm.  Each of the 13 reduces of a
+// dalle_example step is a 64-block kernel of ~7 us; the results are only needed by the gradient exchange / the optimizer.
+#define LN_FINISH_MAX 16
+struct LnFinishBatch {
+  const float* part[LN_FINISH_MAX];
+  float* dg[LN_FINISH_MAX];
+  float* db[LN_FINISH_MAX];
+  int P[LN_FINISH_MAX];
+  int d;
+};
+__global__ __launch_bounds__(256) void ln_bwd_finish_batch_kernel(LnFinishBatch b) {
+  __shared__ float sm[16][17];
+  const int it = blockIdx.y;
+  const float* __restrict__ part = b.part[it];
+  const int P = b.P[it], d = b.d;
+  const int cl = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const int64_t nc = 2 * (int64_t)d;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+  if (c < nc) {   // the same fixed summation order as ln_bwd_finish_kernel: bit-identical results
+    int p = grp;
+    for (; p + 112 < P; p += 128) {
+      const float* q = part + (int64_t)p * nc + c;
+      a0 += q[0];
+      a1 += q[16 * nc];
+      a2 += q[32 * nc];
+      a3 += q[48 * nc];
+      a4 += q[64 * nc];
+      a5 += q[80 * nc];
+      a6 += q[96 * nc];
+      a7 += q[112 * nc];
+    }
+    for (; p < P; p += 16) a0 += part[(int64_t)p * nc + c];
+  }
+  sm[grp][cl] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+  __syncthreads();
+  if (grp == 0 && c < nc) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s += sm[q][cl];
+    if (c < d) b.dg[it][c] = s;
+    else b.db[it][c - d] = s;
+  }
+}
+extern "C" int dmi_layernorm_bwd_finish_batch(const void* const* workspaces, float* const* dgs, float* const* dbs, const int64_t* rows,
+                                              int n, int d, void* stream) {
+  DMI_REQUIRE(workspaces && dgs && dbs && rows && n >= 1 && n <= LN_FINISH_MAX, "layernorm_bwd_finish_batch: 1..%d items", LN_FINISH_MAX);
+  DMI_REQUIRE(d % 8 == 0 && d <= 2048, "layernorm_bwd_finish_batch: unsupported d=%d", d);
+  LnFinishBatch b;
+  b.d = d;
+  for (int i = 0; i < n; ++i) {
+    DMI_REQUIRE(workspaces[i] && dgs[i] && dbs[i] && rows[i] > 0, "layernorm_bwd_finish_batch: null pointer in item %d", i);
+    b.part[i] = (const float*)workspaces[i]; b.dg[i] = dgs[i]; b.db[i] = dbs[i];
+    b.P[i] = (int)cdiv64(rows[i], LN_BWD_RPB);
+  }
+  ln_bwd_finish_batch_kernel<<<dim3((2 * d + 15) / 16, n), dim3(256), 0, (hipStream_t)stream>>>(b);
+  DMI_CHECK_LAUNCH("layernorm_bwd_finish_batch");
   return DMI_OK;
 }
 

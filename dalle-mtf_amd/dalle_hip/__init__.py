@@ -64,6 +64,7 @@ def _declare(L):
         "dmi_layernorm_fwd": (I, [P, P, P, P, P, P, L64, I, F, P]),
         "dmi_layernorm_bwd_workspace_bytes": (L64, [L64, I]),
         "dmi_layernorm_bwd": (I, [P, P, P, P, P, P, P, P, P, P, L64, I, P]),
+        "dmi_layernorm_bwd_finish_batch": (I, [P, P, P, P, I, I, P]),
         "dmi_gemm_nt": (I, [P, I, P, I, P, I, I, I, I, I, P, P, P, P, P]),
         "dmi_gemm_nt_splitk_workspace_bytes": (L64, [I, I, I]),
         "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P, P]),
@@ -194,9 +195,19 @@ def layernorm_bwd_workspace_bytes(rows, d):
 
 
 def layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, ws, rows, d):
-    _dev(dy, x, g, mean, rstd, dx, dg, db, ws)
+    """dg = db = None: deferred -- the partials stay in `ws` until layernorm_bwd_finish_batch"""
+    _dev(dy, x, g, mean, rstd, dx, ws)
     _check(lib().dmi_layernorm_bwd(_p(dy), _p(x), _p(g), _p(mean), _p(rstd), _p(dres), _p(dx), _p(dg), _p(db),
                                    _p(ws), rows, d, _stream()), "layernorm_bwd")
+
+
+def layernorm_bwd_finish_batch(items, d):
+    """items: [(workspace, dg, db, rows)] of deferred layernorm_bwd calls (at most 16, one width)"""
+    import ctypes
+    n = len(items)
+    PA, LA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    _check(lib().dmi_layernorm_bwd_finish_batch(PA(*[_p(i[0]) for i in items]), PA(*[_p(i[1]) for i in items]), PA(*[_p(i[2]) for i in items]),
+                                                LA(*[int(i[3]) for i in items]), n, d, _stream()), "layernorm_bwd_finish_batch")
 
 
 def gemm_nt(A, lda, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, residual=None, relu_src=None, rowscale=None):

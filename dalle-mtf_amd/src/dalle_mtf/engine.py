@@ -287,6 +287,13 @@ class DalleEngine:
         self.ws_blk = [torch.empty(int(dh.gemm_tn_workspace_bytes(M, i_, j_)) + 256, dtype=torch.uint8, device=self.dev)
                        for i_, j_ in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d))]
         self.deferred = dh.DeferredReduces()
+        # [r05-prep, NOT YET RUN ON A GPU] the gain / bias gradient reduces of the 2L + 1 LayerNorm backwards deferred into batched
+        # launches (dmi_layernorm_bwd_finish_batch): one at the end of the backward on one GPU, one per block under data parallelism
+        # (the exchange takes a block's gradients as soon as its backward is done).  13 launches of ~7 us -> 1 at dalle_example.
+        self.defer_ln = bool(self.hp.get("defer_ln_finish", os.environ.get("DALLE_DEFER_LN", "0") != "0"))
+        if self.defer_ln:
+            nb = int(dh.layernorm_bwd_workspace_bytes(M, d)) + 256
+            self.ln_ws = [torch.empty(nb, dtype=torch.uint8, device=self.dev) for _ in range(2 * L + 1)]
         # tuning switch: hparams win, the environment variable gives the default (A/B runs: tools/ab_env.sh)
         # LayerNorm fused into the products that feed it (dmi_gemm_nt_ln): the full-row tiles exist for n_embd = 512
         # Measured (profiles/r04q_kbench_ln512.log, r04q_ab_fuse_ln.log): out-projection + norm_2 46.5 us fused vs 33.4 + 16.1 us,
@@ -616,8 +623,22 @@ class DalleEngine:
             dh.gemm_nt_splitk(E[whole_rows:], Vp, Wk, Vp, self.dxn[whole_rows:], tail_rows, d, Vp, ns, self.ws,
                               rowscale=self.rowscale[whole_rows:])
         dxa, dxb = self.dx
-        dh.layernorm_bwd(self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
-                         self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"), ws, M, d)
+        pend = []
+
+        def ln_bwd(idx, dy, x, g, mean, rstd, dres, dx, dg, db):
+            if self.defer_ln:
+                dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, None, None, self.ln_ws[idx], M, d)
+                pend.append((self.ln_ws[idx], dg, db, M))
+            else:
+                dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, ws, M, d)
+
+        def flush_ln():
+            while pend:
+                dh.layernorm_bwd_finish_batch(pend[:16], d)
+                del pend[:16]
+
+        ln_bwd(2 * L, self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
+               self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"))
         for bi, l in enumerate(reversed(range(L))):
             p = f"layer_{l}/"
             st = self.stats[l]
@@ -633,8 +654,8 @@ class DalleEngine:
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
                         dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
             dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
-            dh.layernorm_bwd(self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
-                             self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"), ws, M, d)
+            ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
+                   self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
             # attention
             self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
                         dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
@@ -642,15 +663,18 @@ class DalleEngine:
             dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
             self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
-            dh.layernorm_bwd(self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
-                             self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"), ws, M, d)
+            ln_bwd(2 * l, self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
+                   self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"))
             self.deferred.run()        # the block's seven slab reduces in one launch
+            if allreduce and self.world > 1:
+                flush_ln()             # the exchange takes this block's gradients now
             ready(rp[1 + bi])
         # embeddings: positions visited in token-id order (sorted on the side stream during the forward)
         if self._sort_done is not None:
             torch.cuda.current_stream().wait_event(self._sort_done)
         dh.embed_bwd(self.tok_sorted, self.tok_perm, dxa, self._gv("embedding/wte"), self._gv("positional_embedding/wpe"),
                      B, S, d, self.V, self.embed_ws)
+        flush_ln()
         ready(rp[L + 1])
         if self.dp_reserve_cus and allreduce:
             dh.set_option("reserve_cus", 0)

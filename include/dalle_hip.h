@@ -68,6 +68,11 @@ int64_t dmi_layernorm_bwd_workspace_bytes(int64_t rows, int d);
 int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const uint16_t* g, const float* mean,
                       const float* rstd, const uint16_t* dres, uint16_t* dx, float* dg, float* db,
                       void* workspace, int64_t rows, int d, void* stream);
+/* dg == db == NULL defers the reduce of the gain / bias gradients: the per-block partials stay in `workspace` (which the caller
+ * then must not reuse) until dmi_layernorm_bwd_finish_batch reduces up to 16 LayerNorms of the same width in one launch (same
+ * summation order: bit-identical to the immediate form).  Host arrays of n device pointers / row counts. */
+int dmi_layernorm_bwd_finish_batch(const void* const* workspaces, float* const* dgs, float* const* dbs, const int64_t* rows,
+                                   int n, int d, void* stream);
 
 /* ---- K3/K5/K6/K7  dense layers: mtf einsum / mtf.layers.dense   models.py:242-244,303-311,320-321,369,393
  * C[M,N] = A[M,K] . Bt[N,K]^T  (both operands K-contiguous), bf16 in, fp32 accumulate on MFMA.

@@ -148,3 +148,38 @@ def test_attention_kernels_at_headline_shape(B, H, S):
     head, every causal tile class, all XCD-grouped block orders in one grid."""
     from test_kernels_gpu import _attention_fwd_bwd
     _attention_fwd_bwd(B, H, S)
+
+
+def test_engine_vs_the_references_own_headline_digest():
+    """[r05-prep, not yet run on a GPU] the engine against tests/golden/ref_callsite_dalle_headline.npz directly: what the reference's
+    own files (src/dalle_mtf/*.py over the shims of oracle/refshim) compute at the exact dalle_example architecture, B = 1 -- loss,
+    the norm of every gradient tensor and the small gradients, with the bounds of the oracle comparison above (the oracle equals
+    that digest to 1e-6, tests/test_reference_callsite.py)."""
+    import importlib.util
+    import os
+    from src.dalle_mtf.engine import DalleEngine
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_ref_callsite_golden", os.path.join(here, "golden", "make_ref_callsite_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    z = np.load(os.path.join(here, "golden", "ref_callsite_dalle_headline.npz"))
+    cfg, weights, tokens = gen.case_inputs(gen.HEADLINE)
+    hp = gen.HEADLINE["hp"]
+    eng = DalleEngine(hp["n_embd"], hp["n_layers"], hp["n_heads"], hp["text_vocab_size"], hp["image_vocab_size"], hp["text_seq_len"],
+                      hp["image_seq_len"], batch_size=1, hparams=dict(lr=hp["lr"], train_steps=hp["train_steps"], warmup_steps=hp["warmup_steps"],
+                                                                      gradient_clipping=hp["gradient_clipping"]))
+    eng.load_reference_params(weights)
+    loss = float(eng.forward(torch.from_numpy(tokens).cuda(), need_grad=True).item())
+    eng.backward()
+    eng.wait_grads()
+    gh = eng.export_reference(eng.g)
+    assert abs(loss - float(z["loss"])) <= 2e-4 * float(z["loss"]), (loss, float(z["loss"]))
+    norms = np.array([np.linalg.norm(gh[k].astype(np.float64)) for k in weights])
+    rel = np.abs(norms - z["grad_norms"]) / (z["grad_norms"] + 1e-30)
+    print("worst gradient-norm deviation vs the reference digest:", float(rel.max()), list(weights)[int(rel.argmax())])
+    assert rel.max() < 0.03
+    worst = max((float(np.linalg.norm(gh[k[5:]] - z[k]) / (np.linalg.norm(z[k]) + 1e-30)), k) for k in z.files if k.startswith("grad:"))
+    print("worst small gradient vs the reference digest:", worst)
+    assert worst[0] < 0.06
+    del eng
+    torch.cuda.empty_cache()

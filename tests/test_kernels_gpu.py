@@ -133,6 +133,57 @@ def test_layernorm_fwd_bwd(rows, d):
     close(dx2, xf.grad, 1.6e-2, 2e-2, "ln_bwd dx (no residual)")
 
 
+def test_layernorm_bwd_deferred_finish_batch():
+    """[r05-prep] dmi_layernorm_bwd with dg = db = NULL leaves the per-block partials in the workspace; one
+    dmi_layernorm_bwd_finish_batch launch reduces several LayerNorms -- bit-identical to the immediate form (same summation order),
+    different row counts per item, 1 and 15 items."""
+    d = 512
+    cases = [(4097, 1), (64, 2), (40960, 3)] + [(256 + 32 * i, 10 + i) for i in range(13)]
+    ref, items, keep = [], [], []
+    for rows, seed in cases:
+        x, dy, g = rnd(rows, d, seed=seed), rnd(rows, d, seed=seed + 100), bf(1 + 0.1 * torch.randn(d))
+        xd, dyd, gd = x.to(DEV), dy.to(DEV), g.to(DEV)
+        y = torch.zeros(rows, d, dtype=torch.bfloat16, device=DEV)
+        mean = torch.zeros(rows, dtype=torch.float32, device=DEV)
+        rstd = torch.zeros(rows, dtype=torch.float32, device=DEV)
+        dh.layernorm_fwd(xd, gd, torch.zeros(d, dtype=torch.bfloat16, device=DEV), y, mean, rstd, rows, d)
+        dx0, dx1 = (torch.zeros(rows, d, dtype=torch.bfloat16, device=DEV) for _ in range(2))
+        dg0, db0, dg1, db1 = (torch.full((d,), float("nan"), dtype=torch.float32, device=DEV) for _ in range(4))
+        ws0, ws1 = (ws(dh.layernorm_bwd_workspace_bytes(rows, d)) for _ in range(2))
+        dh.layernorm_bwd(dyd, xd, gd, mean, rstd, None, dx0, dg0, db0, ws0, rows, d)
+        dh.layernorm_bwd(dyd, xd, gd, mean, rstd, None, dx1, None, None, ws1, rows, d)
+        assert torch.equal(dx0, dx1)
+        ref.append((dg0, db0))
+        items.append((ws1, dg1, db1, rows))
+        keep.append((xd, dyd, gd, mean, rstd))
+    dh.layernorm_bwd_finish_batch(items[:1], d)
+    dh.layernorm_bwd_finish_batch(items[1:], d)
+    for (dg0, db0), (_, dg1, db1, _) in zip(ref, items):
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+
+
+def test_full_row_kernel_residual_prefetch_changes_nothing():
+    """[r05-prep] option ntr_prefetch: the residual rows of a full-row tile are pulled into L2 by LDS-DMA loads into a scratch block
+    during the last k-steps -- results bit-identical with and without, K = 512 (16 k-steps: the prefetch starts at k-step 4) and
+    K = 2048, M a multiple of the 160-row tile and not."""
+    for M, K in ((40960, 512), (1600, 2048), (1000, 512), (161, 64)):
+        A, Bt = rnd(M, K, seed=1).to(DEV), rnd(512, K, scale=0.1, seed=2).to(DEV)
+        bias, res = rnd(512, seed=3).to(DEV), rnd(M, 512, seed=4).to(DEV)
+        out = []
+        for pf in (0, 1):
+            dh.set_option("ntr", 2)
+            dh.set_option("ntr_prefetch", pf)
+            try:
+                C = torch.zeros(M, 512, dtype=torch.bfloat16, device=DEV)
+                dh.gemm_nt(A, K, Bt, K, C, 512, M, 512, K, dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=bias, residual=res)
+                out.append(C)
+            finally:
+                dh.set_option("ntr", 1)
+                dh.set_option("ntr_prefetch", 0)
+        assert torch.equal(out[0], out[1]), (M, K)
+        close(out[1], _gemm_ref(A.cpu(), Bt.cpu(), bias.cpu(), residual=res.cpu()), 1.6e-2, 2e-2 * math.sqrt(K) * 0.1, "ntr prefetch")
+
+
 # ------------------------------------------------------------------ GEMMs
 
 def _gemm_ref(A, Bt, bias=None, relu=False, residual=None, relu_src=None):
