@@ -45,7 +45,7 @@ VAE_MODELS = {"vae_example": 32, "vae_coco": 16}     # per-GPU batch (SURVEY §8
 HP = dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0)
 PER_GPU_BATCH = 32
 PEAK_BF16_TFLOPS = 2500.0
-ROUND_TAG = "r04"      # profiles/<ROUND_TAG>_traffic_*.json must come from this round's kernels
+ROUND_TAG = "r05"      # profiles/<ROUND_TAG>_traffic_*.json must come from this round's kernels
 
 
 def fwd_flops_per_token(d, L, S, V):
@@ -179,6 +179,9 @@ def bench_vae(args, world, rank, pg, comm):
     from src.vae_tf import DiscreteVAE
     p = json.load(open(os.path.join(ROOT, "configs", args.model + ".json")))
     B = args.batch or VAE_MODELS[args.model]
+    if args.scaling == "strong":     # global batch fixed at the model's BASELINE value, as on the DALL-E path
+        assert B % world == 0, f"strong scaling: the global batch {B} must divide by the number of GPUs {world}"
+        B = B // world
     vae = DiscreteVAE(num_tokens=p["num_tokens"], dimensions=p["dataset"]["image_size"], convblocks=p["convblocks"],
                       dim=p.get("dim") or 512, hidden_dim=p.get("hidden_dim") or 64, input_channels=p.get("n_channels") or 3,
                       use_bf16=bool(p.get("use_bf16")), recompute_grad=bool(p.get("recompute_grad")),
@@ -262,7 +265,7 @@ def bench_vae(args, world, rank, pg, comm):
                 "step_tflops_per_gpu": train_fl / (ms * 1e-3) / 1e12}
     out = {"metric": f"train image tokens/sec per node, {args.model}", "value": B * world * g2 * args.steps / dt, "unit": "tokens/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": f"configs/{args.model}.json discrete-VAE train step ({vae.H}x{vae.W} images, convblocks "
                                   f"{p['convblocks']}, {vae.num_tokens} tokens, grid {vae.grid}x{vae.grid}), synthetic images",
                       "global_batch": B * world, "per_gpu_batch": B, "images_per_s": B * world * args.steps / dt,
@@ -285,6 +288,9 @@ def main():
                     help="weak (default, the primary line): per-GPU batch fixed, global batch = batch x N.  strong (BASELINE.md §2's "
                          "secondary number): GLOBAL batch fixed at the model's BASELINE value, per-GPU batch = global / N")
     ap.add_argument("--model", default="dalle_example", choices=sorted(MODELS) + sorted(VAE_MODELS))
+    ap.add_argument("--reserve-cus", type=int, default=None,
+                    help="N > 1: CUs the persistent kernels of the BACKWARD leave to the exchange's RCCL channels (engine option "
+                         "dp_reserve_cus; default: DALLE_DP_RESERVE_CUS or 0).  For the first multi-GPU A/B: one call per value.")
     args = ap.parse_args()
     world, rank, pg, comm = setup_dist(args)
     if args.model in VAE_MODELS:
@@ -302,7 +308,8 @@ def main():
         assert B % world == 0, f"strong scaling: the global batch {B} must divide by the number of GPUs {world}"
         B = B // world
     eng = DalleEngine(CFG["n_embd"], CFG["n_layers"], CFG["n_heads"], CFG["text_vocab_size"], CFG["image_vocab_size"],
-                      CFG["text_seq_len"], CFG["image_seq_len"], batch_size=B, global_batch_size=B * world, hparams=HP,
+                      CFG["text_seq_len"], CFG["image_seq_len"], batch_size=B, global_batch_size=B * world,
+                      hparams=dict(HP, **({"dp_reserve_cus": args.reserve_cus} if args.reserve_cus is not None else {})),
                       process_group=pg, world_size=world, comm=comm)
     eng.init_params(seed=1234)
     if world > 1:
@@ -363,6 +370,7 @@ def main():
                                    f"{CFG['n_heads']} heads, seq 256+1024, V={V}), synthetic captions + synthetic image-token ids",
                        "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
                        "dp_transport": eng.reducer.transport if world > 1 else None,
+                       "dp_reserve_cus": eng.dp_reserve_cus if world > 1 else None,
                        "dp_pieces_per_step": len(schedule) if world > 1 else None,
                        "dp_largest_piece_MB": (max(b - a for a, b in schedule) * 4 / 2 ** 20) if (world > 1 and schedule) else None,
                        # every exchange piece in issue order, and the bytes issued after the last backward kernel (the embedding

@@ -837,8 +837,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
 //     every wave in the queue of the CU's one address unit for ~1200 cycles with the matrix pipe idle (the one-tile kernels run
 //     4.1 k cycles per k-step against 2 k of MFMA issue per SIMD).
 // One buffer descriptor per operand for the whole kernel (based at the matrix origin, exact size: rows past M / N read as
-// zeros), tile and k position in the scalar offset: the per-lane offsets are tile-independent and "which tile does this load
-// belong to" is two scalar selects -- every k-step of every tile runs the same code.
+// zeros) -- [r05] one descriptor per operand and TILE, based at the tile's first row: with one whole-matrix descriptor and the tile
+// origin in the instruction's scalar offset (round 4) the rows of a ragged last tile past M / N were fetched from beyond the operand
+// (the range check does not cover the scalar offset; masked in the epilogue, but an out-of-allocation read).  The per-lane offsets
+// are tile-independent and "which tile does this load belong to" is a scalar select of the descriptor -- every k-step of every tile
+// runs the same code.
 // Tiles: virtual block id v = blockIdx + i * gridDim (gridDim a multiple of 8, so v % 8 is this block's XCD) through the same
 // XCD remap + GROUP_M order as the one-tile-per-block kernels: the 32 CUs of an XCD work on 32 consecutive tiles of its list.
 // Same k order as every other NT kernel -> bit-identical results.  Needs K % 128 == 0 (a tile's k-steps alternate between the
@@ -861,8 +864,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
     offa[ks] = lds_chunk_off(wm * 128 + c16, ks * 4 + g16);
     offb[ks] = 32768 + lds_chunk_off(wn * 64 + c16, ks * 4 + g16);
   }
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (int)(((int64_t)(a.M - 1) * a.lda + a.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
+  // descriptors based at a tile's first row, sized to the end of the operand: a row past M / N has a vector offset >= num_records
+  // and reads as zeros (the range check covers the vector offset only, so the k position -- always inside a valid row -- may ride in
+  // the scalar offset, but the tile origin may not)
+  auto rsrc_a = [&](int m0_) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0_ * a.lda), 0, (int)(((int64_t)(a.M - 1 - m0_) * a.lda + a.K) * 2), 0x00020000);
+  };
+  auto rsrc_b = [&](int n0_) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.B + (int64_t)n0_ * a.ldb), 0, (int)(((int64_t)(a.N - 1 - n0_) * a.ldb + a.K) * 2), 0x00020000);
+  };
   int voa[4], vob[4];      // per-lane source offsets inside a tile (16-B chunk XOR-swizzled on the source side), tile-independent
   {
     const int chp = tid & 7;
@@ -881,7 +891,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
   // second substep's groups cover the landing of the last pieces.  The order is pinned with sched_barrier(0) between the groups
   // (left alone, hipcc clusters the DMAs again) and the fragment reads are software-pipelined by hand: the A fragment of group
   // g + 2 and, in group 5, the second substep's B fragments are requested two groups ahead of their first use.
-  auto compute = [&](int st, int sa, int sb) {   // sa / sb: byte offsets (tile origin + k) of the A / B rows being loaded
+  auto compute = [&](int st, const __amdgpu_buffer_rsrc_t ra, const __amdgpu_buffer_rsrc_t rb, int sk) {   // ra / rb: the tile being loaded, sk: its k position (bytes)
     const char* cur = smem + st * STG;
     char* dst = smem + (st ^ 1) * STG + wid * 1024;
     bf16x8 fb[2][4], fa[16];
@@ -901,8 +911,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][j], fa[g], acc[i][j], 0, 0, 0);  // D[n][m]: lane (c, g) holds C[m = c][n = 4g ..]
-      if (g < 4) glds16(ra, dst + g * 8192, voa[g], sa);
-      else if (g < 8) glds16(rb, dst + 32768 + (g - 4) * 8192, vob[g - 4], sb);
+      if (g < 4) glds16(ra, dst + g * 8192, voa[g], sk);
+      else if (g < 8) glds16(rb, dst + 32768 + (g - 4) * 8192, vob[g - 4], sk);
       __builtin_amdgcn_sched_barrier(0);
     }
     MFMA_PRIO(0);
@@ -917,8 +927,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
     char* base = smem + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      glds16(ra, base + i * 8192, voa[i], m0 * a.lda * 2);
-      glds16(rb, base + 32768 + i * 8192, vob[i], n0 * a.ldb * 2);
+      glds16(rsrc_a(m0), base + i * 8192, voa[i], 0);
+      glds16(rsrc_b(n0), base + 32768 + i * 8192, vob[i], 0);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -943,17 +953,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8p_kernel(GemmArgs a) {
       tile_of_block(xcd_remap(vn, ntiles), a.tiles_m, a.tiles_n, tm2, tn2);
       nm0 = tm2 * BM8; nn0 = tn2 * BN8;
     }
-    const int ca = m0 * a.lda * 2, cb = n0 * a.ldb * 2;        // this tile's origin in A / B (bytes)
-    const int na = nm0 * a.lda * 2, nb = nn0 * a.ldb * 2;      // the next tile's
+    const __amdgpu_buffer_rsrc_t ra_c = rsrc_a(m0), rb_c = rsrc_b(n0);       // this tile's rows of A / B
+    const __amdgpu_buffer_rsrc_t ra_n = rsrc_a(nm0), rb_n = rsrc_b(nn0);     // the next tile's (built at the use instead, the softmax form spills VGPRs)
     for (int t = 0; t < nt; t += 2) {
       // k-step t in buffer 0 while k-step t+1 loads into buffer 1
-      compute(0, ca + (t + 1) * BK * 2, cb + (t + 1) * BK * 2);
+      compute(0, ra_c, rb_c, (t + 1) * BK * 2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // t = 0 of a later tile: also the previous tile's output stores
       __syncthreads();
       if (a.dbg && t == 0) c_first += __builtin_readcyclecounter() - s0;
       // k-step t+1 in buffer 1 while k-step t+2 -- or the NEXT tile's k-step 0 -- loads into buffer 0
       const bool last = t + 2 >= nt;
-      compute(1, last ? na : ca + (t + 2) * BK * 2, last ? nb : cb + (t + 2) * BK * 2);
+      compute(1, last ? ra_n : ra_c, last ? rb_n : rb_c, last ? 0 : (t + 2) * BK * 2);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
@@ -1222,6 +1232,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (LN) {
+    // every wave's in-flight pieces have landed before anybody's partial sums overwrite the stage buffers (when (K / 32) % 3 == 2 the
+    // last k-step's redundant reload targets buffer 0, where `red` lives: K = 256, 1024)
+    __syncthreads();
     epilogue_ln<RT>(a, acc, smem, lane, wm, wn, m0);     // (the last k-step's barrier: every wave is done with the stage buffers)
   } else {   // the register epilogue works on 64-column halves of the wave tile
     f32x4 lo[RT][4], hi[RT][4];
@@ -1455,7 +1468,10 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     // persistent 256x256 tiles: short-K products with at least two tiles per CU (see gemm_nt8p_kernel)
     const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
     const bool can = nsplit == 1 && a.k_per_split == a.K && a.K % 128 == 0 && (int64_t)a.M * a.lda < (1 << 30) && (int64_t)a.N * a.ldb < (1 << 30);
-    if (can && ((g_opt_nt8p == 1 && a.K <= g_opt_nt8p_max_k && t8m * t8n >= 2 * num_cus()) || g_opt_nt8p == 2)) {
+    const bool auto_ok = a.K <= g_opt_nt8p_max_k && t8m * t8n >= 2 * num_cus();
+    // 3 = auto for the softmax head only (tests: its register epilogue adds the row-sum partials in its own fixed order, so a
+    // step that is to be compared bit for bit with the 128x128 kernels keeps the head where it is)
+    if (can && ((g_opt_nt8p == 1 && auto_ok) || g_opt_nt8p == 2 || (g_opt_nt8p == 3 && (FLAGS & GEMM_SOFTMAX) && auto_ok))) {
       static bool attr8p = false;
       if (!attr8p) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8p = true; }
       GemmArgs b = a;

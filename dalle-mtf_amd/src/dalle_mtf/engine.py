@@ -132,8 +132,10 @@ class DalleEngine:
         # The exchange's RCCL channels run beside the BACKWARD: there the persistent kernels leave CUs for them (a block of a
         # one-block-per-CU kernel whose CU an intruder holds starts when the others have finished: the launch takes twice as long --
         # measured with the token sort as the intruder).  16 CUs cost 3.7 % of a single-GPU step when applied to
-        # the whole step, so the option is set for the backward only; 0 = off.  Unmeasured on a multi-GPU node.
-        self.dp_reserve_cus = int(os.environ.get("DALLE_DP_RESERVE_CUS", "16")) if world_size > 1 else 0
+        # the whole step, so the option is set for the backward only; 0 = off.  Unmeasured on a multi-GPU node, hence OFF by
+        # default (it also hands the full-row products back to the 128x128 kernel): hparams["dp_reserve_cus"], DALLE_DP_RESERVE_CUS
+        # or bench.py --reserve-cus select it for the first multi-GPU A/B.
+        self.dp_reserve_cus = int(self.hp.get("dp_reserve_cus", os.environ.get("DALLE_DP_RESERVE_CUS", "0"))) if world_size > 1 else 0
 
     # ------------------------------------------------------------------ parameter access
     def view(self, buf, name):
@@ -587,6 +589,16 @@ class DalleEngine:
         """Gradients of the last forward(need_grad=True) into the flat fp32 buffer.  With world_size > 1 every finished
         prefix of the buffer is handed to the exchange (src/dp.py: SUM all-reduce in <= 64 MB pieces on the side stream) --
         the explicit form of mtf's implicit all-reduce over the `data` mesh axis (src/model_fns.py:81-82,189)."""
+        reserve = self.dp_reserve_cus if allreduce else 0
+        if not reserve:
+            return self._backward(allreduce)
+        dh.set_option("reserve_cus", reserve)     # (read at launch time: applies to the launches enqueued inside the try)
+        try:
+            return self._backward(allreduce)
+        finally:                                  # the option is process-global: never leave it set for later forwards / other engines
+            dh.set_option("reserve_cus", 0)
+
+    def _backward(self, allreduce):
         M, d, L, B, H, S, Vp = self.M, self.d, self.L, self.B, self.H, self.S, self.Vp
         ws = self.ws
         E = self.z   # unnormalised dlogits: dlogits[m, :] = rowscale[m] * E[m, :]
@@ -600,8 +612,6 @@ class DalleEngine:
 
         if self._sort_done is None:
             self._launch_sort()
-        if self.dp_reserve_cus and allreduce:
-            dh.set_option("reserve_cus", self.dp_reserve_cus)     # (read at launch time: applies to the launches enqueued from here on)
         # head: dW = (rowscale * xnf)^T E, dbias = rowscale^T E, dxn = rowscale * (E W^T)
         self._wgrad(self.xs, d, E, Vp, self._gv("to_logits/linear_out/kernel"), M, d, Vp,
                     dbias=self._gv("to_logits/linear_out/bias"), bias_weights=self.rowscale_bf)
@@ -676,8 +686,6 @@ class DalleEngine:
                      B, S, d, self.V, self.embed_ws)
         flush_ln()
         ready(rp[L + 1])
-        if self.dp_reserve_cus and allreduce:
-            dh.set_option("reserve_cus", 0)
 
     def wait_grads(self):
         self.reducer.finish()

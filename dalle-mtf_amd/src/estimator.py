@@ -60,12 +60,15 @@ class CheckpointSaverHook:
             err = interrupt = e
         if err is None:
             # pruning old checkpoints happens after the new one is committed: a failure here is a warning, not a failed save
+            # (any failure: the other ranks wait in _sync() below and must be reached -- a stray "model.ckpt-best.pt" in the
+            # directory is skipped by the match, anything else that goes wrong here is reported and ignored)
             try:
-                ck = sorted(glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt")),
-                            key=lambda p: int(re.search(r"-(\d+)\.pt$", p).group(1)))
+                ck = [(int(m.group(1)), p) for p in glob.glob(os.path.join(self.model_dir, "model.ckpt-*.pt"))
+                      for m in [re.search(r"model\.ckpt-(\d+)\.pt$", p)] if m]
+                ck = [p for _, p in sorted(ck)]
                 for old in ck[:-self.max_to_keep] if self.max_to_keep else []:
                     os.remove(old)
-            except OSError as e:
+            except Exception as e:
                 import warnings
                 warnings.warn(f"checkpoint retention: could not remove an old checkpoint ({e!r}); the new one is saved")
         try:

