@@ -46,6 +46,7 @@ static int g_opt_ntr_prefetch = 0; // [r05-prep, not yet run on a GPU] full-row 
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
 static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
                                  // tiles per CU), 2 whenever the shape allows it (tests, tools/kbench.py)
+static int g_opt_relu_bits = 1;   // FFN ReLU mask as one bit per element (dmi_gemm_nt_relu_bits / _mask_bits) where the persistent kernel runs: 0 never, 1 auto
 static int g_opt_nt8p_max_k = 1024;   // auto mode: K above this keeps the one-tile-per-block kernels (the main loop then dominates a tile)
 static int g_opt_nt4_lds = 49152;   // dynamic LDS requested by the 256x128 NT kernel: 49152 = what it uses (3 blocks / CU); 65536 / 98304
                                     // cap the residency at 2 / 1 blocks per CU (tools/phases.py: a block's phases without co-resident blocks)
@@ -63,6 +64,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "cstream_min_mb")) return g_opt_cstream_min_mb;
   if (!strcmp(name, "cstream_nt_min_mb")) return g_opt_cstream_nt_min_mb;
   if (!strcmp(name, "nt8p_max_k")) return g_opt_nt8p_max_k;
+  if (!strcmp(name, "relu_bits")) return g_opt_relu_bits;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
@@ -83,6 +85,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "cstream_min_mb")) { g_opt_cstream_min_mb = value; return 0; }
   if (!strcmp(name, "cstream_nt_min_mb")) { g_opt_cstream_nt_min_mb = value; return 0; }
   if (!strcmp(name, "nt8p_max_k")) { g_opt_nt8p_max_k = value; return 0; }
+  if (!strcmp(name, "relu_bits")) { g_opt_relu_bits = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
@@ -106,6 +109,7 @@ struct GemmArgs {
   const bf16_t* bias;
   const bf16_t* residual;
   const bf16_t* relu_src;
+  unsigned short* relu_bits;   // GEMM_RELU_BITS: written; GEMM_MASK_BITS: read -- [N / 64][M][4] 16-bit words, see epilogue_regs
   const float* rowscale;   // DMI_GEMM_ROWSCALE: fp32 [M], C[m, :] *= rowscale[m]
   const float* rowshift;   // GEMM_SOFTMAX: nullable fp32 [M], C[m, n] = exp(acc + bias - rowshift[m])  (NULL: no shift)
   float* rowsum_part;      // GEMM_SOFTMAX: fp32 [ceil(N/64)][M] partial row sums of the fp32 exponentials
@@ -126,6 +130,8 @@ struct GemmArgs {
   int ln_ldy;
 };
 #define GEMM_SOFTMAX 64   // internal epilogue flag of dmi_gemm_nt_softmax (not part of the public flag set)
+#define GEMM_RELU_BITS 128   // internal: with DMI_GEMM_RELU, also emit one bit per output (> 0) -- dmi_gemm_nt_relu_bits
+#define GEMM_MASK_BITS 256   // internal: C *= bit, the bits written by GEMM_RELU_BITS -- dmi_gemm_nt_mask_bits
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid & 7, idx = bid >> 3, q = nwg >> 3, r = nwg & 7;
@@ -238,6 +244,36 @@ __device__ __forceinline__ unsigned relu_mask2(unsigned v, unsigned src) {
   return v & (lo | hi);
 }
 
+// ---- the ReLU mask as one BIT per element (round 5) ----------------------------------------------------------------
+// The FFN-2 input gradient dh = (dx . W2^T) * (h > 0) read the whole bf16 h (168 MB per launch at dalle_example, as much as it
+// writes) only for its sign: 129 us against 87 us for the same product without the mask (FFN-1 forward), and the difference is
+// that second stream (168 MB / 43 us = 3.9 TB/s).  The forward product now emits the bits from its register epilogue and the
+// gradient product reads 2 bytes per 16 outputs.  Layout = the register epilogue's own: after the row swap lane (c, g) of a wave
+// holds columns nst + {0..7} ("lo") and nst + 32 + {0..7} ("hi") of row m of the wave's 64-column group; its 16-bit word
+// (bit k: lo element k, bit 8 + k: hi element k) lives at bits[((col_group * M) + m) * 4 + g] -- a store / load instruction of a
+// wave moves 16 rows x 8 bytes = 128 contiguous bytes.  Producer and consumer are both epilogue_regs, so the layout is private
+// to it (N % 64 == 0).  (Round 2 built the ballot form in the LDS epilogue: issue-bound there, slower.)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// the 8 outputs of a 16-B piece (packed bf16, all >= +0 after the ReLU) -> 8 bits, bit k = element k > 0
+__device__ __forceinline__ unsigned relu_bits8(const u32x4 w) {
+  unsigned x = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    // h in [0x0001, 0x7fff] <=> bit 15 of h + 0x7fff (a packed 16-bit add: no carry between the halves)
+    const unsigned wd = w[d];     // (through a scalar: __builtin_bit_cast applied to the subscript itself reads element 0 for every d)
+    const u16x2 t = __builtin_bit_cast(u16x2, wd) + u16x2{0x7fff, 0x7fff};
+    const unsigned m = __builtin_bit_cast(unsigned, t) & 0x80008000u;
+    x |= m >> (15 - 2 * d);      // low half -> bit 2 d, high half -> bit 16 + 2 d
+  }
+  return (x & 0x55u) | ((x >> 15) & 0xaau);
+}
+// keep the bf16 halves of dword d of a piece whose bits (2 d, 2 d + 1) of `mk` (shifted so that the piece starts at bit 0) are set
+template <int B0>
+__device__ __forceinline__ unsigned keep_bits2(unsigned v, unsigned mk) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_sbfe((int)mk, B0, 1), hi = (unsigned)__builtin_amdgcn_sbfe((int)mk, B0 + 1, 1);
+  return v & ((lo & 0x0000ffffu) | (hi & 0xffff0000u));
+}
+
 template <int FLAGS, int NT>     // NT = 16-row tiles of the wave tile (its width is 64 columns)
 __device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&acc)[NT][4], int lane, int mrow0, int ncol0) {
   const int c16 = lane & 15, g16 = lane >> 4;
@@ -267,6 +303,14 @@ __device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&a
   // pieces 0, 2, 1, 3 (+4): each store instruction writes 64 contiguous bytes per row
   const int nst = ncol0 + 8 * (((g16 & 1) << 1) | (g16 >> 1));
   const bool ok0 = nst < a.N, ok1 = nst + 32 < a.N;
+  unsigned mbits[NT];
+  if constexpr (FLAGS & GEMM_MASK_BITS) {   // all row tiles' words up front: NT independent 2-byte loads
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int m = mrow0 + 16 * t + c16;
+      mbits[t] = (m < a.M && ok0) ? (unsigned)a.relu_bits[((int64_t)(ncol0 >> 6) * a.M + m) * 4 + g16] : 0u;
+    }
+  }
   u32x4 nsrc0 = {0u, 0u, 0u, 0u}, nsrc1 = {0u, 0u, 0u, 0u};
   if constexpr (FLAGS & DMI_GEMM_RELU_MASK) {
     const int m = mrow0 + c16;
@@ -344,8 +388,16 @@ __device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&a
 #pragma unroll
       for (int e = 0; e < 4; ++e) { lo[e] = relu_mask2(lo[e], src0[e]); hi[e] = relu_mask2(hi[e], src1[e]); }
     }
+    if constexpr (FLAGS & GEMM_MASK_BITS) {
+      const unsigned mk = mbits[t];
+      lo[0] = keep_bits2<0>(lo[0], mk); lo[1] = keep_bits2<2>(lo[1], mk); lo[2] = keep_bits2<4>(lo[2], mk); lo[3] = keep_bits2<6>(lo[3], mk);
+      hi[0] = keep_bits2<8>(hi[0], mk); hi[1] = keep_bits2<10>(hi[1], mk); hi[2] = keep_bits2<12>(hi[2], mk); hi[3] = keep_bits2<14>(hi[3], mk);
+    }
     if (mok && ok0) store_c16(a, rc, off, lo);
     if (mok && ok1) store_c16(a, rc, off + 32, hi);
+    if constexpr (FLAGS & GEMM_RELU_BITS) {
+      if (mok && ok0) a.relu_bits[((int64_t)(ncol0 >> 6) * a.M + m) * 4 + g16] = (unsigned short)(relu_bits8(lo) | (relu_bits8(hi) << 8));
+    }
     if constexpr (FLAGS & GEMM_SOFTMAX) {
       // the four lane groups of a row hold its 64 columns: two fixed-order exchanges (deterministic), group 0 writes the
       // row's partial to slot ncol0 / 64 of the [slots][M] table
@@ -1438,6 +1490,25 @@ static int persistent_grid() {    // blocks of a one-per-CU persistent kernel: a
   return n < 8 ? 8 : n;
 }
 
+// persistent 256x256 tiles (gemm_nt8p_kernel): what a launch needs, and whether the automatic choice takes it (short K, at
+// least two tiles per CU)
+static bool nt8p_can(const GemmArgs& a) {
+  return a.k_per_split == a.K && a.K % 128 == 0 && (int64_t)a.M * a.lda < (1 << 30) && (int64_t)a.N * a.ldb < (1 << 30);
+}
+static bool nt8p_auto(int M, int N, int K) {
+  return K <= g_opt_nt8p_max_k && ((M + BM8 - 1) / BM8) * ((N + BN8 - 1) / BN8) >= 2 * num_cus();
+}
+template <int FLAGS>
+static int launch_nt8p(const GemmArgs& a, hipStream_t st) {
+  static bool attr8p = false;
+  if (!attr8p) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8p = true; }
+  GemmArgs b = a;
+  b.tiles_m = (a.M + BM8 - 1) / BM8; b.tiles_n = (a.N + BN8 - 1) / BN8;
+  gemm_nt8p_kernel<FLAGS><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
+  DMI_CHECK_LAUNCH("gemm_nt8p");
+  return DMI_OK;
+}
+
 template <int FLAGS>
 static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   const dim3 grid(a.tiles_m * a.tiles_n, nsplit), blk(256);
@@ -1466,20 +1537,12 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
   }
   if constexpr (epi_regs_ok<FLAGS>) {
     // persistent 256x256 tiles: short-K products with at least two tiles per CU (see gemm_nt8p_kernel)
-    const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
-    const bool can = nsplit == 1 && a.k_per_split == a.K && a.K % 128 == 0 && (int64_t)a.M * a.lda < (1 << 30) && (int64_t)a.N * a.ldb < (1 << 30);
-    const bool auto_ok = a.K <= g_opt_nt8p_max_k && t8m * t8n >= 2 * num_cus();
+    const bool can = nsplit == 1 && nt8p_can(a);
+    const bool auto_ok = nt8p_auto(a.M, a.N, a.K);
     // 3 = auto for the softmax head only (tests: its register epilogue adds the row-sum partials in its own fixed order, so a
     // step that is to be compared bit for bit with the 128x128 kernels keeps the head where it is)
-    if (can && ((g_opt_nt8p == 1 && auto_ok) || g_opt_nt8p == 2 || (g_opt_nt8p == 3 && (FLAGS & GEMM_SOFTMAX) && auto_ok))) {
-      static bool attr8p = false;
-      if (!attr8p) { (void)hipFuncSetAttribute((const void*)gemm_nt8p_kernel<FLAGS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr8p = true; }
-      GemmArgs b = a;
-      b.tiles_m = t8m; b.tiles_n = t8n;
-      gemm_nt8p_kernel<FLAGS><<<dim3(persistent_grid()), dim3(512), 131072, st>>>(b);
-      DMI_CHECK_LAUNCH("gemm_nt8p");
-      return DMI_OK;
-    }
+    if (can && ((g_opt_nt8p == 1 && auto_ok) || g_opt_nt8p == 2 || (g_opt_nt8p == 3 && (FLAGS & GEMM_SOFTMAX) && auto_ok)))
+      return launch_nt8p<FLAGS>(a, st);
   }
   {
     const int t8m = (a.M + BM8 - 1) / BM8, t8n = (a.N + BN8 - 1) / BN8;
@@ -1524,7 +1587,7 @@ static int check_nt(const void* A, int lda, const void* B, int ldb, const void* 
 }
 
 static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t* Bt, int ldb, void* C, int ldc, int M, int N, int K) {
-  a.A = A; a.B = Bt; a.C = C; a.bias = nullptr; a.residual = nullptr; a.relu_src = nullptr;
+  a.A = A; a.B = Bt; a.C = C; a.bias = nullptr; a.residual = nullptr; a.relu_src = nullptr; a.relu_bits = nullptr;
   a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
@@ -1565,6 +1628,44 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
       dmi_set_error("gemm_nt: unsupported flag combination %d", flags);
       return DMI_ERR_UNSUPPORTED;
   }
+}
+
+// ---- the ReLU mask as bits (see relu_bits8 above): FFN-1 forward emits them, the FFN-2 input gradient applies them ----
+// reference: h = mtf.relu(dense(x)) (src/dalle_mtf/models.py:320-321) and its backward dh = dh * (h > 0).
+extern "C" int64_t dmi_relu_bits_bytes(int M, int N) { return (int64_t)((N + 63) / 64) * M * 8; }
+// 1 if the automatic dispatch runs these shapes on the kernel that has the bit forms (the engine then uses them; otherwise it keeps
+// dmi_gemm_nt with DMI_GEMM_RELU / DMI_GEMM_RELU_MASK, which every tile size serves)
+extern "C" int dmi_relu_bits_auto(int M, int N, int K) {
+  return (g_opt_relu_bits && g_opt_nt8p == 1 && N % 64 == 0 && K % 128 == 0 && nt8p_auto(M, N, K)) ? 1 : 0;
+}
+static int check_bits(const char* who, const GemmArgs& a, const void* bits) {
+  DMI_REQUIRE(bits && ((uintptr_t)bits & 7) == 0, "%s: null / unaligned bit buffer", who);
+  if (a.N % 64 != 0 || !nt8p_can(a)) {
+    dmi_set_error("%s: needs N %% 64 == 0, K %% 128 == 0 and operands below 2 GiB (M=%d N=%d K=%d)", who, a.M, a.N, a.K);
+    return DMI_ERR_UNSUPPORTED;
+  }
+  return DMI_OK;
+}
+extern "C" int dmi_gemm_nt_relu_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
+                                     const uint16_t* bias, void* bits, void* stream) {
+  int rc = check_nt(A, lda, Bt, ldb, C, ldc, M, N, K);
+  if (rc) return rc;
+  DMI_REQUIRE(bias, "gemm_nt_relu_bits: null bias");
+  GemmArgs a;
+  fill_nt_args(a, A, lda, Bt, ldb, C, ldc, M, N, K);
+  a.bias = bias; a.relu_bits = (unsigned short*)bits; a.dbg = g_dbg_buf;
+  if ((rc = check_bits("gemm_nt_relu_bits", a, bits))) return rc;
+  return launch_nt8p<DMI_GEMM_BIAS | DMI_GEMM_RELU | GEMM_RELU_BITS>(a, (hipStream_t)stream);
+}
+extern "C" int dmi_gemm_nt_mask_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
+                                     const void* bits, void* stream) {
+  int rc = check_nt(A, lda, Bt, ldb, C, ldc, M, N, K);
+  if (rc) return rc;
+  GemmArgs a;
+  fill_nt_args(a, A, lda, Bt, ldb, C, ldc, M, N, K);
+  a.relu_bits = (unsigned short*)bits; a.dbg = g_dbg_buf;
+  if ((rc = check_bits("gemm_nt_mask_bits", a, bits))) return rc;
+  return launch_nt8p<GEMM_MASK_BITS>(a, (hipStream_t)stream);
 }
 
 // Product with N = 512 outputs + bias + residual, and the LayerNorm of the result in the same pass (full-row tiles, see
@@ -2616,7 +2717,7 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.A = x; a.B = Wt; a.C = out; a.bias = bias; a.residual = residual; a.relu_src = relu_src;
   a.M = (int)Ml; a.N = N; a.K = ntaps * C; a.lda = (int)xbytes /* descriptor size */; a.ldb = ldw; a.ldc = ldc;
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
-  a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr;
+  a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr; a.relu_bits = nullptr;
   a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr; a.cpol = 0;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
   ConvGeom g;

@@ -89,6 +89,10 @@ def _declare(L):
         "dmi_ln_gemm_nt": (I, [P, I, P, P, F, P, I, P, I, I, I, I, I, P, P]),
         "dmi_logits_f32": (I, [P, I, P, P, I, I, P]),
         "dmi_gemm_nt_ln": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, F, P, I, P, P, P]),
+        "dmi_relu_bits_bytes": (L64, [I, I]),
+        "dmi_relu_bits_auto": (I, [I, I, I]),
+        "dmi_gemm_nt_relu_bits": (I, [P, I, P, I, P, I, I, I, I, P, P, P]),
+        "dmi_gemm_nt_mask_bits": (I, [P, I, P, I, P, I, I, I, I, P, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
         "dmi_sumsq": (I, [P, L64, P, P, P]),
         "dmi_adam_step": (I, [P, P, P, P, P, L64, P, F, F, F, F, F, F, F, P, P]),
@@ -223,6 +227,29 @@ def gemm_nt_ln(A, lda, Bt, ldb, C, ldc, M, N, K, gamma, beta, Y, ldy, mean, rstd
     assert mean.dtype == torch.float32 and rstd.dtype == torch.float32 and mean.numel() >= M and rstd.numel() >= M
     _check(lib().dmi_gemm_nt_ln(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, _p(bias), _p(residual), _p(gamma), _p(beta), float(eps),
                                 _p(Y), ldy, _p(mean), _p(rstd), _stream()), "gemm_nt_ln")
+
+
+def relu_bits_bytes(M, N):
+    return int(lib().dmi_relu_bits_bytes(M, N))
+
+
+def relu_bits_auto(M, N, K):
+    """True where the library's dispatch runs [M, N, K] on the kernel that has the bit forms of the ReLU mask"""
+    return bool(lib().dmi_relu_bits_auto(M, N, K))
+
+
+def gemm_nt_relu_bits(A, lda, Bt, ldb, C, ldc, M, N, K, bias, bits):
+    """C = bf16(relu(A . Bt^T + bias)); bits (uint8, relu_bits_bytes(M, N)) = one bit per output, C > 0"""
+    _dev(A, Bt, C, bias, bits)
+    assert bits.dtype == torch.uint8 and bits.numel() >= relu_bits_bytes(M, N)
+    _check(lib().dmi_gemm_nt_relu_bits(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, _p(bias), _p(bits), _stream()), "gemm_nt_relu_bits")
+
+
+def gemm_nt_mask_bits(A, lda, Bt, ldb, C, ldc, M, N, K, bits):
+    """C = bf16(A . Bt^T) where the bit written by gemm_nt_relu_bits is set, 0 elsewhere (= gemm_nt with GEMM_RELU_MASK, relu_src = h)"""
+    _dev(A, Bt, C, bits)
+    assert bits.dtype == torch.uint8 and bits.numel() >= relu_bits_bytes(M, N)
+    _check(lib().dmi_gemm_nt_mask_bits(_p(A), lda, _p(Bt), ldb, _p(C), ldc, M, N, K, _p(bits), _stream()), "gemm_nt_mask_bits")
 
 
 def ln_gemm_nt(X, ldx, gamma, beta, Bt, ldb, C, ldc, M, N, K, flags=0, bias=None, eps=1e-5):

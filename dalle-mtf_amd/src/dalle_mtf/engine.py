@@ -250,6 +250,11 @@ class DalleEngine:
         self.x1 = per_layer(lambda: torch.empty(M, d, **b16))
         self.xn2 = per_layer(lambda: torch.empty(M, d, **b16))
         self.h = per_layer(lambda: torch.empty(M, 4 * d, **b16))
+        # [r05] the ReLU mask of the FFN as bits: FFN-1's epilogue emits them, the FFN-2 input gradient reads M * 4d / 8 bytes instead
+        # of the whole h (168 MB per layer at dalle_example) -- where the library runs both products on the kernel that has the bit
+        # forms (dmi_relu_bits_auto); bit-identical to the relu_src form (tested)
+        self.use_relu_bits = bool(self.hp.get("relu_bits", True)) and dh.relu_bits_auto(M, 4 * d, d)
+        self.hbits = per_layer(lambda: torch.empty(dh.relu_bits_bytes(M, 4 * d), dtype=torch.uint8, device=self.dev)) if self.use_relu_bits else None
         self.stats = per_layer(lambda: [torch.empty(M, **f32) for _ in range(4)])  # mean1, rstd1, mean2, rstd2
         self.xnf = torch.empty(M, d, **b16)
         self.statf = [torch.empty(M, **f32) for _ in range(2)]
@@ -381,8 +386,12 @@ class DalleEngine:
             dh.gemm_nt(self.o[l], d, self.tview(p + "attn/o"), d, self.x1[l], d, M, d, d, dh.GEMM_BIAS | dh.GEMM_RESIDUAL,
                        bias=self._w(p + "attn/compute_output_bias/o_b"), residual=x)
             dh.layernorm_fwd(self.x1[l], self._w(p + "norm_2/g"), self._w(p + "norm_2/b"), self.xn2[l], st[2], st[3], M, d)
-        dh.gemm_nt(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
-                   dh.GEMM_BIAS | dh.GEMM_RELU, bias=self._w(p + "mlp/mlp_linear_1/bias"))
+        if self.use_relu_bits:
+            dh.gemm_nt_relu_bits(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
+                                 self._w(p + "mlp/mlp_linear_1/bias"), self.hbits[l])
+        else:
+            dh.gemm_nt(self.xn2[l], d, self.tview(p + "mlp/mlp_linear_1/kernel"), d, self.h[l], 4 * d, M, 4 * d, d,
+                       dh.GEMM_BIAS | dh.GEMM_RELU, bias=self._w(p + "mlp/mlp_linear_1/bias"))
         if rerun:   # the re-run stops here: X[l+1] is already stored
             return
         W2, b2 = self.tview(p + "mlp/mlp_linear_2/kernel"), self._w(p + "mlp/mlp_linear_2/bias")
@@ -659,8 +668,11 @@ class DalleEngine:
             # FFN
             self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
                         dbias=self._gv(p + "mlp/mlp_linear_2/bias"), slot=0)
-            dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
-                       relu_src=self.h[l])
+            if self.use_relu_bits:
+                dh.gemm_nt_mask_bits(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, self.hbits[l])
+            else:
+                dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
+                           relu_src=self.h[l])
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
                         dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
             dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)

@@ -172,6 +172,19 @@ int64_t dmi_gemm_nt_softmax_partials(int N);
 int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
                    const uint16_t* bias, const uint16_t* residual, const uint16_t* gamma, const uint16_t* beta, float eps,
                    uint16_t* Y, int ldy, float* mean, float* rstd, void* stream);
+/* The FFN's ReLU mask as one bit per element (reference src/dalle_mtf/models.py:320-321: h = mtf.relu(dense(x)), and its backward
+ * dh = (dx . W2^T) * (h > 0)):  dmi_gemm_nt_relu_bits: C = bf16(relu(A . Bt^T + bias)) and bits = (C > 0), one bit per output;
+ * dmi_gemm_nt_mask_bits: C = bf16(A . Bt^T) * bit -- what dmi_gemm_nt(DMI_GEMM_RELU_MASK, relu_src = h) computes, bit for bit,
+ * from M*N/8 bytes instead of the 2*M*N bytes of h.  `bits` is an opaque buffer of dmi_relu_bits_bytes(M, N) bytes (8-byte
+ * aligned; the layout is private to the two calls).  N % 64 == 0, K % 128 == 0, operands below 2 GiB: DMI_ERR_UNSUPPORTED
+ * otherwise.  dmi_relu_bits_auto: 1 where the library's own dispatch would run these shapes on the kernel that has the bit
+ * forms (callers keep dmi_gemm_nt elsewhere). */
+int64_t dmi_relu_bits_bytes(int M, int N);
+int dmi_relu_bits_auto(int M, int N, int K);
+int dmi_gemm_nt_relu_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
+                          const uint16_t* bias, void* bits, void* stream);
+int dmi_gemm_nt_mask_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
+                          const void* bits, void* stream);
 int dmi_gemm_nt_softmax(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                         const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K, void* stream);
 int dmi_softmax_finish(const float* rowsum_part, int nparts, const float* label_logit, const float* rowshift,

@@ -151,7 +151,7 @@ def test_attention_kernels_at_headline_shape(B, H, S):
 
 
 def test_engine_vs_the_references_own_headline_digest():
-    """[r05-prep, not yet run on a GPU] the engine against tests/golden/ref_callsite_dalle_headline.npz directly: what the reference's
+    """[r05: run, bounds = measured + 25 %] the engine against tests/golden/ref_callsite_dalle_headline.npz directly: what the reference's
     own files (src/dalle_mtf/*.py over the shims of oracle/refshim) compute at the exact dalle_example architecture, B = 1 -- loss,
     the norm of every gradient tensor and the small gradients, with the bounds of the oracle comparison above (the oracle equals
     that digest to 1e-6, tests/test_reference_callsite.py)."""
@@ -177,10 +177,10 @@ def test_engine_vs_the_references_own_headline_digest():
     norms = np.array([np.linalg.norm(gh[k].astype(np.float64)) for k in weights])
     rel = np.abs(norms - z["grad_norms"]) / (z["grad_norms"] + 1e-30)
     print("worst gradient-norm deviation vs the reference digest:", float(rel.max()), list(weights)[int(rel.argmax())])
-    assert rel.max() < 0.03
+    assert rel.max() < 0.0067            # measured 0.0053 (layer_3/attn/q)
     worst = max((float(np.linalg.norm(gh[k[5:]] - z[k]) / (np.linalg.norm(z[k]) + 1e-30)), k) for k in z.files if k.startswith("grad:"))
     print("worst small gradient vs the reference digest:", worst)
-    assert worst[0] < 0.06
+    assert worst[0] < 0.032             # measured 0.0255 (layer_5/norm_2/g)
     # per-position loss (reference: loss_batch of src/dalle_mtf/models.py:348-352, before the mean)
     lr_ = eng.loss_rows.float().cpu().numpy().reshape(1, -1)
     dl = np.abs(lr_ - z["loss_batch"])
@@ -203,8 +203,10 @@ def test_engine_vs_the_references_own_headline_digest():
 
 
 # bounds of test_engine_vs_the_references_own_headline_digest: measured on an MI355X + 25 % (profiles/r05_parity_ref_digest.log)
-PERPOS_LOSS_ABS, PERPOS_LOSS_MEAN_ABS = 0.08, 0.01
-LOGIT_ROWS_REL, LOGIT_MAX_ABS, ARGMAX_AGREE = 0.012, 0.08, 0.97
+# measured: per-position loss max 0.0132 / mean 0.0033 abs; logit rows rel-L2 0.0091; max-logit 0.0185 abs; arg-max agreement 0.9969
+# (4 of 1280 positions, all exact bf16 ties in the engine's logits: top-gap 0.0); gradient norms 0.0053; small gradients 0.0255
+PERPOS_LOSS_ABS, PERPOS_LOSS_MEAN_ABS = 0.0165, 0.0042
+LOGIT_ROWS_REL, LOGIT_MAX_ABS, ARGMAX_AGREE = 0.0114, 0.0232, 0.99
 
 
 def _headline_engine(B, seed=1234):
@@ -219,8 +221,9 @@ def _headline_engine(B, seed=1234):
 def test_production_dispatch_at_the_benchmark_batch_is_bit_identical_to_the_128x128_kernels():
     """The step bench.py times (dalle_example, B = 32, S = 1280: M = 40 960) runs its layer products on gemm_ntr / gemm_nt8p /
     gemm_nt8, kernels that launch_nt only selects from M >= 20 480 or >= 512 tiles on -- the oracle-checked steps (B <= 2) run
-    gemm_nt2 everywhere.  Every NT kernel claims the 128x128 kernel's bits (same k order); here the COMPOSED step is held to it:
-    production dispatch vs ntr = nt8p = nt8 = nt4 = 0 -- loss, every gradient and the parameters after clip + Adam, bit for bit.
+    gemm_nt2 for every layer product.  Every NT kernel claims the 128x128 kernel's bits (same k order); here the COMPOSED step is
+    held to it: production dispatch vs ntr = nt8 = nt4 = 0 and nt8p for the softmax head only (which the B <= 2 steps also run on
+    nt8p) -- loss, per-position losses, every gradient and the parameters after clip + Adam, bit for bit.
     And the first two sequences' per-position losses equal those of a B = 2 engine on the same rows (whose gradients
     test_dalle_example_shape_step_vs_fp32_oracle compares with the oracle): the link from the benchmarked dispatch to the oracle."""
     import dalle_hip as dh
@@ -233,8 +236,8 @@ def test_production_dispatch_at_the_benchmark_batch_is_bit_identical_to_the_128x
     out = []
     try:
         for plain in (False, True):
-            for n in names:
-                dh.set_option(n, 0 if plain else saved[n])
+            for n in names:   # (nt8p = 3: the softmax head alone stays on the persistent kernel -- its register epilogue adds the row-sum
+                dh.set_option(n, saved[n] if not plain else (3 if n == "nt8p" else 0))   # partials in its own fixed order, by design)
             eng = _headline_engine(B)
             loss = float(eng.train_step(tokens).item())
             torch.cuda.synchronize()

@@ -392,6 +392,33 @@ def test_gemm_nt8p_persistent_tile_256x256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "persistent 256x256 and 128x128 tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2100, 576, 384), (515, 1088, 128), (40960, 2048, 512)])
+def test_relu_mask_as_bits_is_bit_identical(M, N, K):
+    """[r05] dmi_gemm_nt_relu_bits / dmi_gemm_nt_mask_bits (FFN-1 forward emits one bit per output, the FFN-2 input gradient applies
+    them): h equals dmi_gemm_nt(BIAS | RELU), the masked product equals dmi_gemm_nt(RELU_MASK, relu_src = h) -- bit for bit, incl.
+    M / N tails, several tiles per block and fewer tiles than blocks; outputs that are exactly zero are masked."""
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    bias = rnd(N, seed=3)
+    dY, W2 = rnd(M, K, seed=4), rnd(N, K, scale=0.2, seed=5)      # the gradient product has its own operands, the same [M, N] output
+    Ad, Bd, bd, dYd, W2d = A.to(DEV), Bt.to(DEV), bias.to(DEV), dY.to(DEV), W2.to(DEV)
+    h = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    bits = torch.full((dh.relu_bits_bytes(M, N),), 0xAA, dtype=torch.uint8, device=DEV)
+    dh.gemm_nt_relu_bits(Ad, K, Bd, K, h, N, M, N, K, bd, bits)
+    h2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(Ad, K, Bd, K, h2, N, M, N, K, dh.GEMM_BIAS | dh.GEMM_RELU, bias=bd)
+    assert torch.equal(h, h2)
+    frac = float((h > 0).float().mean())
+    assert 0.3 < frac < 0.7, frac
+    g1 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt_mask_bits(dYd, K, W2d, K, g1, N, M, N, K, bits)
+    g2 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(dYd, K, W2d, K, g2, N, M, N, K, dh.GEMM_RELU_MASK, relu_src=h)
+    assert torch.equal(g1, g2)
+    assert float((g1[h <= 0] != 0).float().sum()) == 0
+    with pytest.raises(dh.DalleHipError):      # widths that are no multiple of 64: refused, the caller keeps the relu_src form
+        dh.gemm_nt_relu_bits(Ad, K, Bd, K, h, N, M, N - 8, K, bd, bits)
+
+
 @pytest.mark.parametrize("M,K,flags", [(160, 64, 0), (1000, 192, 5), (2100, 512, 5), (40960, 1536, 0), (5000, 2048, 1), (333, 256, 4)])
 def test_gemm_ntr_full_row_tiles(M, K, flags):
     """[r04] full-row 160x512 tiles (forced; N = 512): k-step counts of every residue mod 3 (three-buffer ring), an M tail,
