@@ -2196,6 +2196,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(TnArgs a) {
           a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
 }
 
+// ---- several weight gradients in ONE launch (round 5) ------------------------------------------------------------------------
+// The 512 x 512 out-projection gradient has 16 tiles: alone it needs 32 row splits to fill the 512 block slots (20 k-steps per
+// block: prologue / epilogue-bound, 458 TFLOP/s) and the 512 x 1536 QKV gradient (48 tiles) fills 480 of them.  Together they are
+// 64 tiles x 8 splits = 512 blocks of 80 k-steps -- the shape of an FFN gradient (960 TFLOP/s).  Problems share M and the split
+// plan; a block picks its problem from the tile index (scalar selects), everything else is tn_tile.  Split-major numbering over
+// the UNION of the tiles, one contiguous range per XCD, as gemm_tn_kernel.
+#define TN_GROUP_MAX 4
+struct TnGroup {
+  TnArgs p[TN_GROUP_MAX];
+  int first_tile[TN_GROUP_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
+  const int T = g.first_tile[g.n];
+  const int P = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = P / T, t = P - split * T;
+  TnArgs a = g.p[0];
+  int t0 = 0;
+  if (g.n > 1 && t >= g.first_tile[1]) { a = g.p[1]; t0 = g.first_tile[1]; }
+  if (g.n > 2 && t >= g.first_tile[2]) { a = g.p[2]; t0 = g.first_tile[2]; }
+  if (g.n > 3 && t >= g.first_tile[3]) { a = g.p[3]; t0 = g.first_tile[3]; }
+  int ti, tj;
+  tile_of_block(t - t0, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = split * a.m_per_split;
+  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  const int rows = me > mb ? me - mb : 0;
+  tn_tile<false>(a, nullptr, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
+                 a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
+}
+
 // ---- 256x256-tile weight gradient (8 waves) ----------------------------------------------------------------------------
 // Same data path as tn_tile (natural-layout LDS tiles by LDS-DMA, hardware transpose reads), block tile 256 (I) x 256 (J),
 // 8 waves as 2 (I) x 4 (J) of 128 x 64 = 4 x 2 MFMA tiles; two stages x (X 64 x 256 | Y 64 x 256) bf16 = 128 KiB -> one
@@ -2491,6 +2522,66 @@ extern "C" int dmi_reduce_slabs_batch(const dmi_reduce_item* items, int n, void*
   reduce_slabs_batch_kernel<<<dim3(nblk), dim3(256), 0, (hipStream_t)stream>>>(g);
   DMI_CHECK_LAUNCH("reduce_slabs_batch");
   return DMI_OK;
+}
+
+// Weight gradients that share M in one launch (see gemm_tn_group_kernel).  Every problem's workspace holds its own slabs
+// (dmi_gemm_tn_workspace_bytes(M, I, J) bytes suffice: the group never splits finer than the single launch would); the slab
+// reduces are appended to `deferred` (2 per problem at most) or, with deferred == NULL, run here as one batched launch.
+extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_reduce_item* deferred, int* n_deferred, void* stream) {
+  DMI_REQUIRE(probs && n >= 1 && n <= TN_GROUP_MAX && M > 0, "gemm_tn_group: 1..%d problems", TN_GROUP_MAX);
+  TnGroup g;
+  g.n = n;
+  int T = 0;
+  for (int k = 0; k < n; ++k) {
+    const dmi_tn_problem& q = probs[k];
+    DMI_REQUIRE(q.X && q.dY && q.dW && q.workspace, "gemm_tn_group: null pointer in problem %d", k);
+    DMI_REQUIRE(q.I % 8 == 0 && q.J % 8 == 0 && q.ldx % 8 == 0 && q.ldy % 8 == 0 && q.ldx >= q.I && q.ldy >= q.J,
+                "gemm_tn_group: I, J, ldx, ldy must be multiples of 8 (problem %d: I=%d J=%d)", k, q.I, q.J);
+    DMI_REQUIRE((((uintptr_t)q.X | (uintptr_t)q.dY | (uintptr_t)q.dW | (uintptr_t)q.workspace) & 15) == 0, "gemm_tn_group: 16-byte alignment required");
+    DMI_REQUIRE(!q.bias_weights || (q.dbias && ((uintptr_t)q.bias_weights & 3) == 0), "gemm_tn_group: bias_weights needs dbias and 4-byte alignment");
+    DMI_REQUIRE((int64_t)TN_BKM * (q.ldx > q.ldy ? q.ldx : q.ldy) * 2 < 0x7fffffff, "gemm_tn_group: leading dimension too large");
+    g.first_tile[k] = T;
+    T += ((q.I + 127) / 128) * ((q.J + 127) / 128);
+  }
+  g.first_tile[n] = T;
+  for (int k = n + 1; k <= TN_GROUP_MAX; ++k) g.first_tile[k] = T;
+  const int max_s = (M + 4 * TN_BKM - 1) / (4 * TN_BKM);
+  int S = T >= 384 ? 1 : 512 / T;
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  dmi_reduce_item items[2 * TN_GROUP_MAX];
+  int ni = 0;
+  for (int k = 0; k < n; ++k) {
+    const dmi_tn_problem& q = probs[k];
+    TnArgs& a = g.p[k];
+    a.X = q.X; a.Y = q.dY; a.M = M; a.I = q.I; a.J = q.J; a.ldx = q.ldx; a.ldy = q.ldy;
+    a.tiles_i = (q.I + 127) / 128; a.tiles_j = (q.J + 127) / 128;
+    a.m_per_split = (int)round_up64((M + S - 1) / S, TN_BKM);
+    float* slabs = (float*)q.workspace;
+    const int64_t slab_bytes = (S > 1) ? round_up64((int64_t)S * q.I * q.J * 4, 256) : 0;
+    float* bpart = (float*)((char*)q.workspace + slab_bytes);
+    a.C = (S > 1) ? slabs : q.dW;
+    a.slab_stride = (S > 1) ? (int64_t)q.I * q.J : 0;
+    a.bias_w = q.bias_weights;
+    a.bias_part = q.dbias ? ((S > 1) ? bpart : q.dbias) : nullptr;
+    a.dbg = nullptr;
+    if (S > 1) {
+      if (q.dbias) { items[ni].slabs = bpart; items[ni].out = q.dbias; items[ni].nsplit = S; items[ni].n4 = q.J / 4; ++ni; }
+      items[ni].slabs = slabs; items[ni].out = q.dW; items[ni].nsplit = S; items[ni].n4 = (int64_t)q.I * q.J / 4; ++ni;
+    }
+  }
+  for (int k = n; k < TN_GROUP_MAX; ++k) g.p[k] = g.p[0];
+  static bool attr_done = false;
+  if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES); attr_done = true; }
+  gemm_tn_group_kernel<<<dim3(T * S), dim3(256), TN_LDS_BYTES, (hipStream_t)stream>>>(g);
+  DMI_CHECK_LAUNCH("gemm_tn_group");
+  if (n_deferred) *n_deferred = 0;
+  if (deferred && n_deferred) {
+    for (int i = 0; i < ni; ++i) deferred[i] = items[i];
+    *n_deferred = ni;
+    return DMI_OK;
+  }
+  return dmi_reduce_slabs_batch(items, ni, stream);
 }
 
 extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* dW, float* dbias,

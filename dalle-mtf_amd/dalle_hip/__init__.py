@@ -70,6 +70,7 @@ def _declare(L):
         "dmi_gemm_nt_splitk": (I, [P, I, P, I, P, I, I, I, I, P, P, P]),
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
         "dmi_gemm_tn": (I, [P, I, P, I, P, P, P, I, I, I, P, P, P, P]),
+        "dmi_gemm_tn_group": (I, [P, I, I, P, P, P]),
         "dmi_reduce_slabs_batch": (I, [P, I, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
         "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
@@ -317,6 +318,32 @@ def gemm_tn(X, ldx, dY, ldy, dW, M, I, J, ws, dbias=None, bias_weights=None, def
     slot = ctypes.byref(deferred.items, deferred.n * ctypes.sizeof(ReduceItem))
     _check(lib().dmi_gemm_tn(_p(X), ldx, _p(dY), ldy, _p(dW), _p(dbias), _p(bias_weights), M, I, J, _p(ws), slot,
                              ctypes.byref(cnt), _stream()), "gemm_tn")
+    deferred.n += cnt.value
+
+
+class TnProblem(ctypes.Structure):
+    """dmi_tn_problem (include/dalle_hip.h)."""
+    _fields_ = [("X", c_void_p), ("ldx", c_int), ("dY", c_void_p), ("ldy", c_int), ("dW", c_void_p), ("dbias", c_void_p),
+                ("bias_weights", c_void_p), ("I", c_int), ("J", c_int), ("workspace", c_void_p)]
+
+
+def gemm_tn_group(problems, M, deferred: "DeferredReduces" = None):
+    """several weight gradients over the same M rows in one launch.  problems: dicts with X, ldx, dY, ldy, dW, I, J, ws and
+    optionally dbias, bias_weights (as gemm_tn); deferred as in gemm_tn."""
+    n = len(problems)
+    arr = (TnProblem * n)()
+    for k, q in enumerate(problems):
+        _dev(q["X"], q["dY"], q["dW"], q["ws"], q.get("dbias"), q.get("bias_weights"))
+        assert q["ws"].numel() * q["ws"].element_size() >= gemm_tn_workspace_bytes(M, q["I"], q["J"])
+        arr[k] = TnProblem(_p(q["X"]), q["ldx"], _p(q["dY"]), q["ldy"], _p(q["dW"]), _p(q.get("dbias")), _p(q.get("bias_weights")),
+                           q["I"], q["J"], _p(q["ws"]))
+    if deferred is None:
+        _check(lib().dmi_gemm_tn_group(ctypes.byref(arr), n, M, None, None, _stream()), "gemm_tn_group")
+        return
+    assert deferred.n + 2 * n <= deferred.capacity
+    cnt = c_int(0)
+    slot = ctypes.byref(deferred.items, deferred.n * ctypes.sizeof(ReduceItem))
+    _check(lib().dmi_gemm_tn_group(ctypes.byref(arr), n, M, slot, ctypes.byref(cnt), _stream()), "gemm_tn_group")
     deferred.n += cnt.value
 
 

@@ -313,6 +313,7 @@ class DalleEngine:
         self.fuse_ln1 = self.fuse_ln and not self.recompute
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
         self.hp.setdefault("defer_reduces", os.environ.get("DALLE_DEFER_REDUCES", "1") != "0")
+        self.hp.setdefault("wgrad_pair", os.environ.get("DALLE_WGRAD_PAIR", "1") != "0")
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -679,11 +680,19 @@ class DalleEngine:
             ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
                    self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
             # attention
-            self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
-                        dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
+            pair = self.hp["wgrad_pair"] and self.hp["defer_reduces"]
+            if not pair:
+                self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
+                            dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
             dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
-            self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
+            if pair:   # [r05] the out-projection and QKV kernels' gradients in ONE launch: 16 + 48 tiles fill the chip together
+                dh.gemm_tn_group([dict(X=self.o[l], ldx=d, dY=dxb, ldy=d, dW=self._gv(p + "attn/o"), I=d, J=d, ws=self.ws_blk[2],
+                                       dbias=self._gv(p + "attn/compute_output_bias/o_b")),
+                                  dict(X=self.xn1[l], ldx=d, dY=self.dqkv, ldy=3 * d, dW=self._gv(p + "attn/qkv"), I=d, J=3 * d,
+                                       ws=self.ws_blk[3])], M, deferred=self.deferred)
+            else:
+                self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
             dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
             ln_bwd(2 * l, self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
                    self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"))

@@ -113,6 +113,15 @@ int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int ldy, float* 
                 const uint16_t* bias_weights, int M, int I, int J, void* workspace, dmi_reduce_item* deferred,
                 int* n_deferred, void* stream);
 int dmi_reduce_slabs_batch(const dmi_reduce_item* items, int n, void* stream);
+/* Up to 4 weight gradients that contract over the same M rows in ONE launch (the gradients of a block's out-projection and QKV
+ * kernels, src/dalle_mtf/models.py:242-244,303-311 under mtf.gradients, src/optimizers.py:34: 16 + 48 tiles fill the chip together,
+ * neither does alone).  Per problem: dW[I,J] = X^T dY (+ dbias / bias_weights as dmi_gemm_tn) with its own workspace of
+ * dmi_gemm_tn_workspace_bytes(M, I, J) bytes.  The slab reduces (<= 2 per problem) go to `deferred` / *n_deferred, or run here
+ * when deferred == NULL.  The row-split plan is the group's, so sums are ordered differently from n single dmi_gemm_tn calls
+ * (fp32, deterministic). */
+typedef struct dmi_tn_problem { const uint16_t* X; int ldx; const uint16_t* dY; int ldy; float* dW; float* dbias;
+                                const uint16_t* bias_weights; int I; int J; void* workspace; } dmi_tn_problem;
+int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_reduce_item* deferred, int* n_deferred, void* stream);
 
 /* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
 int64_t dmi_colsum_workspace_bytes(int64_t M, int N);

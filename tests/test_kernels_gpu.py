@@ -392,6 +392,44 @@ def test_gemm_nt8p_persistent_tile_256x256(M, N, K, flags):
     assert torch.equal(outs[0], outs[1]), "persistent 256x256 and 128x128 tile kernels must be bit-identical"
 
 
+@pytest.mark.parametrize("M,shapes", [(40960, [(512, 512, True), (512, 1536, False)]), (2560, [(512, 512, True), (512, 1536, False)]),
+                                      (1000, [(136, 200, True), (264, 72, True), (128, 128, False)]), (300, [(2048, 512, True)]),
+                                      (5000, [(512, 2048, True), (2048, 512, True), (512, 512, True), (512, 1536, False)])])
+def test_gemm_tn_group_matches_fp32(M, shapes):
+    """[r05] dmi_gemm_tn_group: several weight gradients over the same M rows in one launch (the out-projection + QKV pair of a block
+    at the benchmark shape, ragged tiles, one problem, four problems, split and unsplit plans), each vs the fp32 product of the same
+    bf16 operands, bias gradients as column sums; and vs dmi_gemm_tn to fp32 summation order; deferred and immediate reduces agree
+    bit for bit."""
+    probs, refs = [], []
+    for k, (I, J, with_bias) in enumerate(shapes):
+        X, dY = rnd(M, I, seed=10 + k), rnd(M, J, seed=20 + k)
+        q = dict(X=X.to(DEV), ldx=I, dY=dY.to(DEV), ldy=J, dW=torch.full((I, J), 7.0, dtype=torch.float32, device=DEV), I=I, J=J,
+                 ws=torch.empty(int(dh.gemm_tn_workspace_bytes(M, I, J)) + 256, dtype=torch.uint8, device=DEV))
+        if with_bias:
+            q["dbias"] = torch.full((J,), 7.0, dtype=torch.float32, device=DEV)
+        probs.append(q)
+        refs.append((X.float().t() @ dY.float(), dY.float().sum(0)))
+    dh.gemm_tn_group(probs, M)
+    first = [(q["dW"].clone(), q["dbias"].clone() if "dbias" in q else None) for q in probs]
+    for q, (rw, rb) in zip(probs, refs):
+        close(q["dW"], rw, 2e-3, 2e-3 * math.sqrt(M), "group dW")
+        if "dbias" in q:
+            close(q["dbias"], rb, 2e-3, 2e-3 * math.sqrt(M), "group dbias")
+        single = torch.zeros_like(q["dW"])
+        sb = torch.zeros(q["J"], dtype=torch.float32, device=DEV) if "dbias" in q else None
+        dh.gemm_tn(q["X"], q["ldx"], q["dY"], q["ldy"], single, M, q["I"], q["J"], q["ws"], dbias=sb)
+        close(q["dW"], single.cpu(), 1e-4, 1e-4 * math.sqrt(M), "group vs single")
+    for q in probs:
+        q["dW"].fill_(3.0)
+        if "dbias" in q:
+            q["dbias"].fill_(3.0)
+    dfr = dh.DeferredReduces()
+    dh.gemm_tn_group(probs, M, deferred=dfr)
+    dfr.run()
+    for q, (w0, b0) in zip(probs, first):
+        assert torch.equal(q["dW"], w0) and (b0 is None or torch.equal(q["dbias"], b0))
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (2100, 576, 384), (515, 1088, 128), (40960, 2048, 512)])
 def test_relu_mask_as_bits_is_bit_identical(M, N, K):
     """[r05] dmi_gemm_nt_relu_bits / dmi_gemm_nt_mask_bits (FFN-1 forward emits one bit per output, the FFN-2 input gradient applies
