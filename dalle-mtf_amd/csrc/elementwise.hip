@@ -556,6 +556,15 @@ extern "C" int dmi_layernorm_bwd(const uint16_t* dy, const uint16_t* x, const ui
   return DMI_OK;
 }
 
+// dg | db = column sums of P partial rows [2 d] (the reduce behind dmi_layernorm_bwd, for partials produced elsewhere: the fused
+// LayerNorm backward of dmi_gemm_nt_lnbwd)
+extern "C" int dmi_layernorm_bwd_finish_parts(const float* part, int P, float* dg, float* db, int d, void* stream) {
+  DMI_REQUIRE(part && dg && db && P > 0 && d % 8 == 0 && d <= 2048, "layernorm_bwd_finish_parts: bad arguments");
+  ln_bwd_finish_kernel<<<dim3((2 * d + 15) / 16), dim3(256), 0, (hipStream_t)stream>>>(part, dg, db, P, d);
+  DMI_CHECK_LAUNCH("layernorm_bwd_finish_parts");
+  return DMI_OK;
+}
+
 // The gain / bias gradients of several LayerNorms reduced in ONE launch: blockIdx.y = the LayerNorm.  Each of the 13 reduces of a
 // dalle_example step is a 64-block kernel of ~7 us; the results are only needed by the gradient exchange / the optimizer.
 #define LN_FINISH_MAX 16

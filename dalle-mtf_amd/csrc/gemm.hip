@@ -128,6 +128,11 @@ struct GemmArgs {
   float* ln_rstd;
   float ln_eps;
   int ln_ldy;
+  // fused LayerNorm BACKWARD of the product (dmi_gemm_nt_lnbwd, full-row tiles only): the product is dy; ln_x = the LayerNorm's input,
+  // ln_gamma / ln_mean / ln_rstd as above, residual = the gradient arriving over the residual connection (nullable), ln_y = dx,
+  // ln_part = [2 * blocks][2 * N] fp32 partial gain | bias gradients (one row per 80-row half tile)
+  const bf16_t* ln_x;
+  float* ln_part;
 };
 #define GEMM_SOFTMAX 64   // internal epilogue flag of dmi_gemm_nt_softmax (not part of the public flag set)
 #define GEMM_RELU_BITS 128   // internal: with DMI_GEMM_RELU, also emit one bit per output (> 0) -- dmi_gemm_nt_relu_bits
@@ -1171,7 +1176,204 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& a, f32x4 (&acc)[RT][
   }
 }
 
-template <int FLAGS, int RT, bool LN = false>
+// Epilogue of the full-row kernel with a fused LayerNorm BACKWARD (round 5).  The two input-gradient products of a block that end
+// in a LayerNorm -- dxn = dh . W1^T -> norm_2, dxn = dqkv . Wqkv^T -> norm_1 (reference: the backward of src/dalle_mtf/models.py:330,
+// 333 through layers.py:30-33 and models.py:387-388) -- wrote dxn (42 MB) for ln_bwd_kernel to read back next to x and the residual
+// gradient.  A block of this kernel owns whole rows, so it does the row reductions itself:
+//   dy = bf16(acc)                                 (what the unfused path stores and reads back: same rounding)
+//   xh = (x - mean) * rstd;  gy = dy * gamma;  s1 = sum_n gy / N;  s2 = sum_n gy * xh / N
+//   dx = bf16(rstd * (gy - s1 - xh * s2) + dres);  dgamma += dy * xh;  dbeta += dy   (column partials per 80-row half tile)
+// Pass 1 walks the accumulators column tile by column tile (x in 8-byte pieces in the accumulator layout), leaves gy in place,
+// reduces the tile's 16 rows of the column partials inside the 16-lane rows with DPP adds (fixed order) and writes one partial row per
+// (block, row half); the row sums combine over the four lane groups by two exchanges and over the four waves of a row through 5 KB
+// of LDS.  Pass 2 re-reads x (L2-hot) and the residual gradient, forms dx and stores it through the row swap as the other register
+// epilogues.  Deterministic; differs from ln_bwd_kernel only in the summation order of the reductions.
+__device__ __forceinline__ float dpp_row_sum16(float v) {     // sum over the 16 lanes of a DPP row, result in every lane
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+  return v;
+}
+template <int RT>
+__device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[RT][8], char* smem, int lane, int wm, int wn, int m0) {
+  constexpr int RM = 32 * RT;
+  const int c16 = lane & 15, g16 = lane >> 4;
+  float* red = (float*)smem;                       // [RM rows][4 waves][2]
+  const int ncolw = wn * 128;
+  const int pcol = 8 * (((g16 & 1) << 1) | (g16 >> 1));
+  const float invn = 1.0f / 512.0f;
+  // x / dres / dx / mean / rstd through buffer descriptors based at the tile's first row: one 32-bit offset per row tile, the column
+  // tile in the instruction's offset field (64-bit pointers per (row, column tile) cost 80 registers); rows past M read as zeros and
+  // their stores are dropped
+  const int nbytes = (int)(((int64_t)(a.M - m0) * 512) * 2);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_x + (int64_t)m0 * 512), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.ln_x) + (int64_t)m0 * 512), 0,
+                                                                       a.residual ? nbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_y + (int64_t)m0 * 512), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rmu = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_mean + m0), 0, (a.M - m0) * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_rstd + m0), 0, (a.M - m0) * 4, 0x00020000);
+  const int r0 = wm * (RM / 2) + c16;                      // this lane's row of row tile 0 (row tile t: + 16 t)
+  const int vo0 = (r0 * 512 + ncolw + 4 * g16) * 2;        // byte offset of (that row, column ncolw + 4 g); row tile t: + 16 KB t
+  float* prow = a.ln_part + (int64_t)(blockIdx.x * 2 + wm) * 1024;
+  auto ld8 = [&](const __amdgpu_buffer_rsrc_t rsrc, int voff, int imm) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, imm, 0));
+  };
+  auto lo = [](unsigned w) { return __uint_as_float(w << 16); };
+  auto hi = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
+  // dy = bf16(acc) and x are kept PACKED (80 + 80 registers; the three passes unpack what they touch).  x and dres are fetched as the
+  // 16-byte pieces of the store layout (64 contiguous bytes per row and instruction) and brought into the accumulator layout by the
+  // row swap, which is its own inverse -- as 8-byte pieces in the accumulator layout, re-read by every pass, the epilogue cost 50 us
+  unsigned dyp[RT][8][2], xp[RT][8][2], gmp[8][2];
+  const int vst = (r0 * 512 + ncolw + pcol) * 2;      // this lane's 16-byte piece: row of tile 0, column ncolw + pcol (+ 32; + 64 h)
+  auto ld16 = [&](const __amdgpu_buffer_rsrc_t rsrc, int voff, int imm) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, imm, 0));
+  };
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 l0 = ld16(rx, vst + 16384 * t, 128 * h), l1 = ld16(rx, vst + 16384 * t, 128 * h + 64);
+      xp[t][4 * h + 0][0] = l0[0]; xp[t][4 * h + 0][1] = l0[1]; xp[t][4 * h + 1][0] = l0[2]; xp[t][4 * h + 1][1] = l0[3];
+      xp[t][4 * h + 2][0] = l1[0]; xp[t][4 * h + 2][1] = l1[1]; xp[t][4 * h + 3][0] = l1[2]; xp[t][4 * h + 3][1] = l1[3];
+    }
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      dyp[t][j][0] = pack2bf(acc[t][j][0], acc[t][j][1]); dyp[t][j][1] = pack2bf(acc[t][j][2], acc[t][j][3]);
+      asm volatile("" : "+v"(dyp[t][j][0]), "+v"(dyp[t][j][1]));   // materialised HERE (left alone, hipcc sinks the conversions to their uses and keeps the accumulators alive)
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const u32x2 graw = *(const u32x2*)(a.ln_gamma + ncolw + 16 * j + 4 * g16);
+    gmp[j][0] = graw[0]; gmp[j][1] = graw[1];
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) { swap16(xp[t][4 * h][dd], xp[t][4 * h + 1][dd]); swap16(xp[t][4 * h + 2][dd], xp[t][4 * h + 3][dd]); }
+  // (between the passes the packed values are made opaque again: otherwise the passes' unpackings are merged into ONE set of 320
+  // live floats, which is what spilled)
+  auto opaque = [&]() {
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(dyp[t][j][0]), "+v"(dyp[t][j][1]), "+v"(xp[t][j][0]), "+v"(xp[t][j][1]));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(gmp[j][0]), "+v"(gmp[j][1]));
+  };
+  opaque();
+  // ---- pass 1a: row sums s1 = sum gy, s2 = sum gy * xh, one row tile at a time
+  float mu[RT], rs[RT], s1[RT], s2[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    mu[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmu, (r0 + 16 * t) * 4, 0, 0));
+    rs[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (r0 + 16 * t) * 4, 0, 0));
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
+      const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
+      const float gm[4] = {lo(gmp[j][0]), hi(gmp[j][0]), lo(gmp[j][1]), hi(gmp[j][1])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mu[t]) * rs[t];
+        const float gy = dy[e] * gm[e];
+        a1 += gy;
+        a2 += gy * xh;
+      }
+    }
+    s1[t] = a1; s2[t] = a2;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the four lane groups of a row, then its four waves through LDS (fixed order)
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    s1[t] += __shfl_xor(s1[t], 16, 64); s1[t] += __shfl_xor(s1[t], 32, 64);
+    s2[t] += __shfl_xor(s2[t], 16, 64); s2[t] += __shfl_xor(s2[t], 32, 64);
+    if (g16 == 0) {
+      float* q = red + ((r0 + 16 * t) * 4 + wn) * 2;
+      q[0] = s1[t]; q[1] = s2[t];
+    }
+  }
+  __syncthreads();
+  opaque();
+  // ---- pass 1b: column partials dgamma += dy * xh, dbeta += dy over this wave's 80 rows, one column tile at a time: the 16 rows of a
+  // row tile are the 16 lanes of a DPP row (4 adds, fixed order), lane c16 == 0 of each lane group writes its four columns
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
+      const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ab[e] += dy[e];
+        ag[e] += dy[e] * ((xv[e] - mu[t]) * rs[t]);
+      }
+    }
+    f32x4 pg, pb;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { pg[e] = dpp_row_sum16(ag[e]); pb[e] = dpp_row_sum16(ab[e]); }
+    if (c16 == 0) {
+      const int n = ncolw + 16 * j + 4 * g16;
+      *(f32x4*)(prow + n) = pg;
+      *(f32x4*)(prow + 512 + n) = pb;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const f32x4 q0 = *(const f32x4*)(red + (r0 + 16 * t) * 8);
+    const f32x4 q1 = *(const f32x4*)(red + (r0 + 16 * t) * 8 + 4);
+    s1[t] = ((q0[0] + q0[2]) + (q1[0] + q1[2])) * invn;
+    s2[t] = ((q0[1] + q0[3]) + (q1[1] + q1[3])) * invn;
+  }
+  opaque();
+  // ---- pass 2: dx = rstd * (dy * gamma - s1 - xh * s2) + dres, one (row tile, 64-column half) at a time; dres arrives as 16-byte pieces
+  // and goes through the row swap into the accumulator layout, dx leaves through it
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32x4 l0 = ld16(rr, vst + 16384 * t, 128 * h), l1 = ld16(rr, vst + 16384 * t, 128 * h + 64);
+      unsigned R[4][2] = {{l0[0], l0[1]}, {l0[2], l0[3]}, {l1[0], l1[1]}, {l1[2], l1[3]}};
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) { swap16(R[0][dd], R[1][dd]); swap16(R[2][dd], R[3][dd]); }
+      unsigned P[4][2];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * h + jj;
+        const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
+        const float rv[4] = {lo(R[jj][0]), hi(R[jj][0]), lo(R[jj][1]), hi(R[jj][1])};
+        const float gm[4] = {lo(gmp[j][0]), hi(gmp[j][0]), lo(gmp[j][1]), hi(gmp[j][1])};
+        const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu[t]) * rs[t];
+          o[e] = rs[t] * (dy[e] * gm[e] - s1[t] - xh * s2[t]) + rv[e];
+        }
+        P[jj][0] = pack2bf(o[0], o[1]);
+        P[jj][1] = pack2bf(o[2], o[3]);
+      }
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) { swap16(P[0][dd], P[1][dd]); swap16(P[2][dd], P[3][dd]); }
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[0][0], P[0][1], P[1][0], P[1][1]}, ry, vst + 16384 * t, 128 * h, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[2][0], P[2][1], P[3][0], P[3][1]}, ry, vst + 16384 * t, 128 * h + 64, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+template <int FLAGS, int RT, int LN = 0>      // LN: 0 plain register epilogue, 1 fused LayerNorm of the output, 2 fused LayerNorm backward
 __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int RM = 32 * RT;                 // rows per tile
@@ -1283,11 +1485,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (LN) {
+  if constexpr (LN != 0) {
     // every wave's in-flight pieces have landed before anybody's partial sums overwrite the stage buffers (when (K / 32) % 3 == 2 the
     // last k-step's redundant reload targets buffer 0, where `red` lives: K = 256, 1024)
     __syncthreads();
-    epilogue_ln<RT>(a, acc, smem, lane, wm, wn, m0);     // (the last k-step's barrier: every wave is done with the stage buffers)
+    if constexpr (LN == 1) epilogue_ln<RT>(a, acc, smem, lane, wm, wn, m0);     // (the last k-step's barrier: every wave is done with the stage buffers)
+    else {
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));     // opaque: keeps the epilogue's address arithmetic and loads out of the main loop (they spilled 140 registers there)
+      epilogue_lnbwd<RT>(a, acc, smem, lane_e, wm, wn, m0);
+    }
   } else {   // the register epilogue works on 64-column halves of the wave tile
     f32x4 lo[RT][4], hi[RT][4];
 #pragma unroll
@@ -1593,6 +1800,7 @@ static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr; a.pf = 0;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
+  a.ln_x = nullptr; a.ln_part = nullptr;
   const int64_t cbytes = ((int64_t)(M - 1) * ldc + N) * 2;     // bf16 outputs (the fp32 forms do not use the policy)
   // 1 (default): auto by size -- sc1 from cstream_min_mb, sc1 nt from cstream_nt_min_mb (a stream far larger than the 256-MB
   // Infinity Cache: the 4-GB softmax numerators; outputs of a few hundred MB that the next kernel re-reads were measured with
@@ -1689,9 +1897,36 @@ extern "C" int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, in
   constexpr int RT = 5;
   constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
-  gemm_ntr_kernel<0, RT, true><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  gemm_ntr_kernel<0, RT, 1><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
   DMI_CHECK_LAUNCH("gemm_nt_ln");
+  return DMI_OK;
+}
+
+// Product with N = 512 outputs whose result is the gradient arriving at a LayerNorm, and that LayerNorm's backward in the same pass
+// (see epilogue_lnbwd): dx = LN'(x; gamma, mean, rstd)(A . Bt^T) + dres.  part: dmi_gemm_nt_lnbwd_parts(M) rows of [2 N] fp32 partial
+// gain | bias gradients, to be summed by dmi_layernorm_bwd_finish_parts.
+extern "C" int dmi_gemm_nt_lnbwd_parts(int M) { return 2 * ((M + 159) / 160); }
+extern "C" int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, const uint16_t* x,
+                                 const uint16_t* gamma, const float* mean, const float* rstd, const uint16_t* dres, uint16_t* dx,
+                                 float* part, void* stream) {
+  int rc = check_nt(A, lda, Bt, ldb, dx, N, M, N, K);
+  if (rc) return rc;
+  DMI_REQUIRE(x && gamma && mean && rstd && part, "gemm_nt_lnbwd: null pointer");
+  DMI_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dres | (uintptr_t)part) & 15) == 0, "gemm_nt_lnbwd: operands must be 16-byte aligned");
+  if (N != 512 || (int64_t)N * ldb >= (1 << 30) || (int64_t)M * lda >= ((int64_t)1 << 31)) {
+    dmi_set_error("gemm_nt_lnbwd: the fused form needs N = 512 (one block owns whole rows); got N=%d", N);
+    return DMI_ERR_UNSUPPORTED;
+  }
+  GemmArgs a;
+  fill_nt_args(a, A, lda, Bt, ldb, dx, N, M, N, K);
+  a.residual = dres; a.ln_x = x; a.ln_gamma = gamma; a.ln_mean = (float*)mean; a.ln_rstd = (float*)rstd; a.ln_y = dx; a.ln_ldy = N; a.ln_part = part;
+  constexpr int RT = 5;
+  constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
+  gemm_ntr_kernel<0, RT, 2><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
+  DMI_CHECK_LAUNCH("gemm_nt_lnbwd");
   return DMI_OK;
 }
 
@@ -2811,6 +3046,7 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr; a.relu_bits = nullptr;
   a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr; a.cpol = 0;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
+  a.ln_x = nullptr; a.ln_part = nullptr;
   ConvGeom g;
   g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = 0; g.lh = 0;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }

@@ -314,6 +314,11 @@ class DalleEngine:
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
         self.hp.setdefault("defer_reduces", os.environ.get("DALLE_DEFER_REDUCES", "1") != "0")
         self.hp.setdefault("wgrad_pair", os.environ.get("DALLE_WGRAD_PAIR", "1") != "0")
+        # [r05] LayerNorm backward fused into the two input-gradient products that feed a LayerNorm (dmi_gemm_nt_lnbwd: n_embd = 512,
+        # full-row tiles): dxn is never written, 12 of the 13 ln_bwd launches of a dalle_example step disappear
+        self.fuse_lnbwd = bool(self.hp.get("fuse_lnbwd", os.environ.get("DALLE_FUSE_LNBWD", "1") != "0")) and d == 512 and not self.defer_ln
+        if self.fuse_lnbwd:
+            self.lnb_part = torch.empty(dh.gemm_nt_lnbwd_parts(M) * 2 * d, dtype=torch.float32, device=self.dev)
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -676,9 +681,14 @@ class DalleEngine:
                            relu_src=self.h[l])
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
                         dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
-            dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
-            ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
-                   self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
+            if self.fuse_lnbwd:
+                dh.gemm_nt_lnbwd(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, M, d, 4 * d, self.x1[l],
+                                 self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb, self.lnb_part,
+                                 dg=self._gv(p + "norm_2/g"), db=self._gv(p + "norm_2/b"))
+            else:
+                dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
+                ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
+                       self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
             # attention
             pair = self.hp["wgrad_pair"] and self.hp["defer_reduces"]
             if not pair:
@@ -693,9 +703,14 @@ class DalleEngine:
                                        ws=self.ws_blk[3])], M, deferred=self.deferred)
             else:
                 self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
-            dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
-            ln_bwd(2 * l, self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
-                   self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"))
+            if self.fuse_lnbwd:
+                dh.gemm_nt_lnbwd(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, M, d, 3 * d, self.X[l],
+                                 self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa, self.lnb_part,
+                                 dg=self._gv(p + "norm_1/g"), db=self._gv(p + "norm_1/b"))
+            else:
+                dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
+                ln_bwd(2 * l, self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
+                       self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"))
             self.deferred.run()        # the block's seven slab reduces in one launch
             if allreduce and self.world > 1:
                 flush_ln()             # the exchange takes this block's gradients now

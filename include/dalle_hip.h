@@ -194,6 +194,18 @@ int dmi_gemm_nt_relu_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ld
                           const uint16_t* bias, void* bits, void* stream);
 int dmi_gemm_nt_mask_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
                           const void* bits, void* stream);
+/* An input-gradient product whose result arrives at a LayerNorm, with that LayerNorm's BACKWARD fused into the epilogue (reference:
+ * the backward of src/dalle_mtf/layers.py:30-33 + models.py:387-388 behind models.py:330 / :333 -- norm_1 <- QKV, norm_2 <- FFN-1):
+ *   dy = bf16(A . Bt^T) [M, N];  xh = (x - mean) * rstd;  dx[M, N] = bf16(rstd * (dy*gamma - mean_n(dy*gamma) - xh * mean_n(dy*gamma*xh)) + dres)
+ * (dres nullable), i.e. what dmi_gemm_nt followed by dmi_layernorm_bwd computes, without writing / re-reading dy; the gain / bias
+ * gradients leave as dmi_gemm_nt_lnbwd_parts(M) partial rows [2 N] fp32 in `part` (dgamma | dbeta), summed by
+ * dmi_layernorm_bwd_finish_parts (fixed order).  N = 512 only (a block owns whole rows): DMI_ERR_UNSUPPORTED otherwise.  x, dres, dx have
+ * row pitch N.  Differs from the two-kernel form only in the summation order of the reductions. */
+int dmi_gemm_nt_lnbwd_parts(int M);
+int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, const uint16_t* x,
+                      const uint16_t* gamma, const float* mean, const float* rstd, const uint16_t* dres, uint16_t* dx,
+                      float* part, void* stream);
+int dmi_layernorm_bwd_finish_parts(const float* part, int P, float* dg, float* db, int d, void* stream);
 int dmi_gemm_nt_softmax(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                         const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K, void* stream);
 int dmi_softmax_finish(const float* rowsum_part, int nparts, const float* label_logit, const float* rowshift,

@@ -162,6 +162,49 @@ def test_layernorm_bwd_deferred_finish_batch():
         assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
 
 
+@pytest.mark.parametrize("M,K,with_res", [(160, 512, True), (1000, 1536, True), (2100, 2048, False), (40960, 1536, True), (333, 256, True)])
+def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
+    """[r05] dmi_gemm_nt_lnbwd (full-row tiles, N = 512): dx, dgamma, dbeta equal dmi_gemm_nt followed by dmi_layernorm_bwd up to the
+    summation order of the reductions (dx within one bf16 ulp almost everywhere), and fp32 autograd of LayerNorm applied to the
+    bf16-rounded product; ragged last tile, K with (K / 32) % 3 == 2."""
+    N = 512
+    A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
+    x, dres = rnd(M, N, seed=3), rnd(M, N, seed=4)
+    gam = bf(1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(5)))
+    Ad, Bd, xd, gd = A.to(DEV), Bt.to(DEV), x.to(DEV), gam.to(DEV)
+    rd = dres.to(DEV) if with_res else None
+    y = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    mean = torch.zeros(M, dtype=torch.float32, device=DEV)
+    rstd = torch.zeros(M, dtype=torch.float32, device=DEV)
+    dh.layernorm_fwd(xd, gd, torch.zeros(N, dtype=torch.bfloat16, device=DEV), y, mean, rstd, M, N)
+    # two-kernel form
+    dy = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(Ad, K, Bd, K, dy, N, M, N, K)
+    dx0 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dg0, db0 = (torch.zeros(N, dtype=torch.float32, device=DEV) for _ in range(2))
+    dh.layernorm_bwd(dy, xd, gd, mean, rstd, rd, dx0, dg0, db0, ws(dh.layernorm_bwd_workspace_bytes(M, N)), M, N)
+    # fused
+    dx1 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dg1, db1 = (torch.full((N,), float("nan"), dtype=torch.float32, device=DEV) for _ in range(2))
+    part = torch.full((dh.gemm_nt_lnbwd_parts(M) * 2 * N,), float("nan"), dtype=torch.float32, device=DEV)
+    dh.gemm_nt_lnbwd(Ad, K, Bd, K, M, N, K, xd, gd, mean, rstd, rd, dx1, part, dg=dg1, db=db1)
+    assert not torch.isnan(dx1.float()).any() and not torch.isnan(dg1).any() and not torch.isnan(db1).any()
+    d = (dx1.float() - dx0.float()).abs()
+    assert float((d > 2.0 ** -7 * dx0.float().abs() + 1e-3).float().mean()) == 0.0, "dx differs from the two-kernel form by more than one bf16 ulp"
+    assert float((dx1 != dx0).float().mean()) < 2e-2, float((dx1 != dx0).float().mean())
+    close(dg1, dg0.cpu(), 1e-4, 1e-4 * math.sqrt(M), "dgamma vs two-kernel form")
+    close(db1, db0.cpu(), 1e-4, 1e-4 * math.sqrt(M), "dbeta vs two-kernel form")
+    # fp32 autograd on the rounded product
+    xf = x.float().requires_grad_(True)
+    gf, bff = gam.float().requires_grad_(True), torch.zeros(N, requires_grad=True)
+    F.layer_norm(xf, (N,), gf, bff, 1e-5).backward(dy.float().cpu())
+    close(dx1, xf.grad + (dres.float() if with_res else 0), 1.6e-2, 2e-2, "dx vs autograd")
+    close(dg1, gf.grad, 2e-3, 2e-3 * math.sqrt(M), "dgamma vs autograd")
+    close(db1, bff.grad, 2e-3, 2e-3 * math.sqrt(M), "dbeta vs autograd")
+    with pytest.raises(dh.DalleHipError):
+        dh.gemm_nt_lnbwd(Ad, K, Bd, K, M, 256, K, xd, gd, mean, rstd, rd, dx1, part)
+
+
 def test_full_row_kernel_residual_prefetch_changes_nothing():
     """[r05-prep] option ntr_prefetch: the residual rows of a full-row tile are pulled into L2 by LDS-DMA loads into a scratch block
     during the last k-steps -- results bit-identical with and without, K = 512 (16 k-steps: the prefetch starts at k-step 4) and
