@@ -138,6 +138,26 @@ def cpu_baseline_vae(p, grid, budget_s=15.0):
             "note": "CPU restatement of the reference; tensorflow itself cannot run here"}
 
 
+def per_gpu_batch(batch_arg, default, world, scaling):
+    """weak (the primary line): per-GPU batch fixed; strong: the GLOBAL batch fixed at the model's BASELINE value"""
+    B = batch_arg or default
+    if scaling == "strong":
+        assert B % world == 0, f"strong scaling: the global batch {B} must divide by the number of GPUs {world}"
+        B = B // world
+    return B
+
+
+def dp_schedule_summary(schedule, lay):
+    """what the JSON line says about the gradient exchange of one step: every piece in issue order (they follow
+    ParamLayout.ready_points, src/dalle_mtf/engine.py, cut to <= 64 MB by src/dp.py) and the bytes issued after the last backward
+    kernel -- the embedding gradients, which nothing is left to hide behind (tests/test_dp_gloo.py checks this against the layout)"""
+    tail0 = lay.offset["positional_embedding/wpe"]
+    return {"dp_pieces_per_step": len(schedule),
+            "dp_largest_piece_MB": (max(b - a for a, b in schedule) * 4 / 2 ** 20) if schedule else None,
+            "dp_piece_MB": [round((b - a) * 4 / 2 ** 20, 2) for a, b in schedule],
+            "dp_exposed_tail_MB": sum(b - a for a, b in schedule if a >= tail0) * 4 / 2 ** 20}
+
+
 def load_traffic(name, kernel_substr):
     """bytes/launch from this round's PMC passes, or None when absent / measured on another kernel"""
     path = os.path.join(ROOT, "profiles", f"{ROUND_TAG}_traffic_{name}.json")
@@ -178,10 +198,7 @@ def setup_dist(args):
 def bench_vae(args, world, rank, pg, comm):
     from src.vae_tf import DiscreteVAE
     p = json.load(open(os.path.join(ROOT, "configs", args.model + ".json")))
-    B = args.batch or VAE_MODELS[args.model]
-    if args.scaling == "strong":     # global batch fixed at the model's BASELINE value, as on the DALL-E path
-        assert B % world == 0, f"strong scaling: the global batch {B} must divide by the number of GPUs {world}"
-        B = B // world
+    B = per_gpu_batch(args.batch, VAE_MODELS[args.model], world, args.scaling)   # (strong: global batch fixed, as on the DALL-E path)
     vae = DiscreteVAE(num_tokens=p["num_tokens"], dimensions=p["dataset"]["image_size"], convblocks=p["convblocks"],
                       dim=p.get("dim") or 512, hidden_dim=p.get("hidden_dim") or 64, input_channels=p.get("n_channels") or 3,
                       use_bf16=bool(p.get("use_bf16")), recompute_grad=bool(p.get("recompute_grad")),
@@ -303,10 +320,7 @@ def main():
     CFG = MODELS[args.model]
     import torch.distributed as dist
     from src.dalle_mtf.engine import DalleEngine
-    B = args.batch or PER_GPU_BATCH
-    if args.scaling == "strong":
-        assert B % world == 0, f"strong scaling: the global batch {B} must divide by the number of GPUs {world}"
-        B = B // world
+    B = per_gpu_batch(args.batch, PER_GPU_BATCH, world, args.scaling)
     eng = DalleEngine(CFG["n_embd"], CFG["n_layers"], CFG["n_heads"], CFG["text_vocab_size"], CFG["image_vocab_size"],
                       CFG["text_seq_len"], CFG["image_seq_len"], batch_size=B, global_batch_size=B * world,
                       hparams=dict(HP, **({"dp_reserve_cus": args.reserve_cus} if args.reserve_cus is not None else {})),
@@ -371,13 +385,10 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "seq_len": S, "parallelism": f"dp{world}",
                        "dp_transport": eng.reducer.transport if world > 1 else None,
                        "dp_reserve_cus": eng.dp_reserve_cus if world > 1 else None,
-                       "dp_pieces_per_step": len(schedule) if world > 1 else None,
-                       "dp_largest_piece_MB": (max(b - a for a, b in schedule) * 4 / 2 ** 20) if (world > 1 and schedule) else None,
                        # every exchange piece in issue order, and the bytes issued after the last backward kernel (the embedding
                        # gradients): nothing is left to hide those behind, they are the exposed tail of the exchange
-                       "dp_piece_MB": [round((b - a) * 4 / 2 ** 20, 2) for a, b in schedule] if world > 1 else None,
-                       "dp_exposed_tail_MB": (sum(b - a for a, b in schedule if a >= eng.lay.offset["positional_embedding/wpe"]) * 4 / 2 ** 20)
-                       if world > 1 else None,
+                       **(dp_schedule_summary(schedule, eng.lay) if world > 1 else
+                          {"dp_pieces_per_step": None, "dp_largest_piece_MB": None, "dp_piece_MB": None, "dp_exposed_tail_MB": None}),
                        "final_loss": loss},
             "roofline": {"bound": "mfma",
                          "kernel": f"{kname} (vocabulary projection with the softmax-numerator epilogue, dmi_gemm_nt_softmax: M=B*S={B * S}, N={eng.Vp}, K={d})",

@@ -43,6 +43,8 @@ static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1; + no
 static int g_opt_cstream_min_mb = 256;
 static int g_opt_cstream_nt_min_mb = 1024;
 static int g_opt_ntr_prefetch = 0; // [r05-prep, not yet run on a GPU] full-row kernel: pull the tile's residual rows into L2 during the last k-steps
+static int g_opt_tn_split_dma = 0;   // weight-gradient kernels: next stage's DMA in two halves around the first MFMA batch (A/B)
+static int g_opt_res16 = 1;      // register epilogue: the residual as 16-byte pieces through the row swap (1) or 8-byte pieces in the accumulator layout (0)
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
 static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
                                  // tiles per CU), 2 whenever the shape allows it (tests, tools/kbench.py)
@@ -65,6 +67,8 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "cstream_nt_min_mb")) return g_opt_cstream_nt_min_mb;
   if (!strcmp(name, "nt8p_max_k")) return g_opt_nt8p_max_k;
   if (!strcmp(name, "relu_bits")) return g_opt_relu_bits;
+  if (!strcmp(name, "res16")) return g_opt_res16;
+  if (!strcmp(name, "tn_split_dma")) return g_opt_tn_split_dma;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
@@ -86,6 +90,8 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "cstream_nt_min_mb")) { g_opt_cstream_nt_min_mb = value; return 0; }
   if (!strcmp(name, "nt8p_max_k")) { g_opt_nt8p_max_k = value; return 0; }
   if (!strcmp(name, "relu_bits")) { g_opt_relu_bits = value; return 0; }
+  if (!strcmp(name, "res16")) { g_opt_res16 = value; return 0; }
+  if (!strcmp(name, "tn_split_dma")) { g_opt_tn_split_dma = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
@@ -328,10 +334,23 @@ __device__ __forceinline__ void epilogue_regs(const GemmArgs& a, const f32x4 (&a
     const bool mok = m < a.M;
     const int64_t off = (int64_t)m * a.ldc + nst;
     u32x2 rres[4];
-    if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {   // fp32 add before rounding: 8-B pieces in the accumulator layout
+    if constexpr (FLAGS & DMI_GEMM_RESIDUAL) {   // fp32 add before rounding, i.e. in the accumulator layout
+      if (a.pf & 2) {
+        // [r05] fetched as the two 16-byte pieces of the STORE layout (64 contiguous bytes per row and instruction) and brought into
+        // the accumulator layout by the row swap, which is its own inverse: same values, half the load instructions
+        u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
+        if (mok && ok0) q0 = *(const u32x4*)(a.residual + off);
+        if (mok && ok1) q1 = *(const u32x4*)(a.residual + off + 32);
+        unsigned R[4][2] = {{q0[0], q0[1]}, {q0[2], q0[3]}, {q1[0], q1[1]}, {q1[2], q1[3]}};
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        rres[j] = (mok && jok[j]) ? *(const u32x2*)(a.residual + (int64_t)m * a.ldc + ncol0 + 16 * j + 4 * g16) : u32x2{0u, 0u};
+        for (int d = 0; d < 2; ++d) { swap16(R[0][d], R[1][d]); swap16(R[2][d], R[3][d]); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rres[j] = u32x2{R[j][0], R[j][1]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          rres[j] = (mok && jok[j]) ? *(const u32x2*)(a.residual + (int64_t)m * a.ldc + ncol0 + 16 * j + 4 * g16) : u32x2{0u, 0u};
+      }
     }
     float rsc = 0.f;
     if constexpr (FLAGS & DMI_GEMM_ROWSCALE) rsc = mok ? a.rowscale[m] : 0.f;
@@ -1076,6 +1095,20 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& a, f32x4 (&acc)[RT][
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     unsigned P[RT][4][2];
+    unsigned R[RT][4][2];     // [r05] the residual as 16-byte pieces of the store layout, through the row swap (its own inverse)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const int m = m0 + wm * (RM / 2) + 16 * t + c16;
+      u32x4 q0 = {0u, 0u, 0u, 0u}, q1 = {0u, 0u, 0u, 0u};
+      if (a.residual && m < a.M) {
+        const bf16_t* rp = a.residual + (int64_t)m * a.ldc + ncolw + 64 * h + pcol;
+        q0 = *(const u32x4*)rp; q1 = *(const u32x4*)(rp + 32);
+      }
+      R[t][0][0] = q0[0]; R[t][0][1] = q0[1]; R[t][1][0] = q0[2]; R[t][1][1] = q0[3];
+      R[t][2][0] = q1[0]; R[t][2][1] = q1[1]; R[t][3][0] = q1[2]; R[t][3][1] = q1[3];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) { swap16(R[t][0][d], R[t][1][d]); swap16(R[t][2][d], R[t][3][d]); }
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int j = 4 * h + jj;
@@ -1085,9 +1118,7 @@ __device__ __forceinline__ void epilogue_ln(const GemmArgs& a, f32x4 (&acc)[RT][
       const float b2 = __uint_as_float(braw[1] << 16), b3 = __uint_as_float(braw[1] & 0xffff0000u);
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const int m = m0 + wm * (RM / 2) + 16 * t + c16;
-        u32x2 r = {0u, 0u};
-        if (a.residual && m < a.M) r = *(const u32x2*)(a.residual + (int64_t)m * a.ldc + n);
+        const u32x2 r = {R[t][jj][0], R[t][jj][1]};
         const float v0 = acc[t][j][0] + b0 + __uint_as_float(r[0] << 16);
         const float v1 = acc[t][j][1] + b1 + __uint_as_float(r[0] & 0xffff0000u);
         const float v2 = acc[t][j][2] + b2 + __uint_as_float(r[1] << 16);
@@ -1423,7 +1454,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
   // the stage buffers: the data is thrown away, the lines stay in L2 for the epilogue.  The counted waits below stay as they are
   // (vmcnt(PW - 1) then also retires these two younger loads' predecessors: conservative).
   constexpr int PFX = 2, PFN = (RM / 8 + PFX - 1) / PFX;          // rows per wave and k-step, k-steps
-  const bool pf_on = (FLAGS & DMI_GEMM_RESIDUAL) && a.pf != 0;
+  const bool pf_on = (FLAGS & DMI_GEMM_RESIDUAL) && (a.pf & 1) != 0;
   const int pf_s0 = ns - 2 - PFN > 0 ? ns - 2 - PFN : 0;
   const __amdgpu_buffer_rsrc_t rres_pf = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((pf_on ? a.residual : a.A) + (pf_on ? (int64_t)m0 * a.ldc : 0)), 0,
@@ -1737,6 +1768,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
       GemmArgs b = a;
       b.pf = (g_opt_ntr_prefetch && (FLAGS & DMI_GEMM_RESIDUAL) && a.residual != nullptr && a.ldc == a.N &&
               (int64_t)a.M * a.ldc < (1 << 30)) ? 1 : 0;
+      b.pf |= g_opt_res16 ? 2 : 0;     // residual rows as 16-byte pieces (A/B switch)
       gemm_ntr_kernel<FLAGS, RT><<<dim3((a.M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, st>>>(b);
       DMI_CHECK_LAUNCH("gemm_ntr");
       return DMI_OK;
@@ -2102,6 +2134,7 @@ struct TnArgs {
   int m_per_split;  // multiple of TN_BKM
   int64_t slab_stride;
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
+  int split_dma;            // [r05] the next stage's LDS-DMA pieces issued in two halves around the first MFMA batch (option tn_split_dma)
 };
 
 // Transposed fragment fetch through inline asm: hipcc orders the ds_read_tr16_b64 INTRINSIC behind every in-flight
@@ -2295,28 +2328,36 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-  auto stage = [&](int st) {
+  // part 0: the whole stage; [r05, option tn_split_dma] 1: the X half (+ the bias weights), 2: the Y half -- issued between the two MFMA
+  // batches of the k-step that runs meanwhile instead of as one burst of eight behind the barrier
+  auto stage = [&](int st, int part = 0) {
     char* base = smem_tn + st * 32768 + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if constexpr (CONV) {
-        const int m = cv_m + 16 * i;
-        const int ox = m & (cg->Wo - 1), oy = (m >> cg->lw) & (cg->Ho - 1), b = m >> (cg->lw + cg->lh);
-        const int iy = oy * cg->stride + cv_dy, ix = ox * cg->stride + cv_dx;
-        const bool ok = cv_colok && (m < mb + rows) && ((unsigned)iy < (unsigned)cg->H) && ((unsigned)ix < (unsigned)cg->W);
-        const int vo = ok ? ((b * cg->H + iy) * cg->W + ix) * cg->C * 2 + cv_coff : 0x7ffffff0;
-        glds16(rx, base + i * 4096, vo, 0);
-      } else {
-        glds16(rx, base + i * 4096, vox[i], 0);
-        vox[i] += stepx;
+      if (part != 2) {
+        if constexpr (CONV) {
+          const int m = cv_m + 16 * i;
+          const int ox = m & (cg->Wo - 1), oy = (m >> cg->lw) & (cg->Ho - 1), b = m >> (cg->lw + cg->lh);
+          const int iy = oy * cg->stride + cv_dy, ix = ox * cg->stride + cv_dx;
+          const bool ok = cv_colok && (m < mb + rows) && ((unsigned)iy < (unsigned)cg->H) && ((unsigned)ix < (unsigned)cg->W);
+          const int vo = ok ? ((b * cg->H + iy) * cg->W + ix) * cg->C * 2 + cv_coff : 0x7ffffff0;
+          glds16(rx, base + i * 4096, vo, 0);
+        } else {
+          glds16(rx, base + i * 4096, vox[i], 0);
+          vox[i] += stepx;
+        }
       }
-      glds16(ry, base + 16384 + i * 4096, voy[i], 0);
-      voy[i] += stepy;
+      if (part != 1) {
+        glds16(ry, base + 16384 + i * 4096, voy[i], 0);
+        voy[i] += stepy;
+      }
     }
-    if constexpr (CONV) cv_m += TN_BKM;
-    if (use_w) {   // block-uniform; every wave writes the same 256 bytes (uniform DMA count per wave)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 65536 + st * 256), 4, vow, 0, 0, 0);
-      vow += TN_BKM * 2;
+    if (part != 2) {
+      if constexpr (CONV) cv_m += TN_BKM;
+      if (use_w) {   // block-uniform; every wave writes the same 256 bytes (uniform DMA count per wave)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 65536 + st * 256), 4, vow, 0, 0, 0);
+        vow += TN_BKM * 2;
+      }
     }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
@@ -2337,7 +2378,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
       }
     }
   };
-  auto compute = [&](int st) {
+  auto compute = [&](int st, int nst = -1) {     // nst >= 0: the next stage's DMA goes out from inside this k-step (tn_split_dma)
     const unsigned base = lds0 + st * 32768;
     unsigned ax[4], ay[4];
 #pragma unroll
@@ -2354,7 +2395,9 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     tr16_wait<8>(X0, Y0);
     if (use_w) w16_keep(wf);
     tr16_issue<8192>(Y1, ay);
+    if (nst >= 0) { stage(nst, 1); __builtin_amdgcn_sched_barrier(0); }
     mfmas(X0, Y0, use_w ? __builtin_bit_cast(bf16x8, wf.w[0]) : ones);
+    if (nst >= 0) { __builtin_amdgcn_sched_barrier(0); stage(nst, 2); __builtin_amdgcn_sched_barrier(0); }
     tr16_wait<0>(X1, Y1);
     mfmas(X1, Y1, use_w ? __builtin_bit_cast(bf16x8, wf.w[1]) : ones);
     MFMA_PRIO(0);
@@ -2370,6 +2413,16 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     __syncthreads();
     if (a.dbg) tq1 = __builtin_readcyclecounter();
     int t = 0;
+    if (a.split_dma) {
+      for (; t + 2 <= nt; t += 2) {
+        compute(0, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < nt) compute(1, 0); else compute(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
+    } else
     for (; t + 2 <= nt; t += 2) {
       stage(1);
       compute(0);
@@ -2799,7 +2852,7 @@ extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_
     a.slab_stride = (S > 1) ? (int64_t)q.I * q.J : 0;
     a.bias_w = q.bias_weights;
     a.bias_part = q.dbias ? ((S > 1) ? bpart : q.dbias) : nullptr;
-    a.dbg = nullptr;
+    a.dbg = nullptr; a.split_dma = g_opt_tn_split_dma;
     if (S > 1) {
       if (q.dbias) { items[ni].slabs = bpart; items[ni].out = q.dbias; items[ni].nsplit = S; items[ni].n4 = q.J / 4; ++ni; }
       items[ni].slabs = slabs; items[ni].out = q.dW; items[ni].nsplit = S; items[ni].n4 = (int64_t)q.I * q.J / 4; ++ni;
@@ -2839,7 +2892,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
   a.C = (nsplit > 1) ? slabs : dW;
   a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-  a.dbg = g_dbg_buf;
+  a.dbg = g_dbg_buf; a.split_dma = g_opt_tn_split_dma;
   a.bias_w = bias_weights;
   float* bpart = (float*)((char*)workspace + slab_bytes);   // [nsplit][J] bias partials behind the slabs
   a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
@@ -3107,7 +3160,7 @@ extern "C" int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, 
   a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
   a.C = (nsplit > 1) ? slabs : dW;
   a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-  a.dbg = nullptr; a.bias_w = nullptr;
+  a.dbg = nullptr; a.bias_w = nullptr; a.split_dma = g_opt_tn_split_dma;
   float* bpart = (float*)((char*)workspace + slab_bytes);
   a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
   ConvGeom g;

@@ -306,8 +306,10 @@ class DalleEngine:
         # Measured (profiles/r04q_kbench_ln512.log, r04q_ab_fuse_ln.log): out-projection + norm_2 46.5 us fused vs 33.4 + 16.1 us,
         # FFN-2 + norm 98.9 vs 77.9 + 16.4 us, step 15.98 vs 15.95 ms -- with ONE tile per CU nothing overlaps the fused epilogue,
         # and its two 160-KB outputs per tile leave at the CU's ~14 B / clk store-issue rate, which costs what the HBM-bound
-        # standalone kernel costs.  Off by default; hparams["fuse_ln"] / DALLE_FUSE_LN=1 select it.
-        self.fuse_ln = bool(self.hp.get("fuse_ln", os.environ.get("DALLE_FUSE_LN", "0") != "0")) and d == 512
+        # standalone kernel costs.  (Round 4: off by default.)
+        # [r05] ON by default: with the residual rows fetched as 16-byte pieces (through the row swap) instead of 8-byte pieces in the
+        # accumulator layout the fused form wins: 14.92 -> 14.83 ms/step same-call (profiles/r05g_ab_fuse_ln.log)
+        self.fuse_ln = bool(self.hp.get("fuse_ln", os.environ.get("DALLE_FUSE_LN", "1") != "0")) and d == 512
         # FFN-2 -> next norm_1: not under recompute_grad, whose re-run of a block starts from the stored residual stream with a
         # standalone norm_1 (its statistics sum in another order; the re-run must reproduce the forward bit for bit)
         self.fuse_ln1 = self.fuse_ln and not self.recompute

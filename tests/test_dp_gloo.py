@@ -158,3 +158,50 @@ def test_transport_choice_is_collective(scenario, strict):
             assert r0["destroyed"] == [4242] and r1["destroyed"] == []
         else:      # nobody may enter the blocking communicator init when one rank could not load the library
             assert not r0["init_entered"] and not r1["init_entered"] and r0["destroyed"] == []
+
+
+def test_bench_schedule_summary_and_strong_scaling_follow_the_layout():
+    """bench.py's description of the exchange (`dp_piece_MB`, `dp_exposed_tail_MB`, `dp_largest_piece_MB`) against
+    ParamLayout.ready_points at the BASELINE architecture, and `--scaling strong`'s batch rule -- so that the first multi-GPU line
+    can be read against the layout without a GPU: pieces follow the ready points in order, none above 64 MB, the head's kernel +
+    bias first (before the head's input gradient runs), the embeddings last and alone in the exposed tail."""
+    import importlib.util
+    from src.dalle_mtf.engine import ParamLayout
+    from src.dp import GradReducer, MAX_BUCKET_BYTES
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cfg = bench.MODELS["dalle_example"]
+    d, L = cfg["n_embd"], cfg["n_layers"]
+    V = cfg["text_vocab_size"] + cfg["image_vocab_size"] + 1
+    S = cfg["text_seq_len"] + cfg["image_seq_len"]
+    lay = ParamLayout(d, L, cfg["n_heads"], V, S)
+    red = GradReducer.__new__(GradReducer)          # the piece rule only: no process group, no device
+    red.max_elems = MAX_BUCKET_BYTES // 4
+    sched, done = [], 0
+    for upto in lay.ready_points:
+        sched += red.pieces(done, upto)
+        done = upto
+    out = bench.dp_schedule_summary(sched, lay)
+    mb = 4 / 2 ** 20
+    assert sched[0][0] == 0 and sched[-1][1] == lay.total and all(a[1] == b[0] for a, b in zip(sched, sched[1:]))
+    assert set(lay.ready_points) <= {b for _, b in sched} and len(lay.ready_points) == L + 2
+    assert out["dp_pieces_per_step"] == len(sched) and len(out["dp_piece_MB"]) == len(sched)
+    assert abs(sum(out["dp_piece_MB"]) - lay.total * mb) < 0.01 * len(sched)
+    assert out["dp_largest_piece_MB"] <= 64.0 + 1e-9 and max(out["dp_piece_MB"]) <= 64.0
+    # the head's kernel + bias (26.0 M + 50.8 k parameters, 99.4 MB) go first, in two pieces
+    head = (lay.offset["to_logits/layer_norm/g"]) * mb
+    assert abs(sum(out["dp_piece_MB"][:2]) - head) < 0.02 and 99.0 < head < 100.0
+    # one piece per block (3.15 M parameters = 12.0 MB; the head LayerNorm's gain / bias ride with the last block)
+    blocks = out["dp_piece_MB"][2:2 + L]
+    assert all(11.9 < x < 12.2 for x in blocks), blocks
+    # the exposed tail = wpe + wte = (1280 + 50771) x 512 fp32 = 101.7 MB, issued after the embedding backward
+    tail = (lay.total - lay.offset["positional_embedding/wpe"]) * mb
+    assert abs(out["dp_exposed_tail_MB"] - tail) < 1e-6 and abs(tail - (S + V) * d * mb) < 0.01
+    assert abs(sum(out["dp_piece_MB"][2 + L:]) - tail) < 0.02
+    # --scaling: weak keeps the per-GPU batch, strong keeps the global batch
+    assert [bench.per_gpu_batch(0, 32, n, "weak") for n in (1, 2, 4, 8)] == [32, 32, 32, 32]
+    assert [bench.per_gpu_batch(0, 32, n, "strong") for n in (1, 2, 4, 8)] == [32, 16, 8, 4]
+    assert bench.per_gpu_batch(16, 32, 8, "strong") == 2
+    with pytest.raises(AssertionError):
+        bench.per_gpu_batch(0, 32, 3, "strong")
