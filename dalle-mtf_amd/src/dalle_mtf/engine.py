@@ -320,7 +320,12 @@ class DalleEngine:
         # full-row tiles): dxn is never written, 12 of the 13 ln_bwd launches of a dalle_example step disappear
         self.fuse_lnbwd = bool(self.hp.get("fuse_lnbwd", os.environ.get("DALLE_FUSE_LNBWD", "1") != "0")) and d == 512 and not self.defer_ln
         if self.fuse_lnbwd:
-            self.lnb_part = torch.empty(dh.gemm_nt_lnbwd_parts(M) * 2 * d, dtype=torch.float32, device=self.dev)
+            # one partial buffer per LayerNorm: the 2L gain / bias reduces run as ONE batched launch at the end of the backward
+            # (per block under data parallelism, where the exchange takes a block's gradients as soon as it is done)
+            self.lnb_batch = bool(self.hp.get("lnbwd_batch_finish", os.environ.get("DALLE_LNBWD_BATCH", "1") != "0"))
+            npart = dh.gemm_nt_lnbwd_parts(M) * 2 * d
+            self.lnb_part = [torch.empty(npart, dtype=torch.float32, device=self.dev) for _ in range(2 * L if self.lnb_batch else 1)]
+            self.ln_ws_final = torch.empty(int(dh.layernorm_bwd_workspace_bytes(M, d)) + 256, dtype=torch.uint8, device=self.dev)
 
     # ------------------------------------------------------------------ forward
     def _w(self, name):
@@ -656,6 +661,9 @@ class DalleEngine:
             if self.defer_ln:
                 dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, None, None, self.ln_ws[idx], M, d)
                 pend.append((self.ln_ws[idx], dg, db, M))
+            elif self.fuse_lnbwd and self.lnb_batch and idx == 2 * L:    # the head's LayerNorm joins the batched finish of the fused ones
+                dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, None, None, self.ln_ws_final, M, d)
+                pend.append((self.ln_ws_final, dg, db, M))
             else:
                 dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, dg, db, ws, M, d)
 
@@ -663,6 +671,17 @@ class DalleEngine:
             while pend:
                 dh.layernorm_bwd_finish_batch(pend[:16], d)
                 del pend[:16]
+
+        def lnbwd(idx, A, K, Wn, x, g, mean, rstd, dres, dx, dg, db):
+            """product + LayerNorm backward in one pass (dmi_gemm_nt_lnbwd); the gain / bias partials are summed right away or,
+            batched, with the other LayerNorms' at the next flush_ln()"""
+            if self.lnb_batch:
+                part = self.lnb_part[idx]
+                dh.gemm_nt_lnbwd(A, K, Wn, K, M, d, K, x, g, mean, rstd, dres, dx, part)
+                # (finish_batch derives the number of partial rows from a row count: 32 rows per partial row)
+                pend.append((part, dg, db, 32 * dh.gemm_nt_lnbwd_parts(M)))
+            else:
+                dh.gemm_nt_lnbwd(A, K, Wn, K, M, d, K, x, g, mean, rstd, dres, dx, self.lnb_part[0], dg=dg, db=db)
 
         ln_bwd(2 * L, self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"))
@@ -684,9 +703,8 @@ class DalleEngine:
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
                         dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
             if self.fuse_lnbwd:
-                dh.gemm_nt_lnbwd(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, M, d, 4 * d, self.x1[l],
-                                 self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb, self.lnb_part,
-                                 dg=self._gv(p + "norm_2/g"), db=self._gv(p + "norm_2/b"))
+                lnbwd(2 * l + 1, self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), self.x1[l], self._w(p + "norm_2/g"), st[2], st[3],
+                      dxa, dxb, self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
             else:
                 dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
                 ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
@@ -706,9 +724,8 @@ class DalleEngine:
             else:
                 self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
             if self.fuse_lnbwd:
-                dh.gemm_nt_lnbwd(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, M, d, 3 * d, self.X[l],
-                                 self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa, self.lnb_part,
-                                 dg=self._gv(p + "norm_1/g"), db=self._gv(p + "norm_1/b"))
+                lnbwd(2 * l, self.dqkv, 3 * d, self._w(p + "attn/qkv"), self.X[l], self._w(p + "norm_1/g"), st[0], st[1],
+                      dxb, dxa, self._gv(p + "norm_1/g"), self._gv(p + "norm_1/b"))
             else:
                 dh.gemm_nt(self.dqkv, 3 * d, self._w(p + "attn/qkv"), 3 * d, self.dxn, d, M, d, 3 * d)
                 ln_bwd(2 * l, self.dxn, self.X[l], self._w(p + "norm_1/g"), st[0], st[1], dxb, dxa,
