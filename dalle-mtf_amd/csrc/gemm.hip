@@ -1849,6 +1849,7 @@ extern "C" int dmi_gemm_nt(const uint16_t* A, int lda, const uint16_t* Bt, int l
   if (rc) return rc;
   DMI_REQUIRE(!(flags & DMI_GEMM_BIAS) || bias, "gemm_nt: bias flag without pointer");
   DMI_REQUIRE(!(flags & DMI_GEMM_RESIDUAL) || residual, "gemm_nt: residual flag without pointer");
+  DMI_REQUIRE((((uintptr_t)residual | (uintptr_t)relu_src) & 15) == 0, "gemm_nt: residual / relu_src must be 16-byte aligned");
   DMI_REQUIRE(!(flags & DMI_GEMM_RELU_MASK) || relu_src, "gemm_nt: relu-mask flag without pointer");
   DMI_REQUIRE(!(flags & DMI_GEMM_ROWSCALE) || rowscale, "gemm_nt: row-scale flag without pointer");
   GemmArgs a;
@@ -1946,8 +1947,8 @@ extern "C" int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt,
   if (rc) return rc;
   DMI_REQUIRE(x && gamma && mean && rstd && part, "gemm_nt_lnbwd: null pointer");
   DMI_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dres | (uintptr_t)part) & 15) == 0, "gemm_nt_lnbwd: operands must be 16-byte aligned");
-  if (N != 512 || (int64_t)N * ldb >= (1 << 30) || (int64_t)M * lda >= ((int64_t)1 << 31)) {
-    dmi_set_error("gemm_nt_lnbwd: the fused form needs N = 512 (one block owns whole rows); got N=%d", N);
+  if (N != 512 || (int64_t)N * ldb >= (1 << 30) || (int64_t)M * lda >= ((int64_t)1 << 31) || (int64_t)M * N * 2 >= ((int64_t)1 << 31)) {
+    dmi_set_error("gemm_nt_lnbwd: the fused form needs N = 512 (one block owns whole rows) and operands below 2 GiB; got M=%d N=%d", M, N);
     return DMI_ERR_UNSUPPORTED;
   }
   GemmArgs a;
