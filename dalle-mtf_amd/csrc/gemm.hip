@@ -139,6 +139,11 @@ struct GemmArgs {
   // ln_part = [2 * blocks][2 * N] fp32 partial gain | bias gradients (one row per 80-row half tile)
   const bf16_t* ln_x;
   float* ln_part;
+  // ... and, chained behind it in the same launch, the product that consumes dx (dmi_gemm_nt_lnbwd with B2): C2[M, 512] = dx . B2^T --
+  // a block owns whole rows of dx, i.e. the whole contraction range of its rows (the out-projection's input gradient d_o = dx . Wo^T)
+  const bf16_t* B2;
+  bf16_t* C2;
+  int ldb2;
 };
 #define GEMM_SOFTMAX 64   // internal epilogue flag of dmi_gemm_nt_softmax (not part of the public flag set)
 #define GEMM_RELU_BITS 128   // internal: with DMI_GEMM_RELU, also emit one bit per output (> 0) -- dmi_gemm_nt_relu_bits
@@ -1254,17 +1259,21 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
   auto hi = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
   // dy = bf16(acc) and x are kept PACKED (80 + 80 registers; the three passes unpack what they touch).  x and dres are fetched as the
   // 16-byte pieces of the store layout (64 contiguous bytes per row and instruction) and brought into the accumulator layout by the
-  // row swap, which is its own inverse -- as 8-byte pieces in the accumulator layout, re-read by every pass, the epilogue cost 50 us
-  unsigned dyp[RT][8][2], xp[RT][8][2], gmp[8][2];
-  const int vst = (r0 * 512 + ncolw + pcol) * 2;      // this lane's 16-byte piece: row of tile 0, column ncolw + pcol (+ 32; + 64 h)
+  // row swap, which is its own inverse -- as 8-byte pieces in the accumulator layout, re-read by every pass, the epilogue cost 50 us.
+  // The per-row statistics and gamma are re-loaded by the passes that use them (L1-hot) instead of living through all three.
+  unsigned dyp[RT][8][2], xp[RT][8][2];
+  const int vst = (r0 * 512 + ncolw + pcol) * 2;      // this lane's 16-byte piece: row of tile 0, column ncolw + pcol (+ 32; + 64 h); row tile t: + 16 KB t
   auto ld16 = [&](const __amdgpu_buffer_rsrc_t rsrc, int voff, int imm) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, imm, 0));
   };
+  auto ldmu = [&](int t) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmu, r0 * 4, 64 * t, 0)); };
+  auto ldrs = [&](int t) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, r0 * 4, 64 * t, 0)); };
+  const bf16_t* gp = a.ln_gamma + ncolw + 4 * g16;     // this lane's gamma pieces: + 16 j
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32x4 l0 = ld16(rx, vst + 16384 * t, 128 * h), l1 = ld16(rx, vst + 16384 * t, 128 * h + 64);
+      const u32x4 l0 = ld16(rx, vst, 16384 * t + 128 * h), l1 = ld16(rx, vst, 16384 * t + 128 * h + 64);
       xp[t][4 * h + 0][0] = l0[0]; xp[t][4 * h + 0][1] = l0[1]; xp[t][4 * h + 1][0] = l0[2]; xp[t][4 * h + 1][1] = l0[3];
       xp[t][4 * h + 2][0] = l1[0]; xp[t][4 * h + 2][1] = l1[1]; xp[t][4 * h + 3][0] = l1[2]; xp[t][4 * h + 3][1] = l1[3];
     }
@@ -1275,11 +1284,6 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
       dyp[t][j][0] = pack2bf(acc[t][j][0], acc[t][j][1]); dyp[t][j][1] = pack2bf(acc[t][j][2], acc[t][j][3]);
       asm volatile("" : "+v"(dyp[t][j][0]), "+v"(dyp[t][j][1]));   // materialised HERE (left alone, hipcc sinks the conversions to their uses and keeps the accumulators alive)
     }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const u32x2 graw = *(const u32x2*)(a.ln_gamma + ncolw + 16 * j + 4 * g16);
-    gmp[j][0] = graw[0]; gmp[j][1] = graw[1];
-  }
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -1293,35 +1297,37 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
     for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(dyp[t][j][0]), "+v"(dyp[t][j][1]), "+v"(xp[t][j][0]), "+v"(xp[t][j][1]));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(gmp[j][0]), "+v"(gmp[j][1]));
   };
   opaque();
   // ---- pass 1a: row sums s1 = sum gy, s2 = sum gy * xh, one row tile at a time
-  float mu[RT], rs[RT], s1[RT], s2[RT];
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    mu[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmu, (r0 + 16 * t) * 4, 0, 0));
-    rs[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (r0 + 16 * t) * 4, 0, 0));
-  }
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    float a1 = 0.f, a2 = 0.f;
+  float s1[RT], s2[RT];
+  {
+    unsigned gmp[8][2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
-      const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
-      const float gm[4] = {lo(gmp[j][0]), hi(gmp[j][0]), lo(gmp[j][1]), hi(gmp[j][1])};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float xh = (xv[e] - mu[t]) * rs[t];
-        const float gy = dy[e] * gm[e];
-        a1 += gy;
-        a2 += gy * xh;
-      }
+      const u32x2 graw = *(const u32x2*)(gp + 16 * j);
+      gmp[j][0] = graw[0]; gmp[j][1] = graw[1];
     }
-    s1[t] = a1; s2[t] = a2;
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      const float mu = ldmu(t), rs = ldrs(t);
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
+        const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
+        const float gm[4] = {lo(gmp[j][0]), hi(gmp[j][0]), lo(gmp[j][1]), hi(gmp[j][1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu) * rs;
+          const float gy = dy[e] * gm[e];
+          a1 += gy;
+          a2 += gy * xh;
+        }
+      }
+      s1[t] = a1; s2[t] = a2;
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // the four lane groups of a row, then its four waves through LDS (fixed order)
 #pragma unroll
@@ -1337,44 +1343,47 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
   opaque();
   // ---- pass 1b: column partials dgamma += dy * xh, dbeta += dy over this wave's 80 rows, one column tile at a time: the 16 rows of a
   // row tile are the 16 lanes of a DPP row (4 adds, fixed order), lane c16 == 0 of each lane group writes its four columns
+  {
+    float mu[RT], rs[RT];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RT; ++t) { mu[t] = ldmu(t); rs[t] = ldrs(t); }
 #pragma unroll
-    for (int t = 0; t < RT; ++t) {
-      const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
-      const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
+    for (int j = 0; j < 8; ++j) {
+      float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ab[e] += dy[e];
-        ag[e] += dy[e] * ((xv[e] - mu[t]) * rs[t]);
+      for (int t = 0; t < RT; ++t) {
+        const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
+        const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ab[e] += dy[e];
+          ag[e] += dy[e] * ((xv[e] - mu[t]) * rs[t]);
+        }
       }
-    }
-    f32x4 pg, pb;
+      f32x4 pg, pb;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { pg[e] = dpp_row_sum16(ag[e]); pb[e] = dpp_row_sum16(ab[e]); }
-    if (c16 == 0) {
-      const int n = ncolw + 16 * j + 4 * g16;
-      *(f32x4*)(prow + n) = pg;
-      *(f32x4*)(prow + 512 + n) = pb;
+      for (int e = 0; e < 4; ++e) { pg[e] = dpp_row_sum16(ag[e]); pb[e] = dpp_row_sum16(ab[e]); }
+      if (c16 == 0) {
+        const int n = ncolw + 16 * j + 4 * g16;
+        *(f32x4*)(prow + n) = pg;
+        *(f32x4*)(prow + 512 + n) = pb;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-#pragma unroll
-  for (int t = 0; t < RT; ++t) {
-    const f32x4 q0 = *(const f32x4*)(red + (r0 + 16 * t) * 8);
-    const f32x4 q1 = *(const f32x4*)(red + (r0 + 16 * t) * 8 + 4);
-    s1[t] = ((q0[0] + q0[2]) + (q1[0] + q1[2])) * invn;
-    s2[t] = ((q0[1] + q0[3]) + (q1[1] + q1[3])) * invn;
   }
   opaque();
   // ---- pass 2: dx = rstd * (dy * gamma - s1 - xh * s2) + dres, one (row tile, 64-column half) at a time; dres arrives as 16-byte pieces
   // and goes through the row swap into the accumulator layout, dx leaves through it
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
+    const f32x4 q0 = *(const f32x4*)(red + (r0 + 16 * t) * 8);
+    const f32x4 q1 = *(const f32x4*)(red + (r0 + 16 * t) * 8 + 4);
+    const float m1 = ((q0[0] + q0[2]) + (q1[0] + q1[2])) * invn;
+    const float m2 = ((q0[1] + q0[3]) + (q1[1] + q1[3])) * invn;
+    const float mu = ldmu(t), rs = ldrs(t);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32x4 l0 = ld16(rr, vst + 16384 * t, 128 * h), l1 = ld16(rr, vst + 16384 * t, 128 * h + 64);
+      const u32x4 l0 = ld16(rr, vst, 16384 * t + 128 * h), l1 = ld16(rr, vst, 16384 * t + 128 * h + 64);
       unsigned R[4][2] = {{l0[0], l0[1]}, {l0[2], l0[3]}, {l1[0], l1[1]}, {l1[2], l1[3]}};
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) { swap16(R[0][dd], R[1][dd]); swap16(R[2][dd], R[3][dd]); }
@@ -1382,23 +1391,24 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const int j = 4 * h + jj;
+        const u32x2 graw = *(const u32x2*)(gp + 16 * j);
         const float xv[4] = {lo(xp[t][j][0]), hi(xp[t][j][0]), lo(xp[t][j][1]), hi(xp[t][j][1])};
         const float rv[4] = {lo(R[jj][0]), hi(R[jj][0]), lo(R[jj][1]), hi(R[jj][1])};
-        const float gm[4] = {lo(gmp[j][0]), hi(gmp[j][0]), lo(gmp[j][1]), hi(gmp[j][1])};
+        const float gm[4] = {lo(graw[0]), hi(graw[0]), lo(graw[1]), hi(graw[1])};
         const float dy[4] = {lo(dyp[t][j][0]), hi(dyp[t][j][0]), lo(dyp[t][j][1]), hi(dyp[t][j][1])};
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float xh = (xv[e] - mu[t]) * rs[t];
-          o[e] = rs[t] * (dy[e] * gm[e] - s1[t] - xh * s2[t]) + rv[e];
+          const float xh = (xv[e] - mu) * rs;
+          o[e] = rs * (dy[e] * gm[e] - m1 - xh * m2) + rv[e];
         }
         P[jj][0] = pack2bf(o[0], o[1]);
         P[jj][1] = pack2bf(o[2], o[3]);
       }
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) { swap16(P[0][dd], P[1][dd]); swap16(P[2][dd], P[3][dd]); }
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[0][0], P[0][1], P[1][0], P[1][1]}, ry, vst + 16384 * t, 128 * h, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[2][0], P[2][1], P[3][0], P[3][1]}, ry, vst + 16384 * t, 128 * h + 64, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[0][0], P[0][1], P[1][0], P[1][1]}, ry, vst, 16384 * t + 128 * h, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[2][0], P[2][1], P[3][0], P[3][1]}, ry, vst, 16384 * t + 128 * h + 64, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1417,23 +1427,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
   const int m0 = blockIdx.x * RM;
-  const int ns = a.K / 32;
+  int ns = a.K / 32;
 
   const int c16 = lane & 15, g16 = lane >> 4;
-  const int offa = lds4_off(wm * (RM / 2) + c16, g16);                // 16-row tiles are 1024 B apart
-  const int offb = ABYTES + lds4_off(wn * 128 + c16, g16);
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda), 0,
-                                                                       (int)(((int64_t)(a.M - 1 - m0) * a.lda + a.K) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
+  int offa = lds4_off(wm * (RM / 2) + c16, g16);                // 16-row tiles are 1024 B apart
+  int offb = ABYTES + lds4_off(wn * 128 + c16, g16);
+  // (operands, offsets and the k-step count are variables: the chained form (LN == 3) runs the main loop a second time on other operands)
+  __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.A + (int64_t)m0 * a.lda), 0,
+                                                                 (int)(((int64_t)(a.M - 1 - m0) * a.lda + a.K) * 2), 0x00020000);
+  __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B, 0, (int)(((int64_t)(a.N - 1) * a.ldb + a.K) * 2), 0x00020000);
   // piece p = wid + 8 q of a k-step: p < NPA -> A rows 16 p .., else B rows 16 (p - NPA) ..; this lane's chunk = row 16 p' + lane / 4, 16-B piece lane % 4
   int vo[PW];
+  auto set_offsets = [&](int lda_, int ldb_, int ln) {
 #pragma unroll
-  for (int q = 0; q < PW; ++q) {
-    const int p = wid + 8 * q;
-    const bool isa = p < NPA;
-    const int row = 16 * (isa ? p : p - NPA) + (lane >> 2), pc = lane & 3;
-    vo[q] = (row * (isa ? a.lda : a.ldb) + 8 * (pc ^ lds4_swz(row))) * 2;
-  }
+    for (int q = 0; q < PW; ++q) {
+      const int p = wid + 8 * q;
+      const bool isa = p < NPA;
+      const int row = 16 * (isa ? p : p - NPA) + (ln >> 2), pc = ln & 3;
+      vo[q] = (row * (isa ? lda_ : ldb_) + 8 * (pc ^ lds4_swz(row))) * 2;
+    }
+  };
+  set_offsets(a.lda, a.ldb, lane);
   auto piece = [&](int buf, int q, int soff) {
     const int p = wid + 8 * q;             // wave-uniform
     if (p >= NP) return;
@@ -1493,30 +1507,68 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
     MFMA_PRIO(0);
   };
 
-  // prologue: k-steps 0 and 1
+  auto mainloop = [&]() {
+    // prologue: k-steps 0 and 1
 #pragma unroll
-  for (int q = 0; q < PW; ++q) piece(0, q, 0);
+    for (int q = 0; q < PW; ++q) piece(0, q, 0);
 #pragma unroll
-  for (int q = 0; q < PW; ++q) piece(1, q, ns > 1 ? 64 : 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // k-step s in buffer s % 3 while k-step s + 2 loads into buffer (s + 2) % 3 (past the end: k-step 0 again, read by nobody);
-  // the pieces of k-step s + 2 may stay in flight across the barrier, those of s + 1 must have landed: every wave issued PW
-  // pieces (or PW - 1) per k-step -> vmcnt(PW - 1) is conservative for both
-  for (int s = 0; s < ns; s += 3) {
+    for (int q = 0; q < PW; ++q) piece(1, q, ns > 1 ? 64 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // k-step s in buffer s % 3 while k-step s + 2 loads into buffer (s + 2) % 3 (past the end: k-step 0 again, read by nobody);
+    // the pieces of k-step s + 2 may stay in flight across the barrier, those of s + 1 must have landed: every wave issued PW
+    // pieces (or PW - 1) per k-step -> vmcnt(PW - 1) is conservative for both
+    for (int s = 0; s < ns; s += 3) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      if (s + u < ns) {
-        const int q = s + u + 2;
-        compute(u, (u + 2) % 3, (q < ns ? q : 0) * 64);
-        prefetch(s + u);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW - 1) : "memory");
-        __builtin_amdgcn_s_barrier();
+      for (int u = 0; u < 3; ++u) {
+        if (s + u < ns) {
+          const int q = s + u + 2;
+          compute(u, (u + 2) % 3, (q < ns ? q : 0) * 64);
+          prefetch(s + u);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW - 1) : "memory");
+          __builtin_amdgcn_s_barrier();
+        }
       }
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (LN != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  mainloop();
+  if constexpr (LN == 3) {
+    // LayerNorm backward, then the product that consumes dx, chained in the same launch: dx has just been stored by THIS block (whole
+    // rows = the whole contraction range of its rows), so it is read back from L2 as the A operand of a second main loop
+    __syncthreads();
+    {
+      int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      asm volatile("" : "+v"(lane_e));
+      epilogue_lnbwd<RT>(a, acc, smem, lane_e, wm, wn, m0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave's dx stores have been acknowledged ...
+    __syncthreads();                                      // ... before anybody's loads of them (and `red` in the stage buffers is dead)
+    ra = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_y + (int64_t)m0 * a.ln_ldy), 0, (int)(((int64_t)(a.M - 1 - m0) * a.ln_ldy + a.N) * 2), 0x00020000);
+    rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.B2, 0, (int)(((int64_t)(a.N - 1) * a.ldb2 + a.N) * 2), 0x00020000);
+    // everything per-lane of the second pass is recomputed from here -- the lane index from the exec mask (v_mbcnt), not from the
+    // work-item id -- so that nothing of the first pass lives through the epilogue (254 registers)
+    int lane2 = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane2));
+    offa = lds4_off(wm * (RM / 2) + (lane2 & 15), lane2 >> 4);
+    offb = ABYTES + lds4_off(wn * 128 + (lane2 & 15), lane2 >> 4);
+    set_offsets(a.ln_ldy, a.ldb2, lane2);
+    ns = a.N / 32;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mainloop();
+    GemmArgs b2 = a;
+    b2.C = a.C2; b2.ldc = a.N; b2.cpol = 0;
+    f32x4 lo[RT][4], hi[RT][4];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { lo[i][j] = acc[i][j]; hi[i][j] = acc[i][j + 4]; }
+    epilogue_regs<0, RT>(b2, lo, lane2, m0 + wm * (RM / 2), wn * 128);
+    epilogue_regs<0, RT>(b2, hi, lane2, m0 + wm * (RM / 2), wn * 128 + 64);
+  } else if constexpr (LN != 0) {
     // every wave's in-flight pieces have landed before anybody's partial sums overwrite the stage buffers (when (K / 32) % 3 == 2 the
     // last k-step's redundant reload targets buffer 0, where `red` lives: K = 256, 1024)
     __syncthreads();
@@ -1832,7 +1884,7 @@ static void fill_nt_args(GemmArgs& a, const uint16_t* A, int lda, const uint16_t
   a.tiles_m = (M + BM - 1) / BM; a.tiles_n = (N + BN - 1) / BN;
   a.k_per_split = K; a.slab_stride = 0; a.dbg = nullptr; a.pf = 0;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
-  a.ln_x = nullptr; a.ln_part = nullptr;
+  a.ln_x = nullptr; a.ln_part = nullptr; a.B2 = nullptr; a.C2 = nullptr; a.ldb2 = 0;
   const int64_t cbytes = ((int64_t)(M - 1) * ldc + N) * 2;     // bf16 outputs (the fp32 forms do not use the policy)
   // 1 (default): auto by size -- sc1 from cstream_min_mb, sc1 nt from cstream_nt_min_mb (a stream far larger than the 256-MB
   // Infinity Cache: the 4-GB softmax numerators; outputs of a few hundred MB that the next kernel re-reads were measured with
@@ -1942,7 +1994,7 @@ extern "C" int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, in
 extern "C" int dmi_gemm_nt_lnbwd_parts(int M) { return 2 * ((M + 159) / 160); }
 extern "C" int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, const uint16_t* x,
                                  const uint16_t* gamma, const float* mean, const float* rstd, const uint16_t* dres, uint16_t* dx,
-                                 float* part, void* stream) {
+                                 float* part, const uint16_t* B2, int ldb2, uint16_t* C2, void* stream) {
   int rc = check_nt(A, lda, Bt, ldb, dx, N, M, N, K);
   if (rc) return rc;
   DMI_REQUIRE(x && gamma && mean && rstd && part, "gemm_nt_lnbwd: null pointer");
@@ -1956,6 +2008,16 @@ extern "C" int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt,
   a.residual = dres; a.ln_x = x; a.ln_gamma = gamma; a.ln_mean = (float*)mean; a.ln_rstd = (float*)rstd; a.ln_y = dx; a.ln_ldy = N; a.ln_part = part;
   constexpr int RT = 5;
   constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
+  if (B2 || C2) {     // chained: C2[M, N] = dx . B2^T in the same launch (B2 [N, ldb2] bf16, K-contiguous like Bt; C2 row pitch N)
+    DMI_REQUIRE(B2 && C2 && ldb2 >= N && ldb2 % 8 == 0 && (((uintptr_t)B2 | (uintptr_t)C2) & 15) == 0 && (const void*)C2 != (const void*)dx,
+                "gemm_nt_lnbwd: bad chained product (B2 / ldb2 / C2)");
+    a.B2 = B2; a.ldb2 = ldb2; a.C2 = C2;
+    static bool attr3 = false;
+    if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr3 = true; }
+    gemm_ntr_kernel<0, RT, 3><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
+    DMI_CHECK_LAUNCH("gemm_nt_lnbwd (chained)");
+    return DMI_OK;
+  }
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
   gemm_ntr_kernel<0, RT, 2><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
@@ -3100,7 +3162,7 @@ extern "C" int dmi_conv_gemm_nt(const uint16_t* x, int B, int H, int W, int C, i
   a.rowscale = nullptr; a.rowshift = nullptr; a.rowsum_part = nullptr; a.relu_bits = nullptr;
   a.k_per_split = a.K; a.slab_stride = 0; a.dbg = nullptr; a.cpol = 0;
   a.ln_gamma = nullptr; a.ln_beta = nullptr; a.ln_y = nullptr; a.ln_mean = nullptr; a.ln_rstd = nullptr; a.ln_eps = 0.f; a.ln_ldy = 0;
-  a.ln_x = nullptr; a.ln_part = nullptr;
+  a.ln_x = nullptr; a.ln_part = nullptr; a.B2 = nullptr; a.C2 = nullptr; a.ldb2 = 0;
   ConvGeom g;
   g.H = H; g.W = W; g.C = C; g.Ho = Ho; g.Wo = Wo; g.stride = stride; g.ntaps = ntaps; g.lw = 0; g.lh = 0;
   for (int i = 0; i < CONV_MAX_TAPS; ++i) { g.dy[i] = i < ntaps ? dy[i] : 0; g.dx[i] = i < ntaps ? dx[i] : 0; }

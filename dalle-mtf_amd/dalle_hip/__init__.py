@@ -91,7 +91,7 @@ def _declare(L):
         "dmi_logits_f32": (I, [P, I, P, P, I, I, P]),
         "dmi_gemm_nt_ln": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, F, P, I, P, P, P]),
         "dmi_gemm_nt_lnbwd_parts": (I, [I]),
-        "dmi_gemm_nt_lnbwd": (I, [P, I, P, I, I, I, I, P, P, P, P, P, P, P, P]),
+        "dmi_gemm_nt_lnbwd": (I, [P, I, P, I, I, I, I, P, P, P, P, P, P, P, P, I, P, P]),
         "dmi_layernorm_bwd_finish_parts": (I, [P, I, P, P, I, P]),
         "dmi_relu_bits_bytes": (L64, [I, I]),
         "dmi_relu_bits_auto": (I, [I, I, I]),
@@ -237,14 +237,15 @@ def gemm_nt_lnbwd_parts(M):
     return int(lib().dmi_gemm_nt_lnbwd_parts(M))
 
 
-def gemm_nt_lnbwd(A, lda, Bt, ldb, M, N, K, x, gamma, mean, rstd, dres, dx, part, dg=None, db=None):
+def gemm_nt_lnbwd(A, lda, Bt, ldb, M, N, K, x, gamma, mean, rstd, dres, dx, part, dg=None, db=None, B2=None, ldb2=0, C2=None):
     """dx = LayerNorm-backward(x; gamma, mean, rstd)(A . Bt^T) + dres in one pass (N = 512: full-row tiles); part: fp32
-    [gemm_nt_lnbwd_parts(M), 2 N] partial gain | bias gradients.  dg / db given: the partials are summed into them right away."""
-    _dev(A, Bt, x, gamma, mean, rstd, dres, dx, part, dg, db)
+    [gemm_nt_lnbwd_parts(M), 2 N] partial gain | bias gradients.  dg / db given: the partials are summed into them right away.
+    B2 / C2: the product that consumes dx chained in the same launch, C2 = dx . B2^T."""
+    _dev(A, Bt, x, gamma, mean, rstd, dres, dx, part, dg, db, B2, C2)
     P = gemm_nt_lnbwd_parts(M)
     assert part.dtype == torch.float32 and part.numel() >= P * 2 * N
     _check(lib().dmi_gemm_nt_lnbwd(_p(A), lda, _p(Bt), ldb, M, N, K, _p(x), _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _p(part),
-                                   _stream()), "gemm_nt_lnbwd")
+                                   _p(B2), ldb2, _p(C2), _stream()), "gemm_nt_lnbwd")
     if dg is not None:
         _check(lib().dmi_layernorm_bwd_finish_parts(_p(part), P, _p(dg), _p(db), N, _stream()), "layernorm_bwd_finish_parts")
 

@@ -316,6 +316,7 @@ class DalleEngine:
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
         self.hp.setdefault("defer_reduces", os.environ.get("DALLE_DEFER_REDUCES", "1") != "0")
         self.hp.setdefault("wgrad_pair", os.environ.get("DALLE_WGRAD_PAIR", "1") != "0")
+        self.hp.setdefault("lnbwd_chain", os.environ.get("DALLE_LNBWD_CHAIN", "1") != "0")
         # [r05] LayerNorm backward fused into the two input-gradient products that feed a LayerNorm (dmi_gemm_nt_lnbwd: n_embd = 512,
         # full-row tiles): dxn is never written, 12 of the 13 ln_bwd launches of a dalle_example step disappear
         self.fuse_lnbwd = bool(self.hp.get("fuse_lnbwd", os.environ.get("DALLE_FUSE_LNBWD", "1") != "0")) and d == 512 and not self.defer_ln
@@ -672,16 +673,18 @@ class DalleEngine:
                 dh.layernorm_bwd_finish_batch(pend[:16], d)
                 del pend[:16]
 
-        def lnbwd(idx, A, K, Wn, x, g, mean, rstd, dres, dx, dg, db):
+        def lnbwd(idx, A, K, Wn, x, g, mean, rstd, dres, dx, dg, db, B2=None, C2=None):
             """product + LayerNorm backward in one pass (dmi_gemm_nt_lnbwd); the gain / bias partials are summed right away or,
-            batched, with the other LayerNorms' at the next flush_ln()"""
+            batched, with the other LayerNorms' at the next flush_ln().  B2 / C2: the product that consumes dx, chained in the
+            same launch (C2 = dx . B2^T)."""
+            kw = dict(B2=B2, ldb2=d, C2=C2) if B2 is not None else {}
             if self.lnb_batch:
                 part = self.lnb_part[idx]
-                dh.gemm_nt_lnbwd(A, K, Wn, K, M, d, K, x, g, mean, rstd, dres, dx, part)
+                dh.gemm_nt_lnbwd(A, K, Wn, K, M, d, K, x, g, mean, rstd, dres, dx, part, **kw)
                 # (finish_batch derives the number of partial rows from a row count: 32 rows per partial row)
                 pend.append((part, dg, db, 32 * dh.gemm_nt_lnbwd_parts(M)))
             else:
-                dh.gemm_nt_lnbwd(A, K, Wn, K, M, d, K, x, g, mean, rstd, dres, dx, self.lnb_part[0], dg=dg, db=db)
+                dh.gemm_nt_lnbwd(A, K, Wn, K, M, d, K, x, g, mean, rstd, dres, dx, self.lnb_part[0], dg=dg, db=db, **kw)
 
         ln_bwd(2 * L, self.dxn, self.X[L], self._w("to_logits/layer_norm/g"), self.statf[0], self.statf[1], None, dxa,
                self._gv("to_logits/layer_norm/g"), self._gv("to_logits/layer_norm/b"))
@@ -702,9 +705,11 @@ class DalleEngine:
                            relu_src=self.h[l])
             self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
                         dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
+            chain = self.fuse_lnbwd and self.hp["lnbwd_chain"]     # ... and the out-projection's input gradient d_o = dxb . Wo^T in the same launch
             if self.fuse_lnbwd:
                 lnbwd(2 * l + 1, self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), self.x1[l], self._w(p + "norm_2/g"), st[2], st[3],
-                      dxa, dxb, self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
+                      dxa, dxb, self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"),
+                      B2=self._w(p + "attn/o") if chain else None, C2=self.d_o if chain else None)
             else:
                 dh.gemm_nt(self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), 4 * d, self.dxn, d, M, d, 4 * d)
                 ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
@@ -714,7 +719,8 @@ class DalleEngine:
             if not pair:
                 self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
                             dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
-            dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
+            if not chain:
+                dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
             if pair:   # [r05] the out-projection and QKV kernels' gradients in ONE launch: 16 + 48 tiles fill the chip together
                 dh.gemm_tn_group([dict(X=self.o[l], ldx=d, dY=dxb, ldy=d, dW=self._gv(p + "attn/o"), I=d, J=d, ws=self.ws_blk[2],

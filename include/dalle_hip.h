@@ -200,11 +200,16 @@ int dmi_gemm_nt_mask_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ld
  * (dres nullable), i.e. what dmi_gemm_nt followed by dmi_layernorm_bwd computes, without writing / re-reading dy; the gain / bias
  * gradients leave as dmi_gemm_nt_lnbwd_parts(M) partial rows [2 N] fp32 in `part` (dgamma | dbeta), summed by
  * dmi_layernorm_bwd_finish_parts (fixed order).  N = 512 only (a block owns whole rows): DMI_ERR_UNSUPPORTED otherwise.  x, dres, dx have
- * row pitch N.  Differs from the two-kernel form only in the summation order of the reductions. */
+ * row pitch N.  Differs from the two-kernel form only in the summation order of the reductions.
+ * B2 / C2 (nullable, both or neither): the product that consumes dx chained in the same launch, C2[M, N] = bf16(dx . B2^T) with
+ * B2 [N, ldb2] (K-contiguous) -- norm_2's dx is the gradient of the attention branch's output, and its next consumer is the
+ * out-projection's input gradient d_o = dx . Wo^T (the backward of src/dalle_mtf/models.py:303-311): a block owns whole rows of
+ * dx, i.e. the whole contraction range of its rows, so it reads them back from L2 as the A operand of a second main loop.
+ * Bit-identical to dmi_gemm_nt on the stored dx. */
 int dmi_gemm_nt_lnbwd_parts(int M);
 int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, const uint16_t* x,
                       const uint16_t* gamma, const float* mean, const float* rstd, const uint16_t* dres, uint16_t* dx,
-                      float* part, void* stream);
+                      float* part, const uint16_t* B2, int ldb2, uint16_t* C2, void* stream);
 int dmi_layernorm_bwd_finish_parts(const float* part, int P, float* dg, float* db, int d, void* stream);
 int dmi_gemm_nt_softmax(const uint16_t* X, int ldx, const uint16_t* Wt, int ldw, const uint16_t* bias,
                         const float* rowshift, uint16_t* E, int lde, float* rowsum_part, int M, int N, int K, void* stream);

@@ -203,6 +203,17 @@ def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
     close(db1, bff.grad, 2e-3, 2e-3 * math.sqrt(M), "dbeta vs autograd")
     with pytest.raises(dh.DalleHipError):
         dh.gemm_nt_lnbwd(Ad, K, Bd, K, M, 256, K, xd, gd, mean, rstd, rd, dx1, part)
+    # chained form: the product that consumes dx in the same launch -- dx, the partials and C2 = dx . B2^T bit-identical to the
+    # unchained call followed by dmi_gemm_nt on the stored dx
+    B2 = rnd(N, N, scale=0.2, seed=7).to(DEV)
+    dx2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dg2, db2 = (torch.full((N,), float("nan"), dtype=torch.float32, device=DEV) for _ in range(2))
+    dh.gemm_nt_lnbwd(Ad, K, Bd, K, M, N, K, xd, gd, mean, rstd, rd, dx2, part, dg=dg2, db=db2, B2=B2, ldb2=N, C2=C2)
+    assert torch.equal(dx2, dx1) and torch.equal(dg2, dg1) and torch.equal(db2, db1)
+    Cref = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(dx1, N, B2, N, Cref, N, M, N, N)
+    assert torch.equal(C2, Cref), "the chained product must equal dmi_gemm_nt on the stored dx"
 
 
 def test_full_row_kernel_residual_prefetch_changes_nothing():
