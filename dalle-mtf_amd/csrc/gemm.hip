@@ -42,7 +42,6 @@ static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1; + no
                                  // tiles share), 2 always sc1, 3 always sc1 nt, 4 auto with sc1 only (A/B)
 static int g_opt_cstream_min_mb = 256;
 static int g_opt_cstream_nt_min_mb = 1024;
-static int g_opt_ntr_prefetch = 0; // [r05-prep, not yet run on a GPU] full-row kernel: pull the tile's residual rows into L2 during the last k-steps
 static int g_opt_tn_split_dma = 0;   // weight-gradient kernels: next stage's DMA in two halves around the first MFMA batch (A/B)
 static int g_opt_res16 = 1;      // register epilogue: the residual as 16-byte pieces through the row swap (1) or 8-byte pieces in the accumulator layout (0)
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
@@ -61,7 +60,6 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4_lds")) return g_opt_nt4_lds;
   if (!strcmp(name, "nt8p")) return g_opt_nt8p;
   if (!strcmp(name, "ntr")) return g_opt_ntr;
-  if (!strcmp(name, "ntr_prefetch")) return g_opt_ntr_prefetch;
   if (!strcmp(name, "cstream")) return g_opt_cstream;
   if (!strcmp(name, "cstream_min_mb")) return g_opt_cstream_min_mb;
   if (!strcmp(name, "cstream_nt_min_mb")) return g_opt_cstream_nt_min_mb;
@@ -84,7 +82,6 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4_lds")) { if (value < 49152 || value > 163840) return -1; g_opt_nt4_lds = value; return 0; }
   if (!strcmp(name, "nt8p")) { g_opt_nt8p = value; return 0; }
   if (!strcmp(name, "ntr")) { g_opt_ntr = value; return 0; }
-  if (!strcmp(name, "ntr_prefetch")) { g_opt_ntr_prefetch = value; return 0; }
   if (!strcmp(name, "cstream")) { g_opt_cstream = value; return 0; }
   if (!strcmp(name, "cstream_min_mb")) { g_opt_cstream_min_mb = value; return 0; }
   if (!strcmp(name, "cstream_nt_min_mb")) { g_opt_cstream_nt_min_mb = value; return 0; }
@@ -124,7 +121,7 @@ struct GemmArgs {
   int k_per_split;     // multiple of BK
   int64_t slab_stride;  // elements between split-K slabs of C (fp32)
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
-  int pf;                   // full-row kernel: prefetch the residual rows of the tile into L2 (0 / 1)
+  int pf;                   // bit 1: register epilogue fetches the residual as 16-byte pieces through the row swap (option res16)
   int cpol;                 // cache policy of the bf16 output stores: 0 plain, 1 sc1 (write-through, the line is not kept in the XCD's L2), 2 sc1 nt
   // fused LayerNorm of the output rows (dmi_gemm_nt_ln, full-row tiles only): Y = LN(C) * gamma + beta, row statistics
   const bf16_t* ln_gamma;
@@ -1462,27 +1459,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // [r05-prep] Residual prefetch (a.pf): inside the step the epilogue's residual rows come from HBM (in a hot micro-benchmark loop
-  // they sit in the Infinity Cache: 56 us per launch there, 77 us in the step).  During ten of the last k-steps every wave sends two
-  // of its RM / 8 residual rows (one row = 1 KB = one LDS-DMA instruction, no registers) into a 1-KB scratch block of LDS behind
-  // the stage buffers: the data is thrown away, the lines stay in L2 for the epilogue.  The counted waits below stay as they are
-  // (vmcnt(PW - 1) then also retires these two younger loads' predecessors: conservative).
-  constexpr int PFX = 2, PFN = (RM / 8 + PFX - 1) / PFX;          // rows per wave and k-step, k-steps
-  const bool pf_on = (FLAGS & DMI_GEMM_RESIDUAL) && (a.pf & 1) != 0;
-  const int pf_s0 = ns - 2 - PFN > 0 ? ns - 2 - PFN : 0;
-  const __amdgpu_buffer_rsrc_t rres_pf = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)((pf_on ? a.residual : a.A) + (pf_on ? (int64_t)m0 * a.ldc : 0)), 0,
-      pf_on ? (int)(((int64_t)(a.M - 1 - m0) * a.ldc + a.N) * 2) : 0, 0x00020000);
-  auto prefetch = [&](int s) {       // k-step s (wave-uniform)
-    const int k = s - pf_s0;
-    if (!pf_on || k < 0 || k >= PFN) return;
-#pragma unroll
-    for (int j = 0; j < PFX; ++j) {
-      const int row = wid + 8 * (PFX * k + j);
-      if (row < RM && m0 + row < a.M) glds16(rres_pf, smem + 3 * BUF + wid * 1024, lane * 16, row * a.ldc * 2);
-    }
-  };
-
+  // (A residual L2 prefetch during the last k-steps -- two rows per wave and k-step as LDS-DMA pieces into a scratch block -- was
+  // prepared in round 4 and measured neutral in round 5, alone with cold caches and in the step: the whole A operand is cold there,
+  // not just the residual.  Removed; profiles/r05a_ab_prefetch.log, r05a_kbench_n512_cold*.log.)
   // k-step in buffer `buf`: RT groups of 8 MFMAs (A fragment i against the eight B fragments); behind the groups go the pieces
   // of the load into buffer `nbuf`
   auto compute = [&](int buf, int nbuf, int soff) {
@@ -1524,7 +1503,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ntr_kernel(GemmArgs a) {
         if (s + u < ns) {
           const int q = s + u + 2;
           compute(u, (u + 2) % 3, (q < ns ? q : 0) * 64);
-          prefetch(s + u);
           asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW - 1) : "memory");
           __builtin_amdgcn_s_barrier();
         }
@@ -1814,13 +1792,11 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     if (g_opt_ntr && a.N == 512 && nsplit == 1 && a.k_per_split == a.K && a.K % 32 == 0 && (int64_t)a.N * a.ldb < (1 << 30) &&
         (g_opt_ntr == 2 || (a.M >= 160 * (num_cus() / 2) && a.K <= 4096 && g_opt_reserve_cus == 0))) {   // (the head's input gradient, K = 50816: 1.83 ms here vs 1.32 ms on 256x256 tiles)
       constexpr int RT = 5;
-      constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;     // + the residual prefetch's scratch (1 KB per wave)
+      constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
       static bool attrr = false;
       if (!attrr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<FLAGS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attrr = true; }
       GemmArgs b = a;
-      b.pf = (g_opt_ntr_prefetch && (FLAGS & DMI_GEMM_RESIDUAL) && a.residual != nullptr && a.ldc == a.N &&
-              (int64_t)a.M * a.ldc < (1 << 30)) ? 1 : 0;
-      b.pf |= g_opt_res16 ? 2 : 0;     // residual rows as 16-byte pieces (A/B switch)
+      b.pf = g_opt_res16 ? 2 : 0;     // residual rows as 16-byte pieces (A/B switch)
       gemm_ntr_kernel<FLAGS, RT><<<dim3((a.M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, st>>>(b);
       DMI_CHECK_LAUNCH("gemm_ntr");
       return DMI_OK;

@@ -216,30 +216,6 @@ def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
     assert torch.equal(C2, Cref), "the chained product must equal dmi_gemm_nt on the stored dx"
 
 
-def test_full_row_kernel_residual_prefetch_changes_nothing():
-    """[r05-prep] option ntr_prefetch: the residual rows of a full-row tile are pulled into L2 by LDS-DMA loads into a scratch block
-    during the last k-steps -- results bit-identical with and without, K = 512 (16 k-steps: the prefetch starts at k-step 4) and
-    K = 2048, M a multiple of the 160-row tile and not."""
-    for M, K in ((40960, 512), (1600, 2048), (1000, 512), (161, 64)):
-        A, Bt = rnd(M, K, seed=1).to(DEV), rnd(512, K, scale=0.1, seed=2).to(DEV)
-        bias, res = rnd(512, seed=3).to(DEV), rnd(M, 512, seed=4).to(DEV)
-        out = []
-        for pf in (0, 1):
-            dh.set_option("ntr", 2)
-            dh.set_option("ntr_prefetch", pf)
-            try:
-                C = torch.zeros(M, 512, dtype=torch.bfloat16, device=DEV)
-                dh.gemm_nt(A, K, Bt, K, C, 512, M, 512, K, dh.GEMM_BIAS | dh.GEMM_RESIDUAL, bias=bias, residual=res)
-                out.append(C)
-            finally:
-                dh.set_option("ntr", 1)
-                dh.set_option("ntr_prefetch", 0)
-        assert torch.equal(out[0], out[1]), (M, K)
-        close(out[1], _gemm_ref(A.cpu(), Bt.cpu(), bias.cpu(), residual=res.cpu()), 1.6e-2, 2e-2 * math.sqrt(K) * 0.1, "ntr prefetch")
-
-
-# ------------------------------------------------------------------ GEMMs
-
 def _gemm_ref(A, Bt, bias=None, relu=False, residual=None, relu_src=None):
     C = A.float() @ Bt.float().t()
     if bias is not None:
