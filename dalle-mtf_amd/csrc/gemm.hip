@@ -42,7 +42,6 @@ static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1; + no
                                  // tiles share), 2 always sc1, 3 always sc1 nt, 4 auto with sc1 only (A/B)
 static int g_opt_cstream_min_mb = 256;
 static int g_opt_cstream_nt_min_mb = 1024;
-static int g_opt_tn_split_dma = 0;   // weight-gradient kernels: next stage's DMA in two halves around the first MFMA batch (A/B)
 static int g_opt_res16 = 1;      // register epilogue: the residual as 16-byte pieces through the row swap (1) or 8-byte pieces in the accumulator layout (0)
 static int g_opt_ntr = 1;        // full-row 160x512 tiles for N = 512 products (gemm_ntr_kernel): 0 never, 1 auto, 2 whenever the shape allows
 static int g_opt_nt8p = 1;       // persistent 256x256 NT kernel with the register epilogue (gemm_nt8p_kernel): 0 never, 1 auto (short K, >= 2
@@ -66,7 +65,6 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt8p_max_k")) return g_opt_nt8p_max_k;
   if (!strcmp(name, "relu_bits")) return g_opt_relu_bits;
   if (!strcmp(name, "res16")) return g_opt_res16;
-  if (!strcmp(name, "tn_split_dma")) return g_opt_tn_split_dma;
   if (!strcmp(name, "skinny")) return g_opt_skinny;
   if (!strcmp(name, "nt8_min_k")) return g_opt_nt8_min_k;
   if (!strcmp(name, "tn8")) return g_opt_tn8;
@@ -88,7 +86,6 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt8p_max_k")) { g_opt_nt8p_max_k = value; return 0; }
   if (!strcmp(name, "relu_bits")) { g_opt_relu_bits = value; return 0; }
   if (!strcmp(name, "res16")) { g_opt_res16 = value; return 0; }
-  if (!strcmp(name, "tn_split_dma")) { g_opt_tn_split_dma = value; return 0; }
   if (!strcmp(name, "skinny")) { g_opt_skinny = value; return 0; }
   if (!strcmp(name, "nt8_min_k")) { g_opt_nt8_min_k = value; return 0; }
   if (!strcmp(name, "tn8")) { g_opt_tn8 = value; return 0; }
@@ -2173,7 +2170,6 @@ struct TnArgs {
   int m_per_split;  // multiple of TN_BKM
   int64_t slab_stride;
   unsigned long long* dbg;  // optional per-block phase timestamps (tools/phases.py); nullptr in production
-  int split_dma;            // [r05] the next stage's LDS-DMA pieces issued in two halves around the first MFMA batch (option tn_split_dma)
 };
 
 // Transposed fragment fetch through inline asm: hipcc orders the ds_read_tr16_b64 INTRINSIC behind every in-flight
@@ -2367,36 +2363,28 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
   const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_u);
 
-  // part 0: the whole stage; [r05, option tn_split_dma] 1: the X half (+ the bias weights), 2: the Y half -- issued between the two MFMA
-  // batches of the k-step that runs meanwhile instead of as one burst of eight behind the barrier
-  auto stage = [&](int st, int part = 0) {
+  auto stage = [&](int st) {
     char* base = smem_tn + st * 32768 + wid * 1024;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (part != 2) {
-        if constexpr (CONV) {
-          const int m = cv_m + 16 * i;
-          const int ox = m & (cg->Wo - 1), oy = (m >> cg->lw) & (cg->Ho - 1), b = m >> (cg->lw + cg->lh);
-          const int iy = oy * cg->stride + cv_dy, ix = ox * cg->stride + cv_dx;
-          const bool ok = cv_colok && (m < mb + rows) && ((unsigned)iy < (unsigned)cg->H) && ((unsigned)ix < (unsigned)cg->W);
-          const int vo = ok ? ((b * cg->H + iy) * cg->W + ix) * cg->C * 2 + cv_coff : 0x7ffffff0;
-          glds16(rx, base + i * 4096, vo, 0);
-        } else {
-          glds16(rx, base + i * 4096, vox[i], 0);
-          vox[i] += stepx;
-        }
+      if constexpr (CONV) {
+        const int m = cv_m + 16 * i;
+        const int ox = m & (cg->Wo - 1), oy = (m >> cg->lw) & (cg->Ho - 1), b = m >> (cg->lw + cg->lh);
+        const int iy = oy * cg->stride + cv_dy, ix = ox * cg->stride + cv_dx;
+        const bool ok = cv_colok && (m < mb + rows) && ((unsigned)iy < (unsigned)cg->H) && ((unsigned)ix < (unsigned)cg->W);
+        const int vo = ok ? ((b * cg->H + iy) * cg->W + ix) * cg->C * 2 + cv_coff : 0x7ffffff0;
+        glds16(rx, base + i * 4096, vo, 0);
+      } else {
+        glds16(rx, base + i * 4096, vox[i], 0);
+        vox[i] += stepx;
       }
-      if (part != 1) {
-        glds16(ry, base + 16384 + i * 4096, voy[i], 0);
-        voy[i] += stepy;
-      }
+      glds16(ry, base + 16384 + i * 4096, voy[i], 0);
+      voy[i] += stepy;
     }
-    if (part != 2) {
-      if constexpr (CONV) cv_m += TN_BKM;
-      if (use_w) {   // block-uniform; every wave writes the same 256 bytes (uniform DMA count per wave)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 65536 + st * 256), 4, vow, 0, 0, 0);
-        vow += TN_BKM * 2;
-      }
+    if constexpr (CONV) cv_m += TN_BKM;
+    if (use_w) {   // block-uniform; every wave writes the same 256 bytes (uniform DMA count per wave)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 65536 + st * 256), 4, vow, 0, 0, 0);
+      vow += TN_BKM * 2;
     }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
@@ -2417,7 +2405,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
       }
     }
   };
-  auto compute = [&](int st, int nst = -1) {     // nst >= 0: the next stage's DMA goes out from inside this k-step (tn_split_dma)
+  auto compute = [&](int st) {
     const unsigned base = lds0 + st * 32768;
     unsigned ax[4], ay[4];
 #pragma unroll
@@ -2434,9 +2422,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     tr16_wait<8>(X0, Y0);
     if (use_w) w16_keep(wf);
     tr16_issue<8192>(Y1, ay);
-    if (nst >= 0) { stage(nst, 1); __builtin_amdgcn_sched_barrier(0); }
     mfmas(X0, Y0, use_w ? __builtin_bit_cast(bf16x8, wf.w[0]) : ones);
-    if (nst >= 0) { __builtin_amdgcn_sched_barrier(0); stage(nst, 2); __builtin_amdgcn_sched_barrier(0); }
     tr16_wait<0>(X1, Y1);
     mfmas(X1, Y1, use_w ? __builtin_bit_cast(bf16x8, wf.w[1]) : ones);
     MFMA_PRIO(0);
@@ -2452,16 +2438,6 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
     __syncthreads();
     if (a.dbg) tq1 = __builtin_readcyclecounter();
     int t = 0;
-    if (a.split_dma) {
-      for (; t + 2 <= nt; t += 2) {
-        compute(0, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 2 < nt) compute(1, 0); else compute(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-    } else
     for (; t + 2 <= nt; t += 2) {
       stage(1);
       compute(0);
@@ -2891,7 +2867,7 @@ extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_
     a.slab_stride = (S > 1) ? (int64_t)q.I * q.J : 0;
     a.bias_w = q.bias_weights;
     a.bias_part = q.dbias ? ((S > 1) ? bpart : q.dbias) : nullptr;
-    a.dbg = nullptr; a.split_dma = g_opt_tn_split_dma;
+    a.dbg = nullptr;
     if (S > 1) {
       if (q.dbias) { items[ni].slabs = bpart; items[ni].out = q.dbias; items[ni].nsplit = S; items[ni].n4 = q.J / 4; ++ni; }
       items[ni].slabs = slabs; items[ni].out = q.dW; items[ni].nsplit = S; items[ni].n4 = (int64_t)q.I * q.J / 4; ++ni;
@@ -2931,7 +2907,7 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
   a.C = (nsplit > 1) ? slabs : dW;
   a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-  a.dbg = g_dbg_buf; a.split_dma = g_opt_tn_split_dma;
+  a.dbg = g_dbg_buf;
   a.bias_w = bias_weights;
   float* bpart = (float*)((char*)workspace + slab_bytes);   // [nsplit][J] bias partials behind the slabs
   a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
@@ -3199,7 +3175,7 @@ extern "C" int dmi_conv_wgrad_tn(const uint16_t* x, int B, int H, int W, int C, 
   a.m_per_split = (int)round_up64((M + nsplit - 1) / nsplit, TN_BKM);
   a.C = (nsplit > 1) ? slabs : dW;
   a.slab_stride = (nsplit > 1) ? (int64_t)I * J : 0;
-  a.dbg = nullptr; a.bias_w = nullptr; a.split_dma = g_opt_tn_split_dma;
+  a.dbg = nullptr; a.bias_w = nullptr;
   float* bpart = (float*)((char*)workspace + slab_bytes);
   a.bias_part = dbias ? ((nsplit > 1) ? bpart : dbias) : nullptr;
   ConvGeom g;
