@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the ntr_prefetch option it toggles was removed after this call measured it neutral)
 # round 5, call A: the tests that round 4 left unrun, the prepared switches (A/B), the cold-cache rows, a baseline profile
 cd /root/repo; mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q -s --timeout=1200 -k "deferred or prefetch or digest or production_dispatch or nt_ln or nt8p_persistent or full_row" 2>&1 | grep -v "amdgpu\|Hostname\|Librccl" | tail -60 > gpurun_out/r05a_pytest.log
