@@ -1260,14 +1260,17 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
   auto ld16 = [&](const __amdgpu_buffer_rsrc_t rsrc, int voff, int imm) {
     return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, imm, 0));
   };
-  auto ldmu = [&](int t) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmu, r0 * 4, 64 * t, 0)); };
-  auto ldrs = [&](int t) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, r0 * 4, 64 * t, 0)); };
+  // [r06] the row-tile term belongs in the VECTOR offset: the descriptor's range check covers voffset + the instruction's immediate, NOT the
+  // scalar offset -- with 16384 t (64 t) in soffset a lane whose tile-0 row is below M read and STORED its rows of the tiles t >= 1 past M
+  // unchecked (advisor finding, round 5; ragged last tile only, M % 160 != 0).  The compiler folds the small column term into the immediate.
+  auto ldmu = [&](int t) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmu, r0 * 4 + 64 * t, 0, 0)); };
+  auto ldrs = [&](int t) { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, r0 * 4 + 64 * t, 0, 0)); };
   const bf16_t* gp = a.ln_gamma + ncolw + 4 * g16;     // this lane's gamma pieces: + 16 j
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32x4 l0 = ld16(rx, vst, 16384 * t + 128 * h), l1 = ld16(rx, vst, 16384 * t + 128 * h + 64);
+      const u32x4 l0 = ld16(rx, vst + 16384 * t + 128 * h, 0), l1 = ld16(rx, vst + 16384 * t + 128 * h + 64, 0);
       xp[t][4 * h + 0][0] = l0[0]; xp[t][4 * h + 0][1] = l0[1]; xp[t][4 * h + 1][0] = l0[2]; xp[t][4 * h + 1][1] = l0[3];
       xp[t][4 * h + 2][0] = l1[0]; xp[t][4 * h + 2][1] = l1[1]; xp[t][4 * h + 3][0] = l1[2]; xp[t][4 * h + 3][1] = l1[3];
     }
@@ -1377,7 +1380,7 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
     const float mu = ldmu(t), rs = ldrs(t);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32x4 l0 = ld16(rr, vst, 16384 * t + 128 * h), l1 = ld16(rr, vst, 16384 * t + 128 * h + 64);
+      const u32x4 l0 = ld16(rr, vst + 16384 * t + 128 * h, 0), l1 = ld16(rr, vst + 16384 * t + 128 * h + 64, 0);
       unsigned R[4][2] = {{l0[0], l0[1]}, {l0[2], l0[3]}, {l1[0], l1[1]}, {l1[2], l1[3]}};
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) { swap16(R[0][dd], R[1][dd]); swap16(R[2][dd], R[3][dd]); }
@@ -1401,8 +1404,8 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
       }
 #pragma unroll
       for (int dd = 0; dd < 2; ++dd) { swap16(P[0][dd], P[1][dd]); swap16(P[2][dd], P[3][dd]); }
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[0][0], P[0][1], P[1][0], P[1][1]}, ry, vst, 16384 * t + 128 * h, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[2][0], P[2][1], P[3][0], P[3][1]}, ry, vst, 16384 * t + 128 * h + 64, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[0][0], P[0][1], P[1][0], P[1][1]}, ry, vst + 16384 * t + 128 * h, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{P[2][0], P[2][1], P[3][0], P[3][1]}, ry, vst + 16384 * t + 128 * h + 64, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1789,7 +1792,7 @@ static int launch_nt(const GemmArgs& a, int nsplit, hipStream_t st) {
     if (g_opt_ntr && a.N == 512 && nsplit == 1 && a.k_per_split == a.K && a.K % 32 == 0 && (int64_t)a.N * a.ldb < (1 << 30) &&
         (g_opt_ntr == 2 || (a.M >= 160 * (num_cus() / 2) && a.K <= 4096 && g_opt_reserve_cus == 0))) {   // (the head's input gradient, K = 50816: 1.83 ms here vs 1.32 ms on 256x256 tiles)
       constexpr int RT = 5;
-      constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
+      constexpr int LDSB = 3 * (32 * RT * 64 + 32768);
       static bool attrr = false;
       if (!attrr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<FLAGS, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attrr = true; }
       GemmArgs b = a;
@@ -1934,6 +1937,16 @@ extern "C" int dmi_gemm_nt_mask_bits(const uint16_t* A, int lda, const uint16_t*
   return launch_nt8p<GEMM_MASK_BITS>(a, (hipStream_t)stream);
 }
 
+// 1 where dmi_gemm_nt_ln / dmi_gemm_nt_lnbwd accept a product [M, K] x [N, K]^T with K-contiguous operands (lda = ldb = K) AND the
+// library would run it on full-row tiles itself: N = 512 (one block owns whole rows), every operand inside the 32-bit buffer offsets
+// of gemm_ntr_kernel, no CUs reserved for a concurrent exchange (launch_nt keeps the 128x128 kernel then).  Callers gate the fused
+// forms on it when they size their buffers and keep the two-kernel path otherwise (advisor finding, round 5).
+extern "C" int dmi_gemm_nt_ln_auto(int M, int N, int K) {
+  if (M <= 0 || N != 512 || K <= 0 || K % BK != 0) return 0;
+  if ((int64_t)N * K >= (1 << 30) || (int64_t)M * K >= ((int64_t)1 << 31) || (int64_t)M * N * 2 >= ((int64_t)1 << 31)) return 0;
+  return g_opt_reserve_cus == 0 ? 1 : 0;
+}
+
 // Product with N = 512 outputs + bias + residual, and the LayerNorm of the result in the same pass (full-row tiles, see
 // gemm_ntr_kernel / epilogue_ln): C = bf16(A . Bt^T + bias + residual) [M, 512], Y = bf16(LN(C) * gamma + beta), mean / rstd fp32 [M].
 extern "C" int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, uint16_t* C, int ldc, int M, int N, int K,
@@ -1953,7 +1966,7 @@ extern "C" int dmi_gemm_nt_ln(const uint16_t* A, int lda, const uint16_t* Bt, in
   a.bias = bias; a.residual = residual;
   a.ln_gamma = gamma; a.ln_beta = beta; a.ln_y = Y; a.ln_ldy = ldy; a.ln_mean = mean; a.ln_rstd = rstd; a.ln_eps = eps;
   constexpr int RT = 5;
-  constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
+  constexpr int LDSB = 3 * (32 * RT * 64 + 32768);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<0, RT, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB); attr = true; }
   gemm_ntr_kernel<0, RT, 1><<<dim3((M + 32 * RT - 1) / (32 * RT)), dim3(512), LDSB, (hipStream_t)stream>>>(a);
@@ -1980,7 +1993,7 @@ extern "C" int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt,
   fill_nt_args(a, A, lda, Bt, ldb, dx, N, M, N, K);
   a.residual = dres; a.ln_x = x; a.ln_gamma = gamma; a.ln_mean = (float*)mean; a.ln_rstd = (float*)rstd; a.ln_y = dx; a.ln_ldy = N; a.ln_part = part;
   constexpr int RT = 5;
-  constexpr int LDSB = 3 * (32 * RT * 64 + 32768) + 8192;
+  constexpr int LDSB = 3 * (32 * RT * 64 + 32768);
   if (B2 || C2) {     // chained: C2[M, N] = dx . B2^T in the same launch (B2 [N, ldb2] bf16, K-contiguous like Bt; C2 row pitch N)
     DMI_REQUIRE(B2 && C2 && ldb2 >= N && ldb2 % 8 == 0 && (((uintptr_t)B2 | (uintptr_t)C2) & 15) == 0 && (const void*)C2 != (const void*)dx,
                 "gemm_nt_lnbwd: bad chained product (B2 / ldb2 / C2)");

@@ -95,6 +95,7 @@ def _declare(L):
         "dmi_layernorm_bwd_finish_parts": (I, [P, I, P, P, I, P]),
         "dmi_relu_bits_bytes": (L64, [I, I]),
         "dmi_relu_bits_auto": (I, [I, I, I]),
+        "dmi_gemm_nt_ln_auto": (I, [I, I, I]),
         "dmi_gemm_nt_relu_bits": (I, [P, I, P, I, P, I, I, I, I, P, P, P]),
         "dmi_gemm_nt_mask_bits": (I, [P, I, P, I, P, I, I, I, I, P, P]),
         "dmi_sumsq_workspace_bytes": (L64, [L64]),
@@ -252,6 +253,11 @@ def gemm_nt_lnbwd(A, lda, Bt, ldb, M, N, K, x, gamma, mean, rstd, dres, dx, part
 
 def relu_bits_bytes(M, N):
     return int(lib().dmi_relu_bits_bytes(M, N))
+
+
+def gemm_nt_ln_auto(M, N, K):
+    """True where gemm_nt_ln / gemm_nt_lnbwd accept the shape and the library would pick the full-row kernel itself."""
+    return bool(lib().dmi_gemm_nt_ln_auto(M, N, K))
 
 
 def relu_bits_auto(M, N, K):

@@ -126,16 +126,16 @@ class DalleEngine:
         self.pb = torch.zeros(n, **b16)
         self.pbt = torch.zeros(self.lay.t_total, **b16)
         self.global_step = 0
-        self._alloc_activations()
-        # gradient exchange: RCCL behind the C ABI when `comm` (dp.init_comm) is given, torch.distributed otherwise
-        self.reducer = GradReducer(self.g, world_size, comm=comm, pg=process_group)
         # The exchange's RCCL channels run beside the BACKWARD: there the persistent kernels leave CUs for them (a block of a
         # one-block-per-CU kernel whose CU an intruder holds starts when the others have finished: the launch takes twice as long --
         # measured with the token sort as the intruder).  16 CUs cost 3.7 % of a single-GPU step when applied to
         # the whole step, so the option is set for the backward only; 0 = off.  Unmeasured on a multi-GPU node, hence OFF by
-        # default (it also hands the full-row products back to the 128x128 kernel): hparams["dp_reserve_cus"], DALLE_DP_RESERVE_CUS
-        # or bench.py --reserve-cus select it for the first multi-GPU A/B.
+        # default (it also hands the full-row products back to the 128x128 kernel and turns the fused LayerNorm forms off):
+        # hparams["dp_reserve_cus"], DALLE_DP_RESERVE_CUS or bench.py --reserve-cus select it for the first multi-GPU A/B.
         self.dp_reserve_cus = int(self.hp.get("dp_reserve_cus", os.environ.get("DALLE_DP_RESERVE_CUS", "0"))) if world_size > 1 else 0
+        self._alloc_activations()
+        # gradient exchange: RCCL behind the C ABI when `comm` (dp.init_comm) is given, torch.distributed otherwise
+        self.reducer = GradReducer(self.g, world_size, comm=comm, pg=process_group)
 
     # ------------------------------------------------------------------ parameter access
     def view(self, buf, name):
@@ -294,13 +294,6 @@ class DalleEngine:
         self.ws_blk = [torch.empty(int(dh.gemm_tn_workspace_bytes(M, i_, j_)) + 256, dtype=torch.uint8, device=self.dev)
                        for i_, j_ in ((4 * d, d), (d, 4 * d), (d, d), (d, 3 * d))]
         self.deferred = dh.DeferredReduces()
-        # [r05-prep, NOT YET RUN ON A GPU] the gain / bias gradient reduces of the 2L + 1 LayerNorm backwards deferred into batched
-        # launches (dmi_layernorm_bwd_finish_batch): one at the end of the backward on one GPU, one per block under data parallelism
-        # (the exchange takes a block's gradients as soon as its backward is done).  13 launches of ~7 us -> 1 at dalle_example.
-        self.defer_ln = bool(self.hp.get("defer_ln_finish", os.environ.get("DALLE_DEFER_LN", "0") != "0"))
-        if self.defer_ln:
-            nb = int(dh.layernorm_bwd_workspace_bytes(M, d)) + 256
-            self.ln_ws = [torch.empty(nb, dtype=torch.uint8, device=self.dev) for _ in range(2 * L + 1)]
         # tuning switch: hparams win, the environment variable gives the default (A/B runs: tools/ab_env.sh)
         # LayerNorm fused into the products that feed it (dmi_gemm_nt_ln): the full-row tiles exist for n_embd = 512
         # Measured (profiles/r04q_kbench_ln512.log, r04q_ab_fuse_ln.log): out-projection + norm_2 46.5 us fused vs 33.4 + 16.1 us,
@@ -309,7 +302,11 @@ class DalleEngine:
         # standalone kernel costs.  (Round 4: off by default.)
         # [r05] ON by default: with the residual rows fetched as 16-byte pieces (through the row swap) instead of 8-byte pieces in the
         # accumulator layout the fused form wins: 14.92 -> 14.83 ms/step same-call (profiles/r05g_ab_fuse_ln.log)
-        self.fuse_ln = bool(self.hp.get("fuse_ln", os.environ.get("DALLE_FUSE_LN", "1") != "0")) and d == 512
+        # [r06] both fused LayerNorm forms are gated on the library's own predicate (dmi_gemm_nt_ln_auto: N = 512, operand sizes inside the
+        # 32-bit buffer offsets of the full-row kernel for the widest product that uses it, no CUs reserved for a concurrent exchange) at
+        # buffer-allocation time; the two-kernel path is the fallback (advisor finding, round 5: the fused calls have no fallback of their own)
+        ln_ok = dh.gemm_nt_ln_auto(M, d, 4 * d) and self.dp_reserve_cus == 0
+        self.fuse_ln = bool(self.hp.get("fuse_ln", os.environ.get("DALLE_FUSE_LN", "1") != "0")) and ln_ok
         # FFN-2 -> next norm_1: not under recompute_grad, whose re-run of a block starts from the stored residual stream with a
         # standalone norm_1 (its statistics sum in another order; the re-run must reproduce the forward bit for bit)
         self.fuse_ln1 = self.fuse_ln and not self.recompute
@@ -319,7 +316,7 @@ class DalleEngine:
         self.hp.setdefault("lnbwd_chain", os.environ.get("DALLE_LNBWD_CHAIN", "1") != "0")
         # [r05] LayerNorm backward fused into the two input-gradient products that feed a LayerNorm (dmi_gemm_nt_lnbwd: n_embd = 512,
         # full-row tiles): dxn is never written, 12 of the 13 ln_bwd launches of a dalle_example step disappear
-        self.fuse_lnbwd = bool(self.hp.get("fuse_lnbwd", os.environ.get("DALLE_FUSE_LNBWD", "1") != "0")) and d == 512 and not self.defer_ln
+        self.fuse_lnbwd = bool(self.hp.get("fuse_lnbwd", os.environ.get("DALLE_FUSE_LNBWD", "1") != "0")) and ln_ok
         if self.fuse_lnbwd:
             # one partial buffer per LayerNorm: the 2L gain / bias reduces run as ONE batched launch at the end of the backward
             # (per block under data parallelism, where the exchange takes a block's gradients as soon as it is done)
@@ -659,10 +656,7 @@ class DalleEngine:
         pend = []
 
         def ln_bwd(idx, dy, x, g, mean, rstd, dres, dx, dg, db):
-            if self.defer_ln:
-                dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, None, None, self.ln_ws[idx], M, d)
-                pend.append((self.ln_ws[idx], dg, db, M))
-            elif self.fuse_lnbwd and self.lnb_batch and idx == 2 * L:    # the head's LayerNorm joins the batched finish of the fused ones
+            if self.fuse_lnbwd and self.lnb_batch and idx == 2 * L:    # the head's LayerNorm joins the batched finish of the fused ones
                 dh.layernorm_bwd(dy, x, g, mean, rstd, dres, dx, None, None, self.ln_ws_final, M, d)
                 pend.append((self.ln_ws_final, dg, db, M))
             else:

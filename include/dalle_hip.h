@@ -207,6 +207,10 @@ int dmi_gemm_nt_mask_bits(const uint16_t* A, int lda, const uint16_t* Bt, int ld
  * dx, i.e. the whole contraction range of its rows, so it reads them back from L2 as the A operand of a second main loop.
  * Bit-identical to dmi_gemm_nt on the stored dx. */
 int dmi_gemm_nt_lnbwd_parts(int M);
+/* dmi_gemm_nt_ln_auto: 1 where dmi_gemm_nt_ln / dmi_gemm_nt_lnbwd accept a K-contiguous [M, K] x [N, K]^T product (N = 512, operands
+ * inside the kernel's 32-bit offsets) and no CUs are reserved for a concurrent exchange; callers gate the fused forms on it when they
+ * size their buffers and keep dmi_gemm_nt + dmi_layernorm_fwd / _bwd elsewhere (same role as dmi_relu_bits_auto). */
+int dmi_gemm_nt_ln_auto(int M, int N, int K);
 int dmi_gemm_nt_lnbwd(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, int M, int N, int K, const uint16_t* x,
                       const uint16_t* gamma, const float* mean, const float* rstd, const uint16_t* dres, uint16_t* dx,
                       float* part, const uint16_t* B2, int ldb2, uint16_t* C2, void* stream);

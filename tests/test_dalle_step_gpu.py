@@ -110,25 +110,6 @@ def test_head_dgrad_tail_split_matches_single_launch(monkeypatch):
     assert num > 0, "the tail-split launch was not taken (identical bits)"
 
 
-def test_deferred_layernorm_finishes_are_bit_identical():
-    """[r05-prep] hparams['defer_ln_finish']: the 2L + 1 LayerNorm gain / bias gradient reduces run as one batched launch at the end
-    of the backward -- same loss, gradients and parameters after one step, bit for bit."""
-    from oracle import dalle_oracle as do
-    from src.dalle_mtf.engine import DalleEngine
-    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(2, 16, 300, seed=1),
-                                                 do.synthetic_image_tokens(2, 112, 64, seed=2), 300)).cuda()
-    out = []
-    for defer in (False, True):
-        eng = DalleEngine(256, 3, 2, 300, 64, 16, 112, batch_size=2, hparams=dict(lr=1e-3, train_steps=10, warmup_steps=0,
-                                                                                defer_ln_finish=defer))
-        eng.init_params(seed=3)
-        loss = float(eng.train_step(tokens))
-        out.append((loss, eng.g.clone(), eng.p.clone()))
-        del eng
-    assert out[0][0] == out[1][0]
-    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
-
-
 def test_recompute_grad_is_bit_identical():
     """hparams['recompute_grad'] (mtf.recompute_grad around every block, src/dalle_mtf/models.py:342-343): block activations live
     in one shared set of buffers and backward() re-runs each block's forward -- same loss, same gradients, bit for bit,

@@ -162,7 +162,8 @@ def test_layernorm_bwd_deferred_finish_batch():
         assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
 
 
-@pytest.mark.parametrize("M,K,with_res", [(160, 512, True), (1000, 1536, True), (2100, 2048, False), (40960, 1536, True), (333, 256, True)])
+@pytest.mark.parametrize("M,K,with_res", [(160, 512, True), (1000, 1536, True), (2100, 2048, False), (40960, 1536, True), (333, 256, True),
+                                          (512, 1536, True), (161, 512, False), (2559, 512, True)])
 def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
     """[r05] dmi_gemm_nt_lnbwd (full-row tiles, N = 512): dx, dgamma, dbeta equal dmi_gemm_nt followed by dmi_layernorm_bwd up to the
     summation order of the reductions (dx within one bf16 ulp almost everywhere), and fp32 autograd of LayerNorm applied to the
@@ -171,11 +172,22 @@ def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
     A, Bt = rnd(M, K, seed=1), rnd(N, K, scale=0.2, seed=2)
     x, dres = rnd(M, N, seed=3), rnd(M, N, seed=4)
     gam = bf(1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(5)))
-    Ad, Bd, xd, gd = A.to(DEV), Bt.to(DEV), x.to(DEV), gam.to(DEV)
-    rd = dres.to(DEV) if with_res else None
+    Ad, Bd, gd = A.to(DEV), Bt.to(DEV), gam.to(DEV)
+    # [r06] every row-indexed operand of the fused call is the first M rows of an allocation with G sentinel rows behind it: NaN behind the
+    # inputs (a read past M would poison dgamma / dbeta through the column partials), a bit pattern behind dx that must survive the call
+    # (advisor finding, round 5: on a ragged last tile the row-tile term sat in the scalar offset, outside the descriptor's range check)
+    G = 192
+    def guarded(t, fill):
+        full = torch.full((M + G,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=DEV)
+        full[:M] = t.to(DEV)
+        return full, full[:M]
+    x_full, xd = guarded(x, float("nan"))
+    r_full, rd = guarded(dres, float("nan"))
+    if not with_res:
+        rd = None
     y = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-    mean = torch.zeros(M, dtype=torch.float32, device=DEV)
-    rstd = torch.zeros(M, dtype=torch.float32, device=DEV)
+    mean_full, mean = guarded(torch.zeros(M, dtype=torch.float32), float("nan"))
+    rstd_full, rstd = guarded(torch.zeros(M, dtype=torch.float32), float("nan"))
     dh.layernorm_fwd(xd, gd, torch.zeros(N, dtype=torch.bfloat16, device=DEV), y, mean, rstd, M, N)
     # two-kernel form
     dy = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
@@ -184,11 +196,15 @@ def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
     dg0, db0 = (torch.zeros(N, dtype=torch.float32, device=DEV) for _ in range(2))
     dh.layernorm_bwd(dy, xd, gd, mean, rstd, rd, dx0, dg0, db0, ws(dh.layernorm_bwd_workspace_bytes(M, N)), M, N)
     # fused
-    dx1 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    SENT = 1.2345678e12    # (bf16(SENT) is a fixed bit pattern no product here produces)
+    dx1_full, dx1 = guarded(torch.full((M, N), float("nan"), dtype=torch.bfloat16), SENT)
     dg1, db1 = (torch.full((N,), float("nan"), dtype=torch.float32, device=DEV) for _ in range(2))
     part = torch.full((dh.gemm_nt_lnbwd_parts(M) * 2 * N,), float("nan"), dtype=torch.float32, device=DEV)
     dh.gemm_nt_lnbwd(Ad, K, Bd, K, M, N, K, xd, gd, mean, rstd, rd, dx1, part, dg=dg1, db=db1)
     assert not torch.isnan(dx1.float()).any() and not torch.isnan(dg1).any() and not torch.isnan(db1).any()
+    guard = torch.full((G, N), SENT, dtype=torch.bfloat16, device=DEV)
+    assert torch.equal(dx1_full[M:], guard), "dmi_gemm_nt_lnbwd stored dx rows past M"
+    assert torch.isnan(x_full[M:].float()).all() and torch.isnan(mean_full[M:]).all() and torch.isnan(rstd_full[M:]).all()
     d = (dx1.float() - dx0.float()).abs()
     assert float((d > 2.0 ** -7 * dx0.float().abs() + 1e-3).float().mean()) == 0.0, "dx differs from the two-kernel form by more than one bf16 ulp"
     assert float((dx1 != dx0).float().mean()) < 2e-2, float((dx1 != dx0).float().mean())
@@ -206,14 +222,15 @@ def test_gemm_nt_lnbwd_fused_layernorm_backward(M, K, with_res):
     # chained form: the product that consumes dx in the same launch -- dx, the partials and C2 = dx . B2^T bit-identical to the
     # unchained call followed by dmi_gemm_nt on the stored dx
     B2 = rnd(N, N, scale=0.2, seed=7).to(DEV)
-    dx2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-    C2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dx2_full, dx2 = guarded(torch.full((M, N), float("nan"), dtype=torch.bfloat16), SENT)
+    C2_full, C2 = guarded(torch.full((M, N), float("nan"), dtype=torch.bfloat16), SENT)
     dg2, db2 = (torch.full((N,), float("nan"), dtype=torch.float32, device=DEV) for _ in range(2))
     dh.gemm_nt_lnbwd(Ad, K, Bd, K, M, N, K, xd, gd, mean, rstd, rd, dx2, part, dg=dg2, db=db2, B2=B2, ldb2=N, C2=C2)
     assert torch.equal(dx2, dx1) and torch.equal(dg2, dg1) and torch.equal(db2, db1)
     Cref = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
     dh.gemm_nt(dx1, N, B2, N, Cref, N, M, N, N)
     assert torch.equal(C2, Cref), "the chained product must equal dmi_gemm_nt on the stored dx"
+    assert torch.equal(dx2_full[M:], guard) and torch.equal(C2_full[M:], guard), "the chained form stored rows past M"
 
 
 def _gemm_ref(A, Bt, bias=None, relu=False, residual=None, relu_src=None):
