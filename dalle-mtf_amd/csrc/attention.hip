@@ -180,6 +180,7 @@ __device__ __forceinline__ void fr3_wait(Fr3& f) {
 }
 
 extern int g_opt_attn_xcd;
+extern int g_opt_attn_fwd;      // 0: the round-2 forward kernel, 1 (default): the software-pipelined round-6 kernel (A/B switch)
 extern int g_opt_reserve_cus;   // CUs the persistent grids leave to concurrent kernels (csrc/gemm.hip)
 // Persistent-block schedule: the grid is one (dK/dV) or two (forward, dQ) blocks per CU; hardware block L (dispatched to XCD L % 8) owns
 // bin k = L / 8 of its XCD.  The XCD's work items -- (tile, batch*head) for its contiguous eighth of the (batch, head) pairs,
@@ -385,6 +386,308 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   }   // items
 }
 
+
+// =====================================================================================
+// forward, round 6: software-pipelined over the key tiles
+// =====================================================================================
+// The round-2 kernel above computes a key tile in program order -- S = K Q^T (hipcc waits for every pair of ds_read_b128 before the
+// two MFMAs that use it), softmax, O += V^T P -- so a wave's LDS latencies, its ~200 VALU instructions per tile and its 32 MFMAs ADD,
+// and only the second wave of the SIMD (the other block of the CU) hides anything: normalised MFMA-busy 0.29, 6.7 k cycles per tile
+// step of a block for 1 k cycles of matrix work per wave (profiles/r05_pmc_normalised.txt).  This form keeps the tile shapes, the
+// LDS layout, the operand roles (softmax row = lane) and the persistent schedule, and changes the instruction stream:
+//   * two S accumulators: step j runs  phase A  S(j+1) = K(j+1) Q^T  (16 MFMAs, K fragments by inline-asm ds_read_b128 one k-step
+//     ahead with counted waits)  interleaved with  exp2 / row sum / bf16 packing of S(j)  (one 4-element slice per two MFMAs,
+//     pinned with sched_group_barrier);  phase B  O += V(j)^T P(j)  (16 MFMAs, transposed V fragments one 16-key step ahead)  with
+//     the causal mask and the row maximum of S(j+1) riding between them.  K is staged two tiles ahead, V one (same 64 KB of LDS);
+//   * the running maximum lives in base-2 units as an INTEGER (m2 = ceil(max * log2 e)): every rescale factor is an exact power of
+//     two, so rescaling or not rescaling gives the same bits as long as nothing overflows -- and the O / l rescale (64 multiplies
+//     per lane) runs only when some row's maximum grew by more than 2^16 since its last rescale (on random scores the round-2
+//     kernel's "some row grew at all" fired on nearly every tile).  P <= 2^17 in bf16 (8 exponent bits), l and O in fp32;
+//   * O leaves through LDS as whole 256-byte rows (16 B per lane, 4 rows per store instruction) instead of 8-byte pieces of 32 rows
+//     per instruction; the half-row exchange of the row maximum is a v_permlane32_swap instead of a ds_bpermute.
+// Semantics unchanged (reference src/dalle_mtf/models.py:275-299): unscaled fp32 logits, key > query contributes exactly 0.
+struct Fk2 {
+  u32x4 a, b;   // K rows r and r + 32 of a 64-key tile, 16-byte chunk of k-step kk
+};
+template <int OFF>
+__device__ __forceinline__ void fk2_issue(Fk2& f, unsigned addr) {
+  asm volatile(
+      "ds_read_b128 %0, %2 offset:%3\n\t"
+      "ds_read_b128 %1, %2 offset:%4"
+      : "=&v"(f.a), "=&v"(f.b)
+      : "v"(addr), "i"(OFF), "i"(OFF + 8192)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void fk2_wait(Fk2& f, Fk2& prev) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.a), "+v"(f.b), "+v"(prev.a), "+v"(prev.b) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void fk2_wait(Fk2& f) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a), "+v"(f.b) : "n"(N) : "memory");
+}
+__device__ __forceinline__ float half_swap_max(float v) {   // max over the two lanes (l, l ^ 32) that share a softmax row
+  // v_permlane32_swap exchanges lanes 32..63 of its first operand with lanes 0..31 of the second: afterwards one register holds the lower
+  // half-row's value in every lane, the other the upper half-row's.  Inline asm with the two wait states the instruction needs behind a
+  // VALU write of its operands: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) maps BOTH results to the first register when
+  // the two inputs are copies of one value (a three-line kernel shows r[0] + 2 r[1] compiled to v_fmac v1, 2.0, v1), i.e. the maximum
+  // came out as the LOWER half's only -- which ordinary scores hide (the running maximum is only a scale) and a late large score in
+  // an upper-half lane turned into exp2 overflow.
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+#define F2_THR 16.0f      // base-2 exponent growth of a row maximum that forces a rescale
+#define F2_OP 272         // pitch (bytes) of the O staging rows
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
+                                                           float* __restrict__ lse, int B, int H, int S, int perxcd) {
+  extern __shared__ __attribute__((aligned(16))) char sm[];  // K slot 0 | K slot 1 | V slot 0 | V slot 1, 16 KB each
+  const int d = H * HD, ld3 = 3 * d;
+  const int T = (S + 127) / 128;
+  const AttnSched sched = attn_sched(T, B * H, perxcd);
+  int tile_, bh;
+  for (int round = 0; attn_item(sched, round, tile_, bh); ++round) {
+  const int qt = T - 1 - tile_;  // heaviest (latest) query tiles first
+  const int b = bh / H, hh = bh % H;
+  const int q0 = qt * 128;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque per item (see attn_bwd_dkv_kernel)
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
+  const int qrow = q0 + wid * 32 + r;
+  const int qrow_c = qrow < S ? qrow : S - 1;
+  const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
+  const int nbytes = (int)(((int64_t)(S - 1) * ld3 + HD) * 2);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + d), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 2 * d), 0, nbytes, 0x00020000);
+
+  bf16x8 qf[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(qb + (int64_t)qrow_c * ld3 + 16 * kk + 8 * h);
+
+  int vo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    vo[i] = (row * ld3 + 8 * (pc ^ swz(row))) * 2;
+  }
+  auto stage_k = [&](int slot, int key0) {
+    char* base = sm + slot * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(rk, base + (wid * 64 + 256 * i) * 16, vo[i] + key0 * ld3 * 2);
+  };
+  auto stage_v = [&](int slot, int key0) {
+    char* base = sm + 32768 + slot * 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16(rv, base + (wid * 64 + 256 * i) * 16, vo[i] + key0 * ld3 * 2);
+  };
+  // K fragment address of k-step kk in slot 0: row r, chunk (2 kk + h) ^ swz(r) = ((h ^ swz(r)) ^ 2 kk) -> ONE base register, kk enters
+  // as an XOR of bits 5..7 and the slot base rides in the add (v_xad_u32); the second 32 keys are an immediate offset.  Transposed V
+  // fragments {keys +0..3, +8..11}: d-tile dt is an XOR of bits 6..7 of two bases.  (Eight + eight address registers hoisted out of
+  // the tile loop were what spilled first; the bases are made opaque per step so that they are recomputed, one VALU each.)
+  unsigned ak0 = r * 256 + ((h ^ swz(r)) << 4);
+  const int rr = l16 >> 2;
+  unsigned av0[2];
+#pragma unroll
+  for (int w2 = 0; w2 < 2; ++w2) {
+    const int row = 4 * h + rr + 8 * w2;
+    const int chunk = 2 * (g4 & 1) + ((l16 & 3) >> 1);
+    av0[w2] = row * 256 + ((chunk ^ swz(row)) << 4) + 8 * (l16 & 1);
+  }
+
+  f32x16 oacc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+  float m2 = -1e30f, l = 0.f, mx = -1e30f;
+
+  const int qlast = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;
+  const int nsteps = qlast / 64 + 1;
+  int jmax = (q0 + wid * 32 + 31) / 64;      // this wave's last (= its only diagonal) key tile
+  jmax = jmax < nsteps ? jmax : nsteps - 1;  // (a wave whose rows all lie past S: garbage in, nothing stored)
+
+  // causal mask of key tile jt (-1e10 additive mask == probability exactly 0) and the row maximum of the masked scores
+  auto mask_tile = [&](int jt, f32x16& s0, f32x16& s1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = 64 * jt + (e & 3) + 8 * (e >> 2) + 4 * h;
+      s0[e] = (key > qrow) ? -1e30f : s0[e];
+      s1[e] = (key + 32 > qrow) ? -1e30f : s1[e];
+    }
+  };
+  // (compiler-visible v_max / v_max3: an inline-asm v_max3_f32 reading MFMA results gets NO hazard protection from hipcc -- placed right behind
+  // the last S MFMA it read accumulators that were still in flight; with ordinary scores a slightly wrong maximum is invisible, a late
+  // spike then overflowed exp2.  The canonicalising v_max per operand that fmaxf on MFMA outputs costs rides in phase B, which has VALU slack.)
+  auto row_max = [&](const f32x16& s0, const f32x16& s1) {
+    float v = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) v = fmaxf(fmaxf(v, s0[e]), s1[e]);
+    return half_swap_max(v);
+  };
+  // K(j + 2) and V(j + 1) on their way at the top of step j: their slots' last readers are behind the previous step's barrier
+  auto step_dma = [&](int j) {
+#ifndef ATTN_DBG_NODMA
+    if (j + 2 < nsteps) stage_k(j & 1, 64 * (j + 2));
+    if (j + 1 < nsteps) stage_v((j + 1) & 1, 64 * (j + 1));
+#endif
+  };
+  auto step_end = [&]() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  // one step: softmax + P V of the tile whose scores are in (c0, c1) (key tile j, V in slot j & 1), S of tile j + 1 into (n0, n1).
+  // ONE variant (two inlined copies for the two buffer roles): the wave's last step computes the scores of a tile it does not need
+  // from whatever its slot holds (16 MFMAs per item, under the softmax) instead of a third code path -- with three variants x two roles
+  // the register allocator shuffled 52 registers and spilled 170 around every transition, 10 us per item.
+  auto body = [&](int j, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+    step_dma(j);
+    asm volatile("" : "+v"(ak0), "+v"(av0[0]), "+v"(av0[1]));
+    const unsigned kb = lds0 + ((j + 1) & 1) * 16384, vb = lds0 + 32768 + (j & 1) * 16384;
+#ifndef ATTN_DBG_NOCOMPUTE
+    // rescale only when some row's maximum outgrew its scale by more than 2^F2_THR (exact power-of-two factors)
+    const float mx2 = mx * LOG2E_F;
+    if (__any(mx2 - m2 > F2_THR)) {
+      const float m2n = fmaxf(m2, __builtin_ceilf(mx2));
+      const float alpha = __builtin_ldexpf(1.0f, (int)fmaxf(m2 - m2n, -200.0f));
+      m2 = m2n;
+      l *= alpha;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+    }
+    unsigned pw[16];
+    float rs = 0.f;
+    Fk2 F[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) n0[e] = n1[e] = 0.f;
+    fk2_issue<0>(F[0], ak0 + kb);
+    Tr4 tv[2];
+    unsigned avt[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      Fk2& c = F[kk & 1];
+      if (kk == 0) fk2_wait<0>(c); else fk2_wait<0>(c, F[(kk + 1) & 1]);
+      if (kk + 1 < 8) fk2_issue<0>(F[(kk + 1) & 1], (ak0 ^ (unsigned)((kk + 1) << 5)) + kb);
+      else {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { avt[2 * dt] = (av0[0] ^ (unsigned)(dt << 6)) + vb; avt[2 * dt + 1] = (av0[1] ^ (unsigned)(dt << 6)) + vb; }
+        tr4_issue_off<0>(tv[0], avt);
+      }
+      n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.a), qf[kk], n0, 0, 0, 0);  // S^T[key][q]
+      n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.b), qf[kk], n1, 0, 0, 0);
+      const f32x16& cs = kk < 4 ? c0 : c1;
+      float pe[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pe[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[4 * (kk & 3) + e], LOG2E_F, -m2));
+        rs += pe[e];
+      }
+      pw[2 * kk] = pack2bf(pe[0], pe[1]);
+      pw[2 * kk + 1] = pack2bf(pe[2], pe[3]);
+      asm volatile("" : "+v"(pw[2 * kk]), "+v"(pw[2 * kk + 1]), "+v"(rs));   // pin here: otherwise the exponentials / the row-sum chain sink below the last MFMA
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l += rs;
+    bf16x8 pb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) pb[ks] = __builtin_bit_cast(bf16x8, u32x4{pw[4 * ks], pw[4 * ks + 1], pw[4 * ks + 2], pw[4 * ks + 3]});
+    // phase B: O^T[d][q] += V^T[d][key] P^T[key][q], 16-key steps: keys 16 ks + {4h..4h+3, 8+4h..8+4h+3}
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      Tr4& c = tv[ks & 1];
+      tr4_wait(c);
+      if (ks == 0) tr4_issue_off<4096>(tv[1], avt);
+      if (ks == 1) tr4_issue_off<8192>(tv[0], avt);
+      if (ks == 2) tr4_issue_off<12288>(tv[1], avt);
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.a0, c.a1), pb[ks], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.b0, c.b1), pb[ks], oacc[1], 0, 0, 0);
+      oacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.c0, c.c1), pb[ks], oacc[2], 0, 0, 0);
+      oacc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.d0, c.d1), pb[ks], oacc[3], 0, 0, 0);
+    }
+    if (j + 1 == jmax) mask_tile(j + 1, n0, n1);     // (wave-uniform)
+    mx = row_max(n0, n1);
+#endif
+    step_end();
+  };
+
+  f32x16 sA0, sA1, sB0, sB1;
+  // prologue: K(0), K(1), V(0); S(0) in program order
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (nsteps > 1) stage_k(1, 64);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sA0[e] = sA1[e] = 0.f;
+    Fk2 F[2];
+    fk2_issue<0>(F[0], ak0 + lds0);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      Fk2& c = F[kk & 1];
+      if (kk == 0) fk2_wait<0>(c); else fk2_wait<0>(c, F[(kk + 1) & 1]);
+      if (kk + 1 < 8) fk2_issue<0>(F[(kk + 1) & 1], (ak0 ^ (unsigned)((kk + 1) << 5)) + lds0);
+      sA0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.a), qf[kk], sA0, 0, 0, 0);
+      sA1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.b), qf[kk], sA1, 0, 0, 0);
+    }
+    if (jmax == 0) mask_tile(0, sA0, sA1);
+    mx = row_max(sA0, sA1);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();     // every wave has read K(0): step 0 refills its slot
+
+  // This wave's steps 0 .. jmax (the diagonal tile's scores are masked when step jmax - 1 produces them); afterwards it only keeps
+  // issuing its share of the DMA and meeting the barriers until the block's last step (the barrier counts arrivals, not program counters).
+  int j = 0;
+  for (;;) {
+    body(j, sA0, sA1, sB0, sB1);
+    if (j == jmax) break;
+    ++j;
+    body(j, sB0, sB1, sA0, sA1);
+    if (j == jmax) break;
+    ++j;
+  }
+  for (j = jmax + 1; j < nsteps; ++j) {
+    step_dma(j);
+    step_end();
+  }
+
+  // epilogue: normalise, stage this wave's 32 x 128 outputs through its private LDS strip, store whole rows
+  l += __shfl_xor(l, 32, 64);
+  {
+    const float inv = 1.f / l;
+    char* wb = sm + wid * (32 * F2_OP);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int dd = dt * 32 + 8 * q4 + 4 * h;
+        *(u32x2*)(wb + r * F2_OP + dd * 2) = u32x2{pack2bf(oacc[dt][4 * q4] * inv, oacc[dt][4 * q4 + 1] * inv),
+                                                    pack2bf(oacc[dt][4 * q4 + 2] * inv, oacc[dt][4 * q4 + 3] * inv)};
+      }
+    if (h == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = (m2 + __log2f(l)) * 0.6931471805599453f;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: in-order LDS, no block barrier needed
+    bf16_t* ob = o + ((int64_t)b * S + q0 + wid * 32) * d + hh * HD;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = 4 * it + g4;
+      const u32x4 v = *(const u32x4*)(wb + row * F2_OP + l16 * 16);
+      if (q0 + wid * 32 + row < S) *(u32x4*)(ob + (int64_t)row * d + l16 * 8) = v;
+    }
+  }
+  __syncthreads();   // the strips are read before the next item's first DMA
+  }   // items
+}
+
 static int attn_num_cus() {
   static int n = 0;
   if (!n) {
@@ -402,12 +705,17 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
   DMI_REQUIRE(B > 0 && H > 0 && S > 0 && S % 8 == 0, "attention_fwd: S must be a multiple of 8 (S=%d)", S);
   DMI_REQUIRE((int64_t)S * 3 * H * HD * 2 < 0x7fffffff, "attention_fwd: sequence too long for 32-bit buffer offsets");
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE); attr_done = true; }
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
+    attr_done = true;
+  }
   {
     const int items = ((S + 127) / 128) * B * H;
     const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    attn_fwd_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd);
+    if (g_opt_attn_fwd == 0) attn_fwd_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd);
+    else attn_fwd2_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd);
   }
   DMI_CHECK_LAUNCH("attention_fwd");
   return DMI_OK;
