@@ -94,6 +94,10 @@ __device__ __forceinline__ void tr4_issue(Tr4& f, unsigned lo0, unsigned hi0, un
 // the same eight reads at a compile-time byte offset from eight per-step base addresses (no address VALU per fragment set)
 template <int OFF>
 __device__ __forceinline__ void tr4_issue_off(Tr4& f, const unsigned (&a)[8]) {
+#ifdef ATTN_DBG_NOLDS
+  asm volatile("" : "=v"(f.a0), "=v"(f.a1), "=v"(f.b0), "=v"(f.b1), "=v"(f.c0), "=v"(f.c1), "=v"(f.d0), "=v"(f.d1) : "v"(a[0]), "v"(a[1]));
+  return;
+#endif
   asm volatile(
       "ds_read_b64_tr_b16 %0, %8 offset:%16\n\t"
       "ds_read_b64_tr_b16 %1, %9 offset:%16\n\t"
@@ -119,6 +123,15 @@ __device__ __forceinline__ void tr4_wait8(Tr4& f, Tr4& prev) {
                : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.c0), "+v"(f.c1), "+v"(f.d0), "+v"(f.d1),
                  "+v"(prev.a0), "+v"(prev.a1), "+v"(prev.b0), "+v"(prev.b1), "+v"(prev.c0), "+v"(prev.c1), "+v"(prev.d0), "+v"(prev.d1)
                :
+               : "memory");
+}
+// wait until at most N younger LDS operations are outstanding; "other" names the set whose readers / whose issue must not move across
+template <int N>
+__device__ __forceinline__ void tr4_waitn(Tr4& f, Tr4& other) {
+  asm volatile("s_waitcnt lgkmcnt(%16)"
+               : "+v"(f.a0), "+v"(f.a1), "+v"(f.b0), "+v"(f.b1), "+v"(f.c0), "+v"(f.c1), "+v"(f.d0), "+v"(f.d1),
+                 "+v"(other.a0), "+v"(other.a1), "+v"(other.b0), "+v"(other.b1), "+v"(other.c0), "+v"(other.c1), "+v"(other.d0), "+v"(other.d1)
+               : "n"(N)
                : "memory");
 }
 struct Tr2 {
@@ -180,6 +193,9 @@ __device__ __forceinline__ void fr3_wait(Fr3& f) {
 }
 
 extern int g_opt_attn_xcd;
+#ifdef ATTN_STAMP
+extern unsigned long long* g_dbg_buf;
+#endif
 extern int g_opt_attn_fwd;      // 0: the round-2 forward kernel, 1 (default): the software-pipelined round-6 kernel (A/B switch)
 extern int g_opt_reserve_cus;   // CUs the persistent grids leave to concurrent kernels (csrc/gemm.hip)
 // Persistent-block schedule: the grid is one (dK/dV) or two (forward, dQ) blocks per CU; hardware block L (dispatched to XCD L % 8) owns
@@ -411,6 +427,10 @@ struct Fk2 {
 };
 template <int OFF>
 __device__ __forceinline__ void fk2_issue(Fk2& f, unsigned addr) {
+#ifdef ATTN_DBG_NOLDS
+  asm volatile("" : "=v"(f.a), "=v"(f.b) : "v"(addr));
+  return;
+#endif
   asm volatile(
       "ds_read_b128 %0, %2 offset:%3\n\t"
       "ds_read_b128 %1, %2 offset:%4"
@@ -437,11 +457,31 @@ __device__ __forceinline__ float half_swap_max(float v) {   // max over the two 
   asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
   return fmaxf(a, b);
 }
+#ifndef F2_THR
 #define F2_THR 16.0f      // base-2 exponent growth of a row maximum that forces a rescale
+#endif
+#ifndef F2_KDEPTH
+#define F2_KDEPTH 2       // K fragment pairs in flight ahead of their MFMAs
+#endif
+#ifndef F2_VEARLY
+#define F2_VEARLY 1       // first two transposed V fragment sets requested under the last two k-steps of S
+#endif
 #define F2_OP 272         // pitch (bytes) of the O staging rows
+#ifdef ATTN_STAMP      // experiment build: per-block sums of shader-clock intervals (wave 0), tools/experiments/r06_fwd_stamps.py
+#define STAMP_ARG , unsigned long long* __restrict__ stamp
+#define STAMP_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_readcyclecounter(); const unsigned long long st_t0 = st_t;
+#define STAMP(i) { const unsigned long long t_ = __builtin_readcyclecounter(); st_acc[i] += t_ - st_t; st_t = t_; }
+#define STAMP_COUNT(i) { st_acc[i] += 1; }
+#else
+#define STAMP_ARG
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_COUNT(i)
+#endif
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
-                                                           float* __restrict__ lse, int B, int H, int S, int perxcd) {
+                                                           float* __restrict__ lse, int B, int H, int S, int perxcd STAMP_ARG) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // K slot 0 | K slot 1 | V slot 0 | V slot 1, 16 KB each
+  STAMP_DECL
   const int d = H * HD, ld3 = 3 * d;
   const int T = (S + 127) / 128;
   const AttnSched sched = attn_sched(T, B * H, perxcd);
@@ -536,13 +576,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   };
   auto step_end = [&]() {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef ATTN_DBG_NOBARRIER
     __builtin_amdgcn_s_barrier();
+#endif
   };
   // one step: softmax + P V of the tile whose scores are in (c0, c1) (key tile j, V in slot j & 1), S of tile j + 1 into (n0, n1).
   // ONE variant (two inlined copies for the two buffer roles): the wave's last step computes the scores of a tile it does not need
   // from whatever its slot holds (16 MFMAs per item, under the softmax) instead of a third code path -- with three variants x two roles
   // the register allocator shuffled 52 registers and spilled 170 around every transition, 10 us per item.
   auto body = [&](int j, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+    STAMP(8)
     step_dma(j);
     asm volatile("" : "+v"(ak0), "+v"(av0[0]), "+v"(av0[1]));
     const unsigned kb = lds0 + ((j + 1) & 1) * 16384, vb = lds0 + 32768 + (j & 1) * 16384;
@@ -559,33 +602,56 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
         for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
     }
+    STAMP(0)
     unsigned pw[16];
     float rs = 0.f;
-    Fk2 F[2];
+    // K fragments F2_KDEPTH k-steps ahead of their MFMAs, the first two transposed V fragment sets under the last two k-steps (F2_VEARLY)
+    Fk2 F[F2_KDEPTH + 1];
 #pragma unroll
     for (int e = 0; e < 16; ++e) n0[e] = n1[e] = 0.f;
-    fk2_issue<0>(F[0], ak0 + kb);
+#pragma unroll
+    for (int q = 0; q < F2_KDEPTH; ++q) fk2_issue<0>(F[q], (ak0 ^ (unsigned)(q << 5)) + kb);
     Tr4 tv[2];
     unsigned avt[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      Fk2& c = F[kk & 1];
-      if (kk == 0) fk2_wait<0>(c); else fk2_wait<0>(c, F[(kk + 1) & 1]);
-      if (kk + 1 < 8) fk2_issue<0>(F[(kk + 1) & 1], (ak0 ^ (unsigned)((kk + 1) << 5)) + kb);
+      Fk2& c = F[kk % (F2_KDEPTH + 1)];
+      Fk2& pv = F[(kk + F2_KDEPTH) % (F2_KDEPTH + 1)];    // the set consumed one k-step ago (its MFMAs stay above this wait)
+      // LDS operations issued behind this k-step's pair: the younger K pairs and, at the end, the first V set
+      constexpr int KD = F2_KDEPTH;
+      const int younger_k = (kk + KD - 1 < 8 ? KD - 1 : 7 - kk) * 2;
+      const int younger_v = (F2_VEARLY && kk == 7) ? 8 : 0;
+      if (kk == 0) { if (younger_k + younger_v == 0) fk2_wait<0>(c); else if (younger_k == 2) fk2_wait<2>(c); }
       else {
+        if (younger_k + younger_v == 0) fk2_wait<0>(c, pv);
+        else if (younger_k + younger_v == 2) fk2_wait<2>(c, pv);
+        else fk2_wait<8>(c, pv);
+      }
+      if (kk + KD < 8) fk2_issue<0>(pv, (ak0 ^ (unsigned)((kk + KD) << 5)) + kb);
+      if (kk == (F2_VEARLY ? 6 : 7)) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { avt[2 * dt] = (av0[0] ^ (unsigned)(dt << 6)) + vb; avt[2 * dt + 1] = (av0[1] ^ (unsigned)(dt << 6)) + vb; }
         tr4_issue_off<0>(tv[0], avt);
       }
+      if (F2_VEARLY && kk == 7) tr4_issue_off<4096>(tv[1], avt);
+#ifndef ATTN_DBG_NOSMFMA
       n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.a), qf[kk], n0, 0, 0, 0);  // S^T[key][q]
       n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.b), qf[kk], n1, 0, 0, 0);
+#else
+      n0[kk] += __builtin_bit_cast(f32x4, c.a)[0]; n1[kk] += __builtin_bit_cast(f32x4, c.b)[0];
+#endif
       const f32x16& cs = kk < 4 ? c0 : c1;
       float pe[4];
+#ifndef ATTN_DBG_NOEXP
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         pe[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(cs[4 * (kk & 3) + e], LOG2E_F, -m2));
         rs += pe[e];
       }
+#else
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pe[e] = cs[4 * (kk & 3) + e];
+#endif
       pw[2 * kk] = pack2bf(pe[0], pe[1]);
       pw[2 * kk + 1] = pack2bf(pe[2], pe[3]);
       asm volatile("" : "+v"(pw[2 * kk]), "+v"(pw[2 * kk + 1]), "+v"(rs));   // pin here: otherwise the exponentials / the row-sum chain sink below the last MFMA
@@ -596,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       __builtin_amdgcn_sched_barrier(0);
     }
     l += rs;
+    STAMP(1)
     bf16x8 pb[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) pb[ks] = __builtin_bit_cast(bf16x8, u32x4{pw[4 * ks], pw[4 * ks + 1], pw[4 * ks + 2], pw[4 * ks + 3]});
@@ -603,22 +670,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       Tr4& c = tv[ks & 1];
+#if F2_VEARLY
+      // two sets in flight: the set of step ks + 2 is requested into this step's registers right behind the MFMAs that read them
+      // (the MFMAs take their A operand when they issue; the LDS data arrive >= 64 cycles later -- as the dK/dV kernel's tdo reuse)
+      if (ks < 3) tr4_waitn<8>(c, tv[(ks + 1) & 1]); else tr4_waitn<0>(c, tv[(ks + 1) & 1]);
+#else
       tr4_wait(c);
       if (ks == 0) tr4_issue_off<4096>(tv[1], avt);
       if (ks == 1) tr4_issue_off<8192>(tv[0], avt);
       if (ks == 2) tr4_issue_off<12288>(tv[1], avt);
+#endif
       oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.a0, c.a1), pb[ks], oacc[0], 0, 0, 0);
       oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.b0, c.b1), pb[ks], oacc[1], 0, 0, 0);
       oacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.c0, c.c1), pb[ks], oacc[2], 0, 0, 0);
       oacc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.d0, c.d1), pb[ks], oacc[3], 0, 0, 0);
+#if F2_VEARLY
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks == 0) tr4_issue_off<8192>(tv[0], avt);
+      if (ks == 1) tr4_issue_off<12288>(tv[1], avt);
+#endif
     }
     if (j + 1 == jmax) mask_tile(j + 1, n0, n1);     // (wave-uniform)
     mx = row_max(n0, n1);
 #endif
+#ifdef ATTN_STAMP
+    asm volatile("" : "+v"(mx));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    STAMP(2)
     step_end();
+    STAMP(3)
+    STAMP_COUNT(6)
   };
 
   f32x16 sA0, sA1, sB0, sB1;
+  STAMP(8)
   // prologue: K(0), K(1), V(0); S(0) in program order
   stage_k(0, 0);
   stage_v(0, 0);
@@ -643,6 +729,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();     // every wave has read K(0): step 0 refills its slot
+  STAMP(4)
 
   // This wave's steps 0 .. jmax (the diagonal tile's scores are masked when step jmax - 1 produces them); afterwards it only keeps
   // issuing its share of the DMA and meeting the barriers until the block's last step (the barrier counts arrivals, not program counters).
@@ -655,10 +742,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     if (j == jmax) break;
     ++j;
   }
+  STAMP(8)
   for (j = jmax + 1; j < nsteps; ++j) {
     step_dma(j);
     step_end();
   }
+  STAMP(7)
 
   // epilogue: normalise, stage this wave's 32 x 128 outputs through its private LDS strip, store whole rows
   l += __shfl_xor(l, 32, 64);
@@ -685,7 +774,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     }
   }
   __syncthreads();   // the strips are read before the next item's first DMA
+  STAMP(5)
+  STAMP_COUNT(9)
   }   // items
+#ifdef ATTN_STAMP
+  if (threadIdx.x == 0 && stamp) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) stamp[blockIdx.x * 12 + i] = st_acc[i];
+    stamp[blockIdx.x * 12 + 10] = __builtin_readcyclecounter() - st_t0;
+  }
+#endif
 }
 
 static int attn_num_cus() {
@@ -715,7 +813,11 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
     const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
     if (g_opt_attn_fwd == 0) attn_fwd_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd);
+#ifdef ATTN_STAMP
+    else attn_fwd2_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd, g_dbg_buf);
+#else
     else attn_fwd2_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, (hipStream_t)stream>>>(qkv, o, lse, B, H, S, perxcd);
+#endif
   }
   DMI_CHECK_LAUNCH("attention_fwd");
   return DMI_OK;

@@ -51,7 +51,7 @@ static int g_opt_relu_bits = 1;   // FFN ReLU mask as one bit per element (dmi_g
 static int g_opt_nt8p_max_k = 1024;   // auto mode: K above this keeps the one-tile-per-block kernels (the main loop then dominates a tile)
 static int g_opt_nt4_lds = 49152;   // dynamic LDS requested by the 256x128 NT kernel: 49152 = what it uses (3 blocks / CU); 65536 / 98304
                                     // cap the residency at 2 / 1 blocks per CU (tools/phases.py: a block's phases without co-resident blocks)
-static unsigned long long* g_dbg_buf = nullptr;
+unsigned long long* g_dbg_buf = nullptr;   // (also read by the ATTN_STAMP experiment build of attention.hip)
 extern "C" int dmi_set_debug_buffer(void* p) { g_dbg_buf = (unsigned long long*)p; return 0; }
 extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
