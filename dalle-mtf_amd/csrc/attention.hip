@@ -197,6 +197,7 @@ extern int g_opt_attn_xcd;
 extern unsigned long long* g_dbg_buf;
 #endif
 extern int g_opt_attn_fwd;      // 0: the round-2 forward kernel, 1 (default): the software-pipelined round-6 kernel (A/B switch)
+extern int g_opt_attn_bwd;      // bit 0: whole-row epilogue stores through LDS in the two backward kernels (A/B switch)
 extern int g_opt_reserve_cus;   // CUs the persistent grids leave to concurrent kernels (csrc/gemm.hip)
 // Persistent-block schedule: the grid is one (dK/dV) or two (forward, dQ) blocks per CU; hardware block L (dispatched to XCD L % 8) owns
 // bin k = L / 8 of its XCD.  The XCD's work items -- (tile, batch*head) for its contiguous eighth of the (batch, head) pairs,
@@ -221,6 +222,33 @@ __device__ __forceinline__ bool attn_item(const AttnSched& s, int r, int& tile, 
   tile = j / s.nbh;
   bh = s.bh_lo + j - tile * s.nbh;
   return true;
+}
+// [r06] Epilogue of a wave's 32 x 128 result tile held as 32x32 MFMA accumulators (lane (r, h) owns row r, acc[dt][e] is column
+// 32 dt + (e & 3) + 8 (e >> 2) + 4 h): staged through a wave-private LDS strip (32 rows, pitch 272 B) and stored as WHOLE 256-byte rows --
+// 16 B per lane, four rows per store instruction -- instead of 16 eight-byte pieces per lane that touch 32 rows per instruction (the
+// store tail of an attention kernel is issue-bound on this part: cdna_hip_programming.md T21 / MI355X_MICROARCH.md "attention epilogue
+// store tail").  The caller guarantees that nobody else uses the strip (a barrier behind the last tile's LDS reads).
+#define ROWS_PITCH 272
+__device__ __forceinline__ void store_rows_via_lds(char* strip, const f32x16 (&acc)[4], float scale, bf16_t* gbase, int64_t pitch,
+                                                   int rows_valid, int lane) {
+  const int r = lane & 31, h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int dd = dt * 32 + 8 * q4 + 4 * h;
+      *(u32x2*)(strip + r * ROWS_PITCH + dd * 2) = u32x2{pack2bf(acc[dt][4 * q4] * scale, acc[dt][4 * q4 + 1] * scale),
+                                                          pack2bf(acc[dt][4 * q4 + 2] * scale, acc[dt][4 * q4 + 3] * scale)};
+    }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: in-order LDS, no block barrier needed
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = 4 * it + g4;
+    const u32x4 v = *(const u32x4*)(strip + row * ROWS_PITCH + l16 * 16);
+    if (row < rows_valid) *(u32x4*)(gbase + (int64_t)row * pitch + l16 * 8) = v;
+  }
+  __builtin_amdgcn_wave_barrier();
 }
 #define QK_STAGE 32768  // K 16384 | V 16384
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
@@ -466,7 +494,6 @@ __device__ __forceinline__ float half_swap_max(float v) {   // max over the two 
 #ifndef F2_VEARLY
 #define F2_VEARLY 1       // first two transposed V fragment sets requested under the last two k-steps of S
 #endif
-#define F2_OP 272         // pitch (bytes) of the O staging rows
 #ifdef ATTN_STAMP      // experiment build: per-block sums of shader-clock intervals (wave 0), tools/experiments/r06_fwd_stamps.py
 #define STAMP_ARG , unsigned long long* __restrict__ stamp
 #define STAMP_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_readcyclecounter(); const unsigned long long st_t0 = st_t;
@@ -751,28 +778,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 
   // epilogue: normalise, stage this wave's 32 x 128 outputs through its private LDS strip, store whole rows
   l += __shfl_xor(l, 32, 64);
-  {
-    const float inv = 1.f / l;
-    char* wb = sm + wid * (32 * F2_OP);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int dd = dt * 32 + 8 * q4 + 4 * h;
-        *(u32x2*)(wb + r * F2_OP + dd * 2) = u32x2{pack2bf(oacc[dt][4 * q4] * inv, oacc[dt][4 * q4 + 1] * inv),
-                                                    pack2bf(oacc[dt][4 * q4 + 2] * inv, oacc[dt][4 * q4 + 3] * inv)};
-      }
-    if (h == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = (m2 + __log2f(l)) * 0.6931471805599453f;
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private strip: in-order LDS, no block barrier needed
-    bf16_t* ob = o + ((int64_t)b * S + q0 + wid * 32) * d + hh * HD;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = 4 * it + g4;
-      const u32x4 v = *(const u32x4*)(wb + row * F2_OP + l16 * 16);
-      if (q0 + wid * 32 + row < S) *(u32x4*)(ob + (int64_t)row * d + l16 * 8) = v;
-    }
-  }
+  if (h == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = (m2 + __log2f(l)) * 0.6931471805599453f;
+  store_rows_via_lds(sm + wid * (32 * ROWS_PITCH), oacc, 1.f / l, o + ((int64_t)b * S + q0 + wid * 32) * d + hh * HD, d, S - (q0 + wid * 32), lane);
   __syncthreads();   // the strips are read before the next item's first DMA
   STAMP(5)
   STAMP_COUNT(9)
@@ -834,7 +841,7 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, float* __restrict__ stats,
-                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
+                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd, int rowstore) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int T = (S + 127) / 128;
@@ -989,7 +996,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
   if (j < nsteps) compute(0, j);
 
-  if (qrow < S) {
+  if (rowstore) {   // [r06] whole-row stores through a wave-private LDS strip (behind a barrier: the last tile's readers are done)
+    __syncthreads();
+    store_rows_via_lds(sm + wid * (32 * ROWS_PITCH), dq, 1.0f, dqkv + ((int64_t)b * S + q0 + wid * 32) * ld3 + hh * HD, ld3, S - (q0 + wid * 32), lane);
+  } else if (qrow < S) {
     bf16_t* op = dqkv + ((int64_t)b * S + qrow) * ld3 + hh * HD;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -999,7 +1009,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         *(u32x2*)(op + dd) = u32x2{pack2bf(dq[dt][4 * q4], dq[dt][4 * q4 + 1]), pack2bf(dq[dt][4 * q4 + 2], dq[dt][4 * q4 + 3])};
       }
   }
-  __syncthreads();   // the last step's LDS reads are done before the next item's first DMA
+  __syncthreads();   // the last step's LDS reads / the strips are done before the next item's first DMA
   }   // items
 }
 
@@ -1047,7 +1057,7 @@ __device__ __forceinline__ void st8_wait(St8& f) {
 }
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ stats /* [B,H,S,2] (lse * log2 e, delta) */,
-                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
+                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd, int rowstore) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const AttnSched sched = attn_sched((S + 127) / 128, B * H, perxcd);
@@ -1305,7 +1315,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
 #undef DKV_WAIT
 #undef DKV_BARRIER
 
-  if (krow < S) {
+  if (rowstore) {   // [r06] whole-row stores (every step ended with a barrier: the ring and the V tile have no readers left)
+    bf16_t* gk = dqkv + ((int64_t)b * S + key0 + wid * 32) * ld3 + d + hh * HD;
+    char* strip = sm + wid * (2 * 32 * ROWS_PITCH);
+    store_rows_via_lds(strip, dk, 1.0f, gk, ld3, S - (key0 + wid * 32), lane);
+    store_rows_via_lds(strip + 32 * ROWS_PITCH, dv, 1.0f, gk + d, ld3, S - (key0 + wid * 32), lane);
+    __syncthreads();   // the strips are read before the next item's DMA overwrites them
+  } else if (krow < S) {
     bf16_t* okp = dqkv + ((int64_t)b * S + krow) * ld3 + d + hh * HD;
     bf16_t* ovp = okp + d;
 #pragma unroll
@@ -1344,13 +1360,13 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
   {
     const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd);
+    attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd, g_opt_attn_bwd & 1);
   }
   DMI_CHECK_LAUNCH("attention_bwd_dq");
   {
     const int grid = items < attn_num_cus() ? items : attn_num_cus();   // one persistent block per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd);
+    attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd, g_opt_attn_bwd & 1);
   }
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;
