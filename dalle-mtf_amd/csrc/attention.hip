@@ -197,7 +197,7 @@ extern int g_opt_attn_xcd;
 extern unsigned long long* g_dbg_buf;
 #endif
 extern int g_opt_attn_fwd;      // 0: the round-2 forward kernel, 1 (default): the software-pipelined round-6 kernel (A/B switch)
-extern int g_opt_attn_bwd;      // bit 0: whole-row epilogue stores through LDS in the two backward kernels (A/B switch)
+extern int g_opt_attn_bwd;      // backward kernels: bit 0 = whole-row epilogue stores through LDS (A/B switch)
 extern int g_opt_reserve_cus;   // CUs the persistent grids leave to concurrent kernels (csrc/gemm.hip)
 // Persistent-block schedule: the grid is one (dK/dV) or two (forward, dQ) blocks per CU; hardware block L (dispatched to XCD L % 8) owns
 // bin k = L / 8 of its XCD.  The XCD's work items -- (tile, batch*head) for its contiguous eighth of the (batch, head) pairs,
@@ -250,6 +250,9 @@ __device__ __forceinline__ void store_rows_via_lds(char* strip, const f32x16 (&a
   }
   __builtin_amdgcn_wave_barrier();
 }
+// (A coalesced form of the prologue fetches -- Q / dO / O / K as 128-byte half rows, 8 rows per load instruction, turned into fragments
+// through wave-private 4-KB LDS strips -- was built, bit-identical and measured NEUTRAL in all three kernels (backward 242.2 vs 242.3 us,
+// profiles/r06_attn_ab.log): the fragments' 32-byte pieces of 32 rows per instruction are absorbed by the vector L1.  Removed.)
 #define QK_STAGE 32768  // K 16384 | V 16384
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ o,
                                                           float* __restrict__ lse, int B, int H, int S, int perxcd) {
@@ -494,6 +497,9 @@ __device__ __forceinline__ float half_swap_max(float v) {   // max over the two 
 #ifndef F2_VEARLY
 #define F2_VEARLY 1       // first two transposed V fragment sets requested under the last two k-steps of S
 #endif
+#ifndef F2_QPREFETCH
+#define F2_QPREFETCH 1    // touch the next item's query rows (L2 prefetch) two steps before the end of an item
+#endif
 #ifdef ATTN_STAMP      // experiment build: per-block sums of shader-clock intervals (wave 0), tools/experiments/r06_fwd_stamps.py
 #define STAMP_ARG , unsigned long long* __restrict__ stamp
 #define STAMP_DECL unsigned long long st_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_readcyclecounter(); const unsigned long long st_t0 = st_t;
@@ -513,6 +519,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const int T = (S + 127) / 128;
   const AttnSched sched = attn_sched(T, B * H, perxcd);
   int tile_, bh;
+#if F2_QPREFETCH
+  unsigned pf_reg = 0;    // landing register of the next item's Q prefetch (kept alive until that item has waited for its loads)
+#endif
   for (int round = 0; attn_item(sched, round, tile_, bh); ++round) {
   const int qt = T - 1 - tile_;  // heaviest (latest) query tiles first
   const int b = bh / H, hh = bh % H;
@@ -595,13 +604,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     return half_swap_max(v);
   };
   // K(j + 2) and V(j + 1) on their way at the top of step j: their slots' last readers are behind the previous step's barrier
+#if F2_QPREFETCH
+  // The NEXT item's query rows, touched two steps before this item ends: one dword per 128-byte line (lane l: row l / 2, half l % 2 of
+  // this wave's 32 rows), so that the item's real loads find them in L2.  Issued BEHIND the step's DMA and left in flight across the
+  // step's barrier (vmcnt(1): loads return in order); the landing register stays reserved until the next item has waited for everything.
+  int ntile, nbh;
+  const bool has_next_item = attn_item(sched, round + 1, ntile, nbh);
+  const int jpf = nsteps > 2 ? nsteps - 3 : 0;
+  const bf16_t* pf_ptr = qkv;
+  if (has_next_item) {
+    int prow = (T - 1 - ntile) * 128 + wid * 32 + (lane >> 1);
+    prow = prow < S ? prow : S - 1;
+    pf_ptr = qkv + ((int64_t)(nbh / H) * S + prow) * ld3 + (nbh % H) * HD + 64 * (lane & 1);
+  }
+#endif
   auto step_dma = [&](int j) {
 #ifndef ATTN_DBG_NODMA
     if (j + 2 < nsteps) stage_k(j & 1, 64 * (j + 2));
     if (j + 1 < nsteps) stage_v((j + 1) & 1, 64 * (j + 1));
 #endif
+#if F2_QPREFETCH
+    if (j == jpf && has_next_item) asm volatile("global_load_dword %0, %1, off" : "=v"(pf_reg) : "v"(pf_ptr) : "memory");
+#endif
   };
-  auto step_end = [&]() {
+  auto step_end = [&](int j) {
+#if F2_QPREFETCH
+    if (j == jpf && has_next_item) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+    else
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifndef ATTN_DBG_NOBARRIER
     __builtin_amdgcn_s_barrier();
@@ -725,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     __builtin_amdgcn_sched_barrier(0);
 #endif
     STAMP(2)
-    step_end();
+    step_end(j);
     STAMP(3)
     STAMP_COUNT(6)
   };
@@ -737,6 +767,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   stage_v(0, 0);
   if (nsteps > 1) stage_k(1, 64);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if F2_QPREFETCH
+  asm volatile("" : "+v"(pf_reg));      // (the previous item's prefetch has landed by now: the register may be reused)
+#endif
   __syncthreads();
   {
 #pragma unroll
@@ -772,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   STAMP(8)
   for (j = jmax + 1; j < nsteps; ++j) {
     step_dma(j);
-    step_end();
+    step_end(j);
   }
   STAMP(7)
 
@@ -838,10 +871,11 @@ extern "C" int dmi_attention_fwd(const uint16_t* qkv, uint16_t* o, float* lse, i
 // The kernel also produces delta[q] = sum_d dO[q,d] O[q,d] itself (a lane pair holds the whole dO row of its query as MFMA
 // fragments; O is read in the same layout) and publishes the (lse, delta) pairs the dK/dV kernel streams in -- the
 // separate delta pass (17 us per layer) is gone.
+template <int rowstore>      // [r06] 1: whole-row epilogue stores through LDS strips; 0: the round-2 form (A/B)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ o,
                                                              const bf16_t* __restrict__ d_o, const float* __restrict__ lse,
                                                              float* __restrict__ delta, float* __restrict__ stats,
-                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd, int rowstore) {
+                                                             bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // 2 x QK_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const int T = (S + 127) / 128;
@@ -865,21 +899,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + d), 0, nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 2 * d), 0, nbytes, 0x00020000);
 
-  bf16x8 qf[8], dof[8];
+  bf16x8 qf[8], dof[8], of_[8];
 #pragma unroll
   for (int kk = 0; kk < 8; ++kk) {
     qf[kk] = *(const bf16x8*)(qb + (int64_t)qrow_c * ld3 + 16 * kk + 8 * h);
     dof[kk] = *(const bf16x8*)(dob + (int64_t)qrow_c * d + 16 * kk + 8 * h);
+    of_[kk] = *(const bf16x8*)(o + ((int64_t)b * S + qrow_c) * d + hh * HD + 16 * kk + 8 * h);
   }
   const float lse_q = lse[(int64_t)bh * S + qrow_c];
   const float lse2_q = lse_q * LOG2E_F;   // p = exp2(s * log2(e) - lse * log2(e)): one fma + one v_exp_f32 per element
   float delta_q = 0.f;
   {
-    const bf16_t* ob = o + (int64_t)b * S * d + hh * HD;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
       float fo[8], fd[8];
-      unpack8(*(const u32x4*)(ob + (int64_t)qrow_c * d + 16 * kk + 8 * h), fo);
+      unpack8(__builtin_bit_cast(u32x4, of_[kk]), fo);
       unpack8(__builtin_bit_cast(u32x4, dof[kk]), fd);
 #pragma unroll
       for (int j = 0; j < 8; ++j) delta_q += fo[j] * fd[j];
@@ -996,7 +1030,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
   }
   if (j < nsteps) compute(0, j);
 
-  if (rowstore) {   // [r06] whole-row stores through a wave-private LDS strip (behind a barrier: the last tile's readers are done)
+  if constexpr (rowstore) {   // [r06] whole-row stores through a wave-private LDS strip (behind a barrier: the last tile's readers are done)
     __syncthreads();
     store_rows_via_lds(sm + wid * (32 * ROWS_PITCH), dq, 1.0f, dqkv + ((int64_t)b * S + q0 + wid * 32) * ld3 + hh * HD, ld3, S - (q0 + wid * 32), lane);
   } else if (qrow < S) {
@@ -1055,9 +1089,10 @@ __device__ __forceinline__ void st8_wait(St8& f) {
                : "n"(N)
                : "memory");
 }
+template <int rowstore>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ d_o,
                                                                const float* __restrict__ stats /* [B,H,S,2] (lse * log2 e, delta) */,
-                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd, int rowstore) {
+                                                               bf16_t* __restrict__ dqkv, int B, int H, int S, int perxcd) {
   extern __shared__ __attribute__((aligned(16))) char sm[];  // V 32768 | 4 x DKV_STAGE
   const int d = H * HD, ld3 = 3 * d;
   const AttnSched sched = attn_sched((S + 127) / 128, B * H, perxcd);
@@ -1315,7 +1350,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
 #undef DKV_WAIT
 #undef DKV_BARRIER
 
-  if (rowstore) {   // [r06] whole-row stores (every step ended with a barrier: the ring and the V tile have no readers left)
+  if constexpr (rowstore) {   // [r06] whole-row stores (every step ended with a barrier: the ring and the V tile have no readers left)
     bf16_t* gk = dqkv + ((int64_t)b * S + key0 + wid * 32) * ld3 + d + hh * HD;
     char* strip = sm + wid * (2 * 32 * ROWS_PITCH);
     store_rows_via_lds(strip, dk, 1.0f, gk, ld3, S - (key0 + wid * 32), lane);
@@ -1352,21 +1387,25 @@ extern "C" int dmi_attention_bwd(const uint16_t* qkv, const uint16_t* o, const u
   static bool attr_done = false;
   const int shm = 32768 + DKV_NSTAGE * DKV_STAGE;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QK_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     attr_done = true;
   }
   const int items = ((S + 127) / 128) * B * H;
   {
     const int grid = items < 2 * attn_num_cus() ? items : 2 * attn_num_cus();   // two persistent blocks per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    attn_bwd_dq_kernel<<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd, g_opt_attn_bwd & 1);
+    if (g_opt_attn_bwd & 1) attn_bwd_dq_kernel<1><<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd);
+    else attn_bwd_dq_kernel<0><<<dim3(grid), dim3(256), 2 * QK_STAGE, st>>>(qkv, o, d_o, lse, delta, stats, dqkv, B, H, S, perxcd);
   }
   DMI_CHECK_LAUNCH("attention_bwd_dq");
   {
     const int grid = items < attn_num_cus() ? items : attn_num_cus();   // one persistent block per CU
     const int perxcd = g_opt_attn_xcd && (B * H) % 8 == 0 && grid % 8 == 0;
-    attn_bwd_dkv_kernel<<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd, g_opt_attn_bwd & 1);
+    if (g_opt_attn_bwd & 1) attn_bwd_dkv_kernel<1><<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd);
+    else attn_bwd_dkv_kernel<0><<<dim3(grid), dim3(256), shm, st>>>(qkv, d_o, stats, dqkv, B, H, S, perxcd);
   }
   DMI_CHECK_LAUNCH("attention_bwd_dkv");
   return DMI_OK;

@@ -912,6 +912,59 @@ def test_persistent_grids_with_reserved_cus():
     assert torch.equal(base, again) and torch.equal(C0, C1)
 
 
+@pytest.mark.parametrize("B,H,S", [(2, 4, 264), (1, 4, 1280), (2, 1, 72)])
+def test_attention_round6_forms_vs_round2_kernels(B, H, S):
+    """[r06] options attn_fwd / attn_bwd select the round-2 kernels (0) or the round-6 forms (1, default).  Backward: coalesced prologue
+    fetches and whole-row epilogue stores through LDS strips move the same numbers -- bit-identical.  Forward: the software-pipelined kernel
+    keeps its running maximum as an integer power of two and defers rescales, i.e. P is rounded to bf16 at another scale: outputs agree to
+    one bf16 ulp of the output range, lse to fp32 rounding; both forms are checked against fp32 autograd by _attention_fwd_bwd."""
+    out = {}
+    for ver in (0, 1):
+        dh.set_option("attn_fwd", ver)
+        dh.set_option("attn_bwd", ver)
+        try:
+            dqkv = _attention_fwd_bwd(B, H, S)
+            d = H * 128
+            g = torch.Generator().manual_seed(S + 1)
+            qkv = (torch.randn(B * S, 3 * d, generator=g) * 0.3).to(torch.bfloat16).to(DEV)
+            o = torch.zeros(B * S, d, dtype=torch.bfloat16, device=DEV)
+            lse = torch.zeros(B, H, S, dtype=torch.float32, device=DEV)
+            dh.attention_fwd(qkv, o, lse, B, H, S)
+            dq2 = torch.zeros(B * S, 3 * d, dtype=torch.bfloat16, device=DEV)
+            if ver == 1:
+                o_use, lse_use = out[0][1], out[0][2]       # the same saved forward for both backward forms
+            else:
+                o_use, lse_use = o, lse
+            dh.attention_bwd(qkv, o_use, rnd(B * S, d, seed=3).to(DEV), lse_use, torch.zeros(3, B, H, S, dtype=torch.float32, device=DEV), dq2, B, H, S)
+            out[ver] = (dqkv, o.clone(), lse.clone(), dq2)
+        finally:
+            dh.set_option("attn_fwd", 1)
+            dh.set_option("attn_bwd", 1)
+    assert torch.equal(out[0][3], out[1][3]), "backward forms must be bit-identical on the same inputs"
+    do_ = (out[0][1].float() - out[1][1].float()).abs()
+    assert float(do_.max()) <= 2.0 ** -7 * max(1.0, float(out[0][1].float().abs().max())), float(do_.max())
+    close(out[1][2], out[0][2], 1e-5, 1e-5, "lse, round-6 vs round-2 forward")
+
+
+@pytest.mark.parametrize("keyrow,qrow,mult", [(700, 900, 3.0), (5, 70, 2.0), (643, 900, 3.0), (675, 901, 1.5), (130, 140, 3.0), (1279, 1279, 3.0)])
+def test_attention_fwd_late_spike(keyrow, qrow, mult):
+    """[r06] one key far above everything a query has seen before (score ~ mult * |q|^2, hundreds of base-2 exponent units above the
+    running maximum), in the lower and in the upper half-row lanes, in the first tile, in a steady-state tile and on the diagonal: the
+    deferred rescale must fire with an exact (possibly flushed-to-zero) factor and the row maximum must cover BOTH half rows -- the first
+    build took it from the lower half only (a compiler fold of the permlane32 swap builtin), invisible on ordinary scores, inf here."""
+    B, H, S = 1, 1, 1280
+    torch.manual_seed(5)
+    qkv = torch.randn(S, 3 * 128).to(torch.bfloat16)
+    qkv[keyrow, 128:256] = (qkv[qrow, :128].float() * mult).to(torch.bfloat16)
+    o = torch.zeros(S, 128, dtype=torch.bfloat16, device=DEV)
+    lse = torch.zeros(1, 1, S, dtype=torch.float32, device=DEV)
+    dh.attention_fwd(qkv.to(DEV), o, lse, B, H, S)
+    o_ref, lse_ref = _attn_ref(qkv, B, H, S)
+    assert torch.isfinite(lse).all() and torch.isfinite(o.float()).all()
+    close(lse, lse_ref, 1e-5, 2e-3, "lse with a late spike")
+    close(o, o_ref, 1.6e-2, 3e-2, "o with a late spike")
+
+
 def test_attention_row0_kat():
     """causal mask: query 0 attends only to key 0 -> o[0] == v[0] exactly (bf16 round trip)."""
     B, H, S = 1, 1, 128
