@@ -129,8 +129,14 @@ class GradReducer:
     as g[lo:hi] is final on the CURRENT stream; finish() must precede the first consumer of the reduced gradients."""
 
     def __init__(self, flat_g: torch.Tensor, world: int, comm: Optional[int] = None, pg=None,
-                 max_bucket_bytes: int = MAX_BUCKET_BYTES):
+                 max_bucket_bytes: int = MAX_BUCKET_BYTES, timeout_s: Optional[float] = None):
         self.g, self.world, self.comm, self.pg = flat_g, world, comm, pg
+        # [r06] A rank that fails inside ready() (a collective that raises, an error in the kernels before it) leaves its peers with
+        # collectives it never joins.  They must not wait for ever: finish() waits at most `timeout_s` per collective on the torch
+        # transport (DALLE_DP_TIMEOUT_S, default 600) and raises; a failing rank remembers its error, stops issuing and re-raises from
+        # finish() as well, so that every rank leaves the step with an exception inside a bounded time (tests/test_dp_gloo.py).
+        self.timeout_s = float(os.environ.get("DALLE_DP_TIMEOUT_S", "600")) if timeout_s is None else float(timeout_s)
+        self.failed: Optional[BaseException] = None
         self.transport = "rccl" if comm else "torch"
         self.max_elems = max(1, max_bucket_bytes // 4)
         self.stream = torch.cuda.Stream(device=flat_g.device) if (comm and flat_g.is_cuda) else None
@@ -150,6 +156,15 @@ class GradReducer:
     def ready(self, lo: int, hi: int):
         if self.world <= 1 or hi <= lo:
             return
+        if self.failed is not None:        # a previous piece of this step failed here: issue nothing more, finish() reports it
+            return
+        try:
+            self._issue(lo, hi)
+        except BaseException as e:
+            self.failed = e
+            raise
+
+    def _issue(self, lo: int, hi: int):
         if self.transport == "rccl":
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
@@ -173,9 +188,24 @@ class GradReducer:
                 torch.cuda.current_stream().wait_event(ev)
                 self._issued = False
         else:
-            for h in self._pending:
-                h.wait()
-            self._pending = []
+            import datetime
+            pending, self._pending = self._pending, []
+            err = self.failed
+            for i, h in enumerate(pending):
+                if err is not None:
+                    break                   # (this rank failed, or a peer did: the remaining handles can never complete)
+                try:
+                    h.wait(timeout=datetime.timedelta(seconds=self.timeout_s))
+                except BaseException as e:
+                    err = RuntimeError(f"[dp] collective {i + 1} of {len(pending)} of this step did not complete within {self.timeout_s:.0f} s "
+                                       f"or failed -- a peer rank has left the gradient exchange: {e}")
+            if err is not None:
+                self.last_log, self.log, self.failed = self.log, [], None
+                raise err
+        if self.failed is not None:
+            err, self.failed = self.failed, None
+            self.last_log, self.log = self.log, []
+            raise err
         self.last_log, self.log = self.log, []
 
     def broadcast(self, buf: torch.Tensor, root: int = 0):

@@ -160,6 +160,72 @@ def test_transport_choice_is_collective(scenario, strict):
             assert not r0["init_entered"] and not r1["init_entered"] and r0["destroyed"] == []
 
 
+def _failing_rank_worker(rank, world, init_file, out_file, scenario):
+    """[r06] rank 1 fails inside GradReducer.ready() on its SECOND piece; rank 0 issues its whole schedule.
+    scenario "exit": rank 1's exception ends the process (what a training script does);
+    scenario "stay": rank 1 catches it and stays alive without ever joining the remaining collectives (the hard case: no
+    connection breaks, only the bounded wait in finish() can release rank 0)."""
+    import time
+    from src.dp import GradReducer
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    g = torch.full((4096,), float(rank + 1))
+    red = GradReducer(g, world, comm=None, pg=dist.group.WORLD, max_bucket_bytes=4096, timeout_s=5.0)
+    if rank == 1:
+        real, calls = dist.all_reduce, [0]
+
+        def flaky(*a, **k):
+            calls[0] += 1
+            if calls[0] == 2:
+                raise RuntimeError("simulated collective failure on rank 1")
+            return real(*a, **k)
+        dist.all_reduce = flaky
+    t0 = time.time()
+    where, msg = None, ""
+    try:
+        red.ready(0, 2048)        # pieces 1, 2 (rank 1 dies in piece 2)
+        where = "ready-2"
+        red.ready(2048, 4096)     # pieces 3, 4: a failed rank must issue nothing more
+        where = "finish"
+        red.finish()
+        where = "done"
+    except RuntimeError as e:
+        msg = str(e)
+    issued = len(red.last_log) + len(red.log)
+    # a failed reducer reports (again) from finish() and is clean afterwards
+    again = None
+    if rank == 1:
+        again = []
+        for _ in range(2):
+            try:
+                red.finish()
+                again.append("no error")
+            except RuntimeError as e:
+                again.append(str(e))
+    torch.save(dict(where=where, msg=msg, again=again, seconds=time.time() - t0, issued=issued,
+                    pending=len(red._pending), failed=red.failed is not None), f"{out_file}.{rank}")
+    if scenario == "stay" and rank == 1:
+        time.sleep(12.0)          # alive, silent, never joins pieces 2..4
+    os._exit(0)                   # (no destroy_process_group: it would try to drain the broken collectives)
+
+
+@pytest.mark.parametrize("scenario", ["exit", "stay"])
+def test_a_rank_failing_inside_ready_cannot_block_its_peers(scenario):
+    """one rank's failure inside GradReducer.ready() must surface on EVERY rank inside a bounded time -- the failing
+    rank raises at once, stops issuing and re-raises from finish(); its peer's finish() gives up after `timeout_s` per collective
+    (or as soon as the connection breaks) with a message that names the exchange, instead of waiting in all_reduce for ever."""
+    with tempfile.TemporaryDirectory() as d:
+        init_file, out_file = os.path.join(d, "init"), os.path.join(d, "out")
+        mp.spawn(_failing_rank_worker, args=(2, init_file, out_file, scenario), nprocs=2, join=True)
+        r0, r1 = torch.load(f"{out_file}.0"), torch.load(f"{out_file}.1")
+        # rank 1: raised inside its first ready(), issued exactly one collective, nothing pending afterwards
+        assert r1["where"] is None and "simulated collective failure" in r1["msg"], r1
+        assert r1["issued"] == 1 and not r1["failed"], r1
+        assert "simulated collective failure" in r1["again"][0] and r1["again"][1] == "no error", r1     # reported once more by finish(), then clean
+        # rank 0: issued all four, then finish() raised inside the bound (5 s per collective; far less when the peer's exit breaks the pair)
+        assert r0["where"] == "finish" and "left the gradient exchange" in r0["msg"], r0
+        assert r0["seconds"] < 30.0 and r0["pending"] == 0, r0
+
+
 def test_bench_schedule_summary_and_strong_scaling_follow_the_layout():
     """bench.py's description of the exchange (`dp_piece_MB`, `dp_exposed_tail_MB`, `dp_largest_piece_MB`) against
     ParamLayout.ready_points at the BASELINE architecture, and `--scaling strong`'s batch rule -- so that the first multi-GPU line
