@@ -975,6 +975,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) s[e] = dp[e] = 0.f;
+      // (K / V row fragments by inline asm one k-step ahead of their MFMAs -- what the round-6 forward kernel does -- measured SLOWER here
+      // than hipcc's own read-wait-MFMA schedule of these C++ loads: backward 252.5 vs 249.5 us, profiles/r06_attn_ab.log.  Not kept.)
 #pragma unroll
       for (int kk = 0; kk < 8; ++kk) {
         const bf16x8 ka = *(const bf16x8*)(base + kt2 * 8192 + ofa[kk]);
