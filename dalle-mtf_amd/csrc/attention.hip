@@ -1214,6 +1214,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const bf16_t* __re
   // Q / dO rows and stats read as zeros (buffer bounds), so dS = 0 and P multiplies a zero dO row.
   auto softmax_pair = [&](auto mask_c, int i, const St8& stt, const f32x16& s, const f32x16& dp, int kd, unsigned* pw, unsigned* dw) {
     constexpr bool MASK = decltype(mask_c)::value;
+#ifdef ATTN_DBG_DKV_NOSOFTMAX     // experiment: what the softmax / dS VALU chain of phase A costs (upper bound of any re-placement)
+    pw[i] = pack2bf(s[2 * i], s[2 * i + 1]);
+    dw[i] = pack2bf(dp[2 * i], dp[2 * i + 1]);
+    asm volatile("" : "+v"(pw[i]), "+v"(dw[i]));
+    return;
+#endif
     const int g = i >> 1;                       // elements 4g + {0,1} (i even) or 4g + {2,3} (i odd)
     const f32x4 sv = stt.v[i];                  // (l2, delta) of rows 8g + 4h + 2(i&1) + {0, 1}
     float x0 = __builtin_fmaf(s[2 * i], LOG2E_F, -sv[0]);
