@@ -329,8 +329,9 @@ def test_ten_step_trajectory_at_the_dalle_example_shape_vs_fp32_oracle():
     fused -- dispatch at the exact dalle_example architecture, B = 1, S = 1280.
     (a) THE CONTRACT: the first ten steps of training as the shipped config runs them -- global steps 0..9 of a 3000-step linear warm-up
         (lr = 0, 3.3e-7, ..., 3e-6): |dloss| <= 1e-2 relative at every step (measured <= 1e-4) and the parameters of the two runs stay
-        within 2 x 3.16 x sum(lr) of each other (Adam without bias correction moves a weight by up to 3.16 lr per step; a noise-level
-        gradient whose sign differs moves it the other way).
+        within 2 x 6.6 x sum(lr) of each other (Adam without bias correction moves a weight by lr * m / sqrt(v) with
+        |m| / sqrt(v) <= (1 - 0.9^t) / sqrt(1 - 0.999^t): 3.16 at t = 1, 6.5 at t = 10; a noise-level gradient whose sign differs
+        moves it the other way).
     (b) A STRESS the contract does not ask for, kept because it is the only trajectory in the suite that actually descends: ten steps from
         schedule position 1500 (lr 5e-4) on that single sequence -- the loss falls 11.0 -> 5.0, i.e. the model memorises the batch with
         sign-like 1.6e-3 updates per weight and step.  Steps 0..4 agree to 2e-4 (asserted 1e-3).  From step 5 the fit OVERSHOOTS: the
@@ -343,7 +344,7 @@ def test_ten_step_trajectory_at_the_dalle_example_shape_vs_fp32_oracle():
     lr_sum = sum(r["lr"] for r in rows_a)
     for r in rows_a:
         assert r["rel"] <= 1e-2, r
-    assert drift_a <= 2 * 3.17 * lr_sum + 1e-7, (drift_a, lr_sum)
+    assert drift_a <= 2 * 6.6 * lr_sum + 1e-7, (drift_a, lr_sum)
     rows_b, _ = _trajectory(1500)
     save_report("parity_dalle_example_trajectory.json", dict(contract=rows_a, contract_param_drift=drift_a, stress=rows_b))
     assert rows_b[-1]["loss_oracle"] < rows_b[0]["loss_oracle"] - 0.5, "the stress trajectory must actually move"
