@@ -51,19 +51,25 @@ def test_no_kernel_uses_scratch(usage):
     bad = {k: v for k, v in usage.items() if v["scratch"] or v["vgpr_spill"]}
     assert not bad, bad
     # scalar registers spilled into VGPR lanes (v_writelane / v_readlane, no memory) are tolerated where they exist today: a few
-    # instantiations of the persistent 256x256 NT kernel, whose eight buffer descriptors and tile bookkeeping exceed the SGPR file
+    # instantiations of the persistent 256x256 NT kernel, whose eight buffer descriptors and tile bookkeeping exceed the SGPR file,
+    # and [r06] the software-pipelined attention forward kernel (two buffer descriptors, eight LDS-DMA destinations, the item schedule
+    # and the next item's prefetch state: 45 lanes, all read / written at item boundaries -- the two 32-MFMA step bodies contain no
+    # v_readlane / v_writelane, checked on the disassembly)
     sg = {k: v["sgpr_spill"] for k, v in usage.items() if v["sgpr_spill"]}
-    assert all("gemm_nt8p_kernel" in k for k in sg) and all(n <= 28 for n in sg.values()), sg
+    assert all("gemm_nt8p_kernel" in k or "attn_fwd2_kernel" in k for k in sg), sg
+    assert all(n <= (48 if "attn_fwd2_kernel" in k else 28) for k, n in sg.items()), sg
 
 
 def test_two_blocks_per_cu_kernels_fit_two_waves_per_simd(usage):
     """launch_bounds(256, 2) kernels: 256 registers (VGPR + AGPR) per lane at most, reported occupancy >= 2; the dK/dV attention
     kernel is the one deliberate one-wave-per-SIMD kernel (252 + 256 registers)"""
     two = [k for k in usage if re.search(r"gemm_nt8p_kernel|gemm_ntr_kernel|gemm_nt8_kernel|gemm_tn_kernel|gemm_tn_tail_kernel|conv_wgrad_tn_kernel|"
-                                          r"conv_gemm_nt_kernel|attn_fwd_kernel|attn_bwd_dq_kernel", k)]
+                                          r"conv_gemm_nt_kernel|attn_fwd_kernel|attn_fwd2_kernel|attn_bwd_dq_kernel", k)]
     assert len(two) >= 30, two
     for k in two:
         u = usage[k]
         assert u["occupancy"] >= 2 and u["vgpr"] + u["agpr"] <= 256, (k, u)
     dkv = [k for k in usage if "attn_bwd_dkv_kernel" in k]
-    assert len(dkv) == 1 and usage[dkv[0]]["occupancy"] == 1 and usage[dkv[0]]["vgpr"] + usage[dkv[0]]["agpr"] <= 512
+    assert len(dkv) == 2      # [r06] the round-2 epilogue (A/B arm) and the whole-row one
+    for k in dkv:
+        assert usage[k]["occupancy"] == 1 and usage[k]["vgpr"] + usage[k]["agpr"] <= 512, (k, usage[k])
