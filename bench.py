@@ -45,7 +45,7 @@ VAE_MODELS = {"vae_example": 32, "vae_coco": 16}     # per-GPU batch (SURVEY §8
 HP = dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0)
 PER_GPU_BATCH = 32
 PEAK_BF16_TFLOPS = 2500.0
-ROUND_TAG = "r05"      # profiles/<ROUND_TAG>_traffic_*.json must come from this round's kernels
+ROUND_TAG = "r06"      # profiles/<ROUND_TAG>_traffic_*.json must come from this round's kernels
 
 
 def fwd_flops_per_token(d, L, S, V):
