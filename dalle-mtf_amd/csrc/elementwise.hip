@@ -1249,18 +1249,16 @@ extern "C" int dmi_sum_f32(const float* x, int64_t n, float scale, float* out, v
 
 #define SUMSQ_BLOCKS 2048
 extern "C" int64_t dmi_sumsq_workspace_bytes(int64_t n) { (void)n; return SUMSQ_BLOCKS * 4; }
-// [r06] The sweep runs from the END of the buffer to its start: the flat gradient buffer is laid out in backward's completion order
-// (head first, embeddings last), so at clip time its tail -- the 104 MB of embedding gradients written microseconds ago -- is what the
-// 256-MB Infinity Cache still holds, and a front-to-back sweep evicts it before reaching it (cyclic LRU).  Adam, which follows, sweeps
-// front to back and meets the lines this sweep touched last.  Same per-thread partial sums in another (fixed) order.
-extern int g_opt_sumsq_rev;
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part, int rev) {
+// (A sweep from the END of the buffer -- the flat gradient buffer is laid out in backward's completion order, so its tail is what the 256-MB
+// Infinity Cache should still hold at clip time -- measured -0.03 ms per step on one box over three alternations, 0.00 on another over four,
+// and slightly slower with Adam behind it in isolation: neutral, not kept.  profiles/r06_ab_sumsq_rev.log)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ part) {
   __shared__ float sm[4];
   float acc = 0.f;
   const int64_t n4 = n / 4;
   const f32x4* g4 = (const f32x4*)g;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const f32x4 v = g4[rev ? n4 - 1 - i : i];
+    const f32x4 v = g4[i];
     acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
@@ -1274,7 +1272,7 @@ extern "C" int dmi_sumsq(const float* g, int64_t n, float* out, void* workspace,
   DMI_REQUIRE(g && out && workspace && n > 0, "sumsq: bad args");
   DMI_REQUIRE(((uintptr_t)g & 15) == 0, "sumsq: g must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  sumsq_kernel<<<dim3(SUMSQ_BLOCKS), dim3(256), 0, st>>>(g, n, (float*)workspace, g_opt_sumsq_rev);
+  sumsq_kernel<<<dim3(SUMSQ_BLOCKS), dim3(256), 0, st>>>(g, n, (float*)workspace);
   DMI_CHECK_LAUNCH("sumsq");
   sum_f32_kernel<<<dim3(1), dim3(1024), 0, st>>>((const float*)workspace, SUMSQ_BLOCKS, 1.0f, out);
   DMI_CHECK_LAUNCH("sumsq_finish");

@@ -31,7 +31,6 @@ int g_opt_reserve_cus = 0;       // CUs the persistent kernels (256x256 NT, atte
                                  // the intruder (layer 0's forward 687 us instead of 410 us).  The engine sets 16 when world_size > 1.
 int g_opt_attn_fwd = 1;          // attention forward kernel: 0 round-2 form, 1 software-pipelined (round 6)
 int g_opt_attn_bwd = 1;          // attention backward: bit 0 = whole-row epilogue stores through LDS (round 6)
-int g_opt_sumsq_rev = 1;         // gradient-norm sweep from the end of the buffer (what the Infinity Cache still holds) to its start
 int g_opt_attn_xcd = 8;          // attention block order: 0 plain grid; G >= 1: per-XCD ranges, groups of G (batch, head) pairs tile-major
 static int g_opt_tn8 = 0;        // 256x256 weight-gradient tile (8 waves, still on 32x32x16 MFMAs): 0 never (default since the 128x128 kernel
                                  // moved to 16x16x32: 45 / 76 us vs 60 / 86 us on the 512x512 / 512x1536 gradients), 1 auto (few tiles), 2 always (tests)
@@ -74,7 +73,6 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "tn8_max_tiles")) return g_opt_tn8_max_tiles;
   if (!strcmp(name, "attn_xcd")) return g_opt_attn_xcd;
   if (!strcmp(name, "attn_fwd")) return g_opt_attn_fwd;
-  if (!strcmp(name, "sumsq_rev")) return g_opt_sumsq_rev;
   if (!strcmp(name, "attn_bwd")) return g_opt_attn_bwd;
   if (!strcmp(name, "reserve_cus")) return g_opt_reserve_cus;
   return -1;
@@ -98,7 +96,6 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "tn8_max_tiles")) { g_opt_tn8_max_tiles = value; return 0; }
   if (!strcmp(name, "attn_xcd")) { g_opt_attn_xcd = value; return 0; }
   if (!strcmp(name, "attn_fwd")) { g_opt_attn_fwd = value; return 0; }
-  if (!strcmp(name, "sumsq_rev")) { g_opt_sumsq_rev = value; return 0; }
   if (!strcmp(name, "attn_bwd")) { g_opt_attn_bwd = value; return 0; }
   if (!strcmp(name, "reserve_cus")) { if (value < 0) return -1; g_opt_reserve_cus = value; return 0; }
   return -1;
