@@ -497,6 +497,9 @@ __device__ __forceinline__ float half_swap_max(float v) {   // max over the two 
 #ifndef F2_VEARLY
 #define F2_VEARLY 1       // first two transposed V fragment sets requested under the last two k-steps of S
 #endif
+#ifndef F2_LROUNDED
+#define F2_LROUNDED 1     // normalise O by the sum of the bf16-ROUNDED probabilities (the weights the MFMA actually applies sum to 1)
+#endif
 #ifndef F2_QPREFETCH
 #define F2_QPREFETCH 1    // touch the next item's query rows (L2 prefetch) two steps before the end of an item
 #endif
@@ -579,6 +582,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
 #pragma unroll
     for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
   float m2 = -1e30f, l = 0.f, mx = -1e30f;
+#if F2_LROUNDED
+  float lr_ = 0.f;      // row sum of the bf16-ROUNDED probabilities: what O is normalised by (l, from the unrounded ones, gives lse)
+#endif
 
   const int qlast = (q0 + 127 < S - 1) ? q0 + 127 : S - 1;
   const int nsteps = qlast / 64 + 1;
@@ -654,6 +660,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       const float alpha = __builtin_ldexpf(1.0f, (int)fmaxf(m2 - m2n, -200.0f));
       m2 = m2n;
       l *= alpha;
+#if F2_LROUNDED
+      lr_ *= alpha;
+#endif
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -662,6 +671,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
     STAMP(0)
     unsigned pw[16];
     float rs = 0.f;
+#if F2_LROUNDED
+    float rr = 0.f;
+#endif
     // K fragments F2_KDEPTH k-steps ahead of their MFMAs, the first two transposed V fragment sets under the last two k-steps (F2_VEARLY)
     Fk2 F[F2_KDEPTH + 1];
 #pragma unroll
@@ -741,12 +753,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
       oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.b0, c.b1), pb[ks], oacc[1], 0, 0, 0);
       oacc[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.c0, c.c1), pb[ks], oacc[2], 0, 0, 0);
       oacc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat2(c.d0, c.d1), pb[ks], oacc[3], 0, 0, 0);
+#if F2_LROUNDED      // the row sum of the ROUNDED probabilities rides here, where the VALU is idle: v_dot2c_f32_bf16 against (1, 1), one per packed word
+      {
+        typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+        const bf2_t one2 = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rr = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, pw[4 * ks + q]), one2, rr, false);
+      }
+#endif
 #if F2_VEARLY
       __builtin_amdgcn_sched_barrier(0);
       if (ks == 0) tr4_issue_off<8192>(tv[0], avt);
       if (ks == 1) tr4_issue_off<12288>(tv[1], avt);
 #endif
     }
+#if F2_LROUNDED
+    lr_ += rr;
+#endif
     if (j + 1 == jmax) mask_tile(j + 1, n0, n1);     // (wave-uniform)
     mx = row_max(n0, n1);
 #endif
@@ -812,6 +835,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   // epilogue: normalise, stage this wave's 32 x 128 outputs through its private LDS strip, store whole rows
   l += __shfl_xor(l, 32, 64);
   if (h == 0 && qrow < S) lse[(int64_t)bh * S + qrow] = (m2 + __log2f(l)) * 0.6931471805599453f;
+#if F2_LROUNDED
+  lr_ += __shfl_xor(lr_, 32, 64);
+  l = lr_;
+#endif
   store_rows_via_lds(sm + wid * (32 * ROWS_PITCH), oacc, 1.f / l, o + ((int64_t)b * S + q0 + wid * 32) * d + hh * HD, d, S - (q0 + wid * 32), lane);
   __syncthreads();   // the strips are read before the next item's first DMA
   STAMP(5)
