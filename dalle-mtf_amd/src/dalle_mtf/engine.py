@@ -277,9 +277,8 @@ class DalleEngine:
         self.embed_ws = torch.empty(dh.embed_bwd_workspace_bytes(B, S, d), dtype=torch.uint8, device=self.dev)
         self.sort_stream = torch.cuda.Stream(device=self.dev)
         self._sort_done = None
-        # where the token sort is launched: "forward" = side stream at the start of the forward (rounds 2-6), "backward" = side stream at the
-        # start of the backward (under the head's weight gradient, a many-block kernel), "main" = main stream at the start of the backward
-        self.sort_at = str(self.hp.get("sort_at", os.environ.get("DALLE_SORT_AT", "forward")))
+        # (launching the sort at the start of the BACKWARD instead -- side stream under the head's weight gradient, or on the main stream -- measured
+        # the same within noise: 14.49 / 14.57 / 14.57 ms over three alternations, profiles/r06_ab_sort_at.log)
         # scratch
         self.dx = [torch.empty(M, d, **b16) for _ in range(2)]
         self.dxn = torch.empty(M, d, **b16)
@@ -343,7 +342,7 @@ class DalleEngine:
         assert tokens.shape == (B, S) and tokens.dtype == torch.int32
         self.tokens.copy_(tokens)
         self._sort_done = None
-        if need_grad and self.sort_at == "forward":   # token-id order for the embedding backward: twelve 3-5 us launches on a side stream (see dmi_sort_tokens)
+        if need_grad:   # token-id order for the embedding backward: twelve 3-5 us launches on a side stream (see dmi_sort_tokens)
             self._launch_sort()
         dh.shift_labels(self.tokens, self.labels, B, S, self.eos)
         dh.embed_fwd(self.tokens, self._w("embedding/wte"), self._w("positional_embedding/wpe"), self.X[0], S, d, self.V)
@@ -601,11 +600,6 @@ class DalleEngine:
                        deferred=self.deferred)
 
     def _launch_sort(self):
-        if self.sort_at == "main":
-            dh.sort_tokens(self.tokens, self.tok_sorted, self.tok_perm, self.M, self.V, self.sort_ws)
-            self._sort_done = torch.cuda.Event()
-            self._sort_done.record(torch.cuda.current_stream())
-            return
         main = torch.cuda.current_stream()
         self.sort_stream.wait_stream(main)
         with torch.cuda.stream(self.sort_stream):
