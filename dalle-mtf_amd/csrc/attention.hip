@@ -450,8 +450,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 //     two, so rescaling or not rescaling gives the same bits as long as nothing overflows -- and the O / l rescale (64 multiplies
 //     per lane) runs only when some row's maximum grew by more than 2^16 since its last rescale (on random scores the round-2
 //     kernel's "some row grew at all" fired on nearly every tile).  P <= 2^17 in bf16 (8 exponent bits), l and O in fp32;
+//   * O is normalised by the sum of the bf16-ROUNDED probabilities (v_dot2c_f32_bf16 against (1, 1) in phase B, where the VALU idles), so
+//     the weights the MFMA applies sum to exactly 1; lse keeps the unrounded sum (the backward needs the true one).  Without this the
+//     integer maximum costs accuracy: the dominant probability is no longer exactly 1, its rounding error stops cancelling and peaked
+//     rows carry one extra bf16 rounding (O at 1.47 x pure rounding against 1.02 for the round-2 kernel; 1.05 with the rounded sum);
 //   * O leaves through LDS as whole 256-byte rows (16 B per lane, 4 rows per store instruction) instead of 8-byte pieces of 32 rows
-//     per instruction; the half-row exchange of the row maximum is a v_permlane32_swap instead of a ds_bpermute.
+//     per instruction; the half-row exchange of the row maximum is a v_permlane32_swap (inline asm: the builtin aliases its two results
+//     when both inputs are one value) instead of a ds_bpermute; the next item's query rows are touched two steps before an item ends.
 // Semantics unchanged (reference src/dalle_mtf/models.py:275-299): unscaled fp32 logits, key > query contributes exactly 0.
 struct Fk2 {
   u32x4 a, b;   // K rows r and r + 32 of a 64-key tile, 16-byte chunk of k-step kk
