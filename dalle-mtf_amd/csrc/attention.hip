@@ -544,8 +544,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(const bf16_t* __restr
   const bf16_t* qb = qkv + (int64_t)b * S * ld3 + hh * HD;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)sm;
   const int nbytes = (int)(((int64_t)(S - 1) * ld3 + HD) * 2);
+#ifdef ATTN_DBG_SAMEKV   // experiment: every item streams the K / V of pair (0, 0) -> always L2-resident (prices perfect K / V locality)
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + d), 0, nbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + 2 * d), 0, nbytes, 0x00020000);
+#else
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + d), 0, nbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)(qb + 2 * d), 0, nbytes, 0x00020000);
+#endif
 
   bf16x8 qf[8];
 #pragma unroll
