@@ -38,6 +38,7 @@ static int g_opt_tn8_max_tiles = 16;   // auto mode: use the 256x256 weight-grad
 static int g_opt_nt8_min_k = 2048;   // auto mode of the 256x256 NT tile: minimum K.  2048 (was 4096): the 1.3B dimensions' K = 2048 products
                                      // run 354 -> 339 ms/step (profiles/r03_ab_nt8_min_k.log); K = 1024 measured equal, K = 512 slower
 static int g_opt_skinny = 1;     // M <= 32 products (the decode step) on the weight-streaming kernel: 0 never, 1 auto
+static int g_opt_tn_wide = 1;    // [r06] unsplit weight gradients with many column stripes (the head) as a gang stream-K on 128 x 256 tiles: 0 never, 1 auto
 static int g_opt_tn_tail = 1;    // weight gradients: row-split the tiles of a ragged last residency (see gemm_tn_tail_kernel)
 static int g_opt_cstream = 1;    // bf16 outputs stored write-through (sc1; + non-temporal from cstream_nt_min_mb MiB): 0 never, 1 auto (outputs >=
                                  // cstream_min_mb MiB: they cannot be re-read from L2 anyway, and as plain stores they evict the operands the concurrent
@@ -58,6 +59,7 @@ extern "C" int dmi_get_option(const char* name) {
   if (!strcmp(name, "nt4")) return g_opt_nt4;
   if (!strcmp(name, "nt8")) return g_opt_nt8;
   if (!strcmp(name, "tn_tail")) return g_opt_tn_tail;
+  if (!strcmp(name, "tn_wide")) return g_opt_tn_wide;
   if (!strcmp(name, "nt4_lds")) return g_opt_nt4_lds;
   if (!strcmp(name, "nt8p")) return g_opt_nt8p;
   if (!strcmp(name, "ntr")) return g_opt_ntr;
@@ -81,6 +83,7 @@ extern "C" int dmi_set_option(const char* name, int value) {
   if (!strcmp(name, "nt4")) { g_opt_nt4 = value; return 0; }
   if (!strcmp(name, "nt8")) { g_opt_nt8 = value; return 0; }
   if (!strcmp(name, "tn_tail")) { g_opt_tn_tail = value; return 0; }
+  if (!strcmp(name, "tn_wide")) { g_opt_tn_wide = value; return 0; }
   if (!strcmp(name, "nt4_lds")) { if (value < 49152 || value > 163840) return -1; g_opt_nt4_lds = value; return 0; }
   if (!strcmp(name, "nt8p")) { g_opt_nt8p = value; return 0; }
   if (!strcmp(name, "ntr")) { g_opt_ntr = value; return 0; }
@@ -2549,6 +2552,263 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
                  a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr);
 }
 
+// ---- [r06] wide weight-gradient tile (128 (I) x 256 (J), 4 waves of 64 x 128, 32-row steps) as a gang stream-K --------------------
+// The 128x128 tile moves 32 KB through the LDS-DMA path per 2.1-MFLOP block step and two co-resident blocks run that path at the
+// ~32-36 B/clk/CU it delivers (the head's gradient: 2047 clk per block step for 515 clk of MFMA issue, twice per CU).  This tile
+// moves 24 KB for the same 2.1 MFLOP (32 rows x (128 + 256) columns), reads 24 transposed fragments per 32 MFMAs instead of 32, and
+// keeps everything else: two blocks per CU (2 x 48 KB LDS, 128 accumulator registers), one barrier per 32 MFMAs per wave, the same
+// source-side swizzle (per 256-byte segment of a row), the same bias path and the same k order (32-row chunks in row order: a whole
+// stripe has the 128x128 kernel's bits).  Measured where whole tiles fill whole residencies (M = 40960, I = 512, J = 65536): 2578 ->
+// 2063 us = 1066 -> 1332 TFLOP/s; the transposed shape (256 x 128) 5 % behind it; on the row-split gradients of the layers (32 tiles x 16
+// splits instead of 64 x 8) slower (88 -> 97 us: twice the slabs, half as long blocks) -- those stay on the 128x128 tile
+// (profiles/r06_tn_wide.log).
+#define TNW_BKM 32
+#define TNW_TI 128
+#define TNW_TJ 256
+#define TNW_XB (TNW_BKM * TNW_TI * 2)     // bytes of a stage's X image (row pitch 256 B)
+#define TNW_YB (TNW_BKM * TNW_TJ * 2)     // ... Y image (row pitch 512 B)
+#define TNW_STB (TNW_XB + TNW_YB)
+#define TNW_LDS_BYTES (2 * TNW_STB + 512)  // two stages + two 256-B bias-weight strips
+template <int OFFA, int OFFB>
+__device__ __forceinline__ void trw_issue(TrHalf16& f, const unsigned (&ad)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+      "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+      "ds_read_b64_tr_b16 %7, %11 offset:%13"
+      : "=&v"(f.t[0][0]), "=&v"(f.t[0][1]), "=&v"(f.t[1][0]), "=&v"(f.t[1][1]), "=&v"(f.t[2][0]), "=&v"(f.t[2][1]),
+        "=&v"(f.t[3][0]), "=&v"(f.t[3][1])
+      : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "i"(OFFA), "i"(OFFB)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void trw_wait(TrHalf16& x, TrHalf16& y, TrHalf16& z) {
+  asm volatile("s_waitcnt lgkmcnt(%24)"
+               : "+v"(x.t[0][0]), "+v"(x.t[0][1]), "+v"(x.t[1][0]), "+v"(x.t[1][1]), "+v"(x.t[2][0]), "+v"(x.t[2][1]),
+                 "+v"(x.t[3][0]), "+v"(x.t[3][1]), "+v"(y.t[0][0]), "+v"(y.t[0][1]), "+v"(y.t[1][0]), "+v"(y.t[1][1]),
+                 "+v"(y.t[2][0]), "+v"(y.t[2][1]), "+v"(y.t[3][0]), "+v"(y.t[3][1]), "+v"(z.t[0][0]), "+v"(z.t[0][1]),
+                 "+v"(z.t[1][0]), "+v"(z.t[1][1]), "+v"(z.t[2][0]), "+v"(z.t[2][1]), "+v"(z.t[3][0]), "+v"(z.t[3][1])
+               : "n"(N)
+               : "memory");
+}
+// One (row tile ti, column stripe tj, row range [mb, mb + rows)) piece: C[128 ti.., 256 tj..] (=|+=) X[rows, 128 ti..]^T dY[rows, 256 tj..],
+// bias_out[256 tj..] (=|+=) the (weighted) column sums of that dY range (blocks of the first row tile only).  atomic: the piece is one of
+// exactly TWO addends onto a zeroed element -- a two-addend fp32 sum does not depend on the order.
+__device__ __forceinline__ void tn_tile_wide(const TnArgs& a, char* smem_tn, int ti, int tj, int mb, int rows, float* C, int64_t ldc,
+                                             float* bias_out, bool atomic) {
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // opaque per call: the caller's piece loop must not keep this function's per-lane constants alive across pieces
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wi = wid >> 1, wj = wid & 1;
+  const int g4 = lane >> 4, l16 = lane & 15;
+  const int i0 = ti * TNW_TI, j0 = tj * TNW_TJ;
+  const int nt = (rows + TNW_BKM - 1) / TNW_BKM;
+  const int wx = (a.I - i0 < TNW_TI) ? a.I - i0 : TNW_TI, wy = (a.J - j0 < TNW_TJ) ? a.J - j0 : TNW_TJ;
+  const int64_t nbx = rows > 0 ? ((int64_t)(rows - 1) * a.ldx + wx) * 2 : 0;
+  const int64_t nby = rows > 0 ? ((int64_t)(rows - 1) * a.ldy + wy) * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X + (int64_t)mb * a.ldx + i0), 0, (int)(nbx > 0x7fffffff ? 0x7fffffff : nbx), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.Y + (int64_t)mb * a.ldy + j0), 0, (int)(nby > 0x7fffffff ? 0x7fffffff : nby), 0x00020000);
+  // DMA: linear LDS chunk c = tid + 256 i -> row c / (pitch / 16), physical chunk pc; its 256-byte segment pc >> 4 holds source chunk
+  // (pc & 15) ^ 4 (row & 3) ^ 2 ((row >> 3) & 1) of that segment (tn_tile's swizzle)
+  int vox[2], voy[4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+    const int col = 8 * (pc ^ (4 * (row & 3)) ^ (2 * ((row >> 3) & 1)));
+    vox[i] = (col < wx) ? (row * a.ldx + col) * 2 : 0x7ffffff0;   // columns past the width read as 0
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, row = c >> 5, pc = c & 31;
+    const int col = (pc >> 4) * 128 + 8 * ((pc & 15) ^ (4 * (row & 3)) ^ (2 * ((row >> 3) & 1)));
+    voy[i] = (col < wy) ? (row * a.ldy + col) * 2 : 0x7ffffff0;
+  }
+  const int stepx = TNW_BKM * a.ldx * 2, stepy = TNW_BKM * a.ldy * 2;
+  // fragment offsets: lane group g4 owns rows 8 g4 + (l16 >> 2) [+ 4]; byte in row as in tn_tile (the XOR stays inside a 256-byte segment)
+  const int rr = l16 >> 2;
+  const int cb = 8 * (l16 & 3);
+  const int xm = (64 * rr) ^ (32 * (g4 & 1));
+  int ofx[4], ofy[8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ofx[t] = (8 * g4 + rr) * 256 + ((wi * 128 + t * 32 + cb) ^ xm);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) ofy[t] = TNW_XB + (8 * g4 + rr) * 512 + ((wj * 256 + t * 32 + cb) ^ xm);
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bacc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bacc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // bias gradient: wave (wi, wj) of a first-row-tile block sums the columns of its y tiles 4 wi .. 4 wi + 3 (A operand all ones, or the
+  // per-row weights broadcast over the 16 output rows), as in tn_tile
+  const bool do_bias = (bias_out != nullptr) && (ti == 0);
+  const bool use_w = do_bias && (a.bias_w != nullptr);
+  const int64_t nbw = rows > 0 ? (int64_t)rows * 2 : 0;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(use_w ? a.bias_w + mb : a.Y), 0, (int)(use_w ? nbw : 0), 0x00020000);
+  int vow = lane * 4;   // 2 weights per lane: 64 lanes cover 128 rows, the step uses the first 32
+  const u32x4 ones_u = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+  auto stage = [&](int st) {
+    char* base = smem_tn + st * TNW_STB + wid * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { glds16(rx, base + i * 4096, vox[i], 0); vox[i] += stepx; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { glds16(ry, base + TNW_XB + i * 4096, voy[i], 0); voy[i] += stepy; }
+    if (use_w) {   // block-uniform; every wave writes the same 256 bytes (uniform DMA count per wave)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem_tn + 2 * TNW_STB + st * 256), 4, vow, 0, 0, 0);
+      vow += TNW_BKM * 2;
+    }
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_tn;
+  auto bf = [](const u32x2 (&p)[2]) { return tr_cat(p[0], p[1]); };
+  auto compute = [&](int st) {   // X once, Y in two halves of four tiles: the second half's reads land under the first half's MFMAs
+    const unsigned base = lds0 + st * TNW_STB;
+    u32x4 wv = ones_u;
+    if (use_w) asm volatile("ds_read_b128 %0, %1" : "=&v"(wv) : "v"(lds0 + 2 * TNW_STB + st * 256 + 16 * g4) : "memory");
+    MFMA_PRIO(1);
+    unsigned ax[4], ay0[4], ay1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { ax[t] = base + ofx[t]; ay0[t] = base + ofy[t]; ay1[t] = base + ofy[4 + t]; }
+    TrHalf16 X, Y0, Y1;
+    trw_issue<0, 1024>(X, ax);
+    trw_issue<0, 2048>(Y0, ay0);
+    trw_issue<0, 2048>(Y1, ay1);
+    trw_wait<8>(X, Y0, Y1);
+    if (use_w) asm volatile("" : "+v"(wv) : : "memory");   // older than every fragment read: already in
+    const bf16x8 wa = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(X.t[i]), bf(Y0.t[j]), acc[i][j], 0, 0, 0);
+    if (do_bias && wi == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bacc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bf(Y0.t[q]), bacc[q], 0, 0, 0);
+    }
+    trw_wait<0>(X, Y0, Y1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][4 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf(X.t[i]), bf(Y1.t[j]), acc[i][4 + j], 0, 0, 0);
+    if (do_bias && wi == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bacc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, bf(Y1.t[q]), bacc[q], 0, 0, 0);
+    }
+    MFMA_PRIO(0);
+  };
+
+  if (nt > 0) {   // stages addressed with compile-time constants (x2 unroll), as in tn_tile
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int t = 0;
+    for (; t + 2 <= nt; t += 2) {
+      stage(1);
+      compute(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 2 < nt) stage(0);
+      compute(1);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (t < nt) {
+      compute(0);
+      __syncthreads();
+    }
+  }
+  // store: tile (i, j), reg e -> row 16 i + 4 g + e ; column 16 j + c
+  // (Whole pieces staged through wave-private LDS strips and stored as 16-byte pieces of 512-byte row segments -- 32 store instructions per
+  // wave instead of 128 -- measured NEUTRAL: 1727 vs 1728 us on the head, profiles/r06_tn_wide.log.  Removed.)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = j0 + wj * 128 + j * 16 + l16;
+      if (col >= a.J) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int row = i0 + wi * 64 + i * 16 + 4 * g4 + e;
+        if (row < a.I) {
+          if (atomic) unsafeAtomicAdd(&C[(int64_t)row * ldc + col], acc[i][j][e]);
+          else C[(int64_t)row * ldc + col] = acc[i][j][e];
+        }
+      }
+    }
+  if (do_bias && g4 == 0) {  // row 0 of D (reg 0 of lane group 0) holds the column sums
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = j0 + wj * 128 + (4 * wi + q) * 16 + l16;
+      if (col < a.J) {
+        if (atomic) unsafeAtomicAdd(&bias_out[col], bacc[q][0]);
+        else bias_out[col] = bacc[q][0];
+      }
+    }
+  }
+}
+// Unsplit gradients with many column stripes (the head: I = 512, J = 50816 -> 4 x 199 wide tiles on 512 block slots = 1.55 residencies,
+// which whole tiles can only run as 2): the block slots form gangs of tiles_i blocks, a gang walks its share of the flattened
+// (stripe, 32-row step) space -- every gang the same number of steps -- and its blocks do the same (stripe, row range) piece for their own
+// row tile AT THE SAME TIME, so a dY stripe still crosses the fabric once and is shared through the XCD's L2 (what a per-block stream-K
+// cut loses, see gemm_tn_tail_kernel).  A gang's share is at least one stripe long, so a stripe is cut at most ONCE: its two pieces are
+// added onto zeroed elements with fp32 atomics, and a two-addend sum does not depend on the order -- deterministic without slabs
+// (whole stripes are stored, with the 128x128 kernel's bits).
+// stripe_is_cut: does a gang boundary fall strictly inside stripe s?  (device and host use this one expression)
+__host__ __device__ __forceinline__ int tnw_gang_begin(int64_t U, int gang, int gangs) { return (int)(U * gang / gangs); }
+__global__ __launch_bounds__(256) void tn_wide_zero_kernel(float* __restrict__ dW, float* __restrict__ dbias, int I, int J, int tiles_j,
+                                                           int gangs, int nsteps) {
+  const int s = blockIdx.x;
+  const int64_t U = (int64_t)tiles_j * nsteps;
+  const int lo = s * nsteps, hi = lo + nsteps;
+  int g = (int)((int64_t)lo * gangs / U);   // tnw_gang_begin(g) <= lo; the first boundary above lo is at g + 1 or g + 2
+  bool cut = false;
+  for (int k = g; k <= g + 2 && k < gangs; ++k) {
+    const int b = tnw_gang_begin(U, k, gangs);
+    cut = cut || (b > lo && b < hi);
+  }
+  if (!cut) return;
+  const int c0 = s * TNW_TJ, w4 = ((J - c0 < TNW_TJ) ? J - c0 : TNW_TJ) / 4;   // J % 4 == 0 (host check)
+  for (int i = threadIdx.x; i < I * w4; i += 256) {
+    const int r = i / w4, c = i - r * w4;
+    *(f32x4*)(dW + (int64_t)r * J + c0 + 4 * c) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (dbias) for (int i = threadIdx.x; i < w4; i += 256) *(f32x4*)(dbias + c0 + 4 * i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__global__ __launch_bounds__(256, 2) void gemm_tn_wide_sk_kernel(TnArgs a, int gangs, int nsteps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
+  const int P = xcd_remap(blockIdx.x, gridDim.x);   // gangs % 8 == 0: a gang's blocks are neighbours on one XCD
+  const int gang = P / a.tiles_i, ti = P - gang * a.tiles_i;
+  const int64_t U = (int64_t)a.tiles_j * nsteps;     // < 2^31 (host check)
+  const int g0 = tnw_gang_begin(U, gang, gangs), g1 = tnw_gang_begin(U, gang + 1, gangs);
+  // The gang walks its range ROTATED: from the first stripe boundary inside it to its end, then the leading partial stripe.  A range is
+  // (tail of a stripe | whole stripes | head of a stripe) and all ranges are equally long, so every gang works on row step t of some
+  // stripe at time t (phase 0) until its leading tail, which all gangs reach at the same time and walk with ONE common phase: at any
+  // moment the XCD's gangs read two row ranges of X, not sixteen (in range order each gang has its own phase: 1844 vs 1730 us).
+  int ub = ((g0 + nsteps - 1) / nsteps) * nsteps;
+  if (ub > g1) ub = g1;
+  for (int part = 0; part < 2; ++part) {
+    int u0 = part == 0 ? ub : g0;
+    const int u1 = part == 0 ? g1 : ub;
+    while (u0 < u1) {
+      const int stripe = u0 / nsteps, st0 = u0 - stripe * nsteps;
+      int ue = (stripe + 1) * nsteps;
+      if (ue > u1) ue = u1;
+      const int nst = ue - u0;
+      const int mb = st0 * TNW_BKM;
+      const int rows = (mb + nst * TNW_BKM < a.M) ? nst * TNW_BKM : a.M - mb;
+      tn_tile_wide(a, smem_tn, ti, stripe, mb, rows, a.C, a.J, a.bias_part, nst < nsteps);
+      u0 = ue;
+    }
+  }
+}
+
 // ---- 256x256-tile weight gradient (8 waves) ----------------------------------------------------------------------------
 // Same data path as tn_tile (natural-layout LDS tiles by LDS-DMA, hardware transpose reads), block tile 256 (I) x 256 (J),
 // 8 waves as 2 (I) x 4 (J) of 128 x 64 = 4 x 2 MFMA tiles; two stages x (X 64 x 256 | Y 64 x 256) bf16 = 128 KiB -> one
@@ -2940,6 +3200,22 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   const int tiles = a.tiles_i * a.tiles_j;
   const int tail_tiles = tiles % 512, n_whole = tiles - tail_tiles;
   const int S = tail_tiles ? 512 / tail_tiles : 1;
+  if (!use8 && g_opt_tn_wide && nsplit == 1) {   // [r06] gang stream-K on the 128 x 256 tile (gemm_tn_wide_sk_kernel): unsplit gradients with many stripes
+    const int wti = (I + TNW_TI - 1) / TNW_TI, wtj = (J + TNW_TJ - 1) / TNW_TJ, nsteps = (M + TNW_BKM - 1) / TNW_BKM;
+    const int gangs = (2 * persistent_grid() / wti) & ~7;   // two blocks per CU, the reserved CUs left free; whole gangs per XCD
+    if (gangs >= 8 && wtj >= gangs && (int64_t)(wtj + 1) * nsteps < 0x7fffffff) {
+      a.tiles_i = wti; a.tiles_j = wtj;
+      a.C = dW; a.slab_stride = 0; a.bias_part = dbias;
+      static bool attrs = false;
+      if (!attrs) { (void)hipFuncSetAttribute((const void*)gemm_tn_wide_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TNW_LDS_BYTES); attrs = true; }
+      tn_wide_zero_kernel<<<dim3(wtj), dim3(256), 0, st>>>(dW, dbias, I, J, wtj, gangs, nsteps);
+      DMI_CHECK_LAUNCH("gemm_tn_wide_zero");
+      gemm_tn_wide_sk_kernel<<<dim3(gangs * wti), dim3(256), TNW_LDS_BYTES, st>>>(a, gangs, nsteps);
+      DMI_CHECK_LAUNCH("gemm_tn_wide_sk");
+      if (n_deferred) *n_deferred = 0;
+      return DMI_OK;
+    }
+  }
   if (use8) {
     static bool attr8 = false;
     if (!attr8) { (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN8_LDS_BYTES); attr8 = true; }

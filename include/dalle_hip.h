@@ -102,7 +102,11 @@ int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, 
 /* weight gradient: dW[I,J] (fp32, ld = J) = sum_m X[m,I] * dY[m,J]; deterministic split over m.
  * dbias (nullable): fp32 [J] = sum_m w[m] * dY[m, :] fused into the same pass (bias gradient of the dense layer), with
  * w = 1, or w = bias_weights (nullable bf16 [M]) for the fused-softmax head where dY holds unnormalised dlogits.
- * workspace: dmi_gemm_tn_workspace_bytes(M, I, J). */
+ * workspace: dmi_gemm_tn_workspace_bytes(M, I, J).
+ * Run-to-run bit-identical for every shape.  Unsplit gradients with at least as many 256-column stripes as the chip has gangs
+ * of ceil(I / 128) block slots (the vocabulary projection's gradient) run as a gang stream-K on 128 x 256 tiles: a column
+ * stripe is cut at most once over m and its two pieces are added onto zeroed elements with fp32 atomics -- a two-addend sum
+ * has no order (option "tn_wide" = 0 keeps those shapes on the 128 x 128 tiles). */
 int64_t dmi_gemm_tn_workspace_bytes(int M, int I, int J);
 /* deferred (nullable, room for 2 items) + n_deferred: when the gradient is split over m, its final slab reduces (dW, dbias)
  * are not launched but described here; the caller runs the reduces of several GEMMs in ONE launch with

@@ -240,7 +240,9 @@ def test_production_dispatch_at_the_benchmark_batch_is_bit_identical_to_the_128x
              PLAIN products (QKV, FFN-1, FFN-2 input gradient, the head's three products): every NT kernel claims the 128x128 kernel's
              bits (same k order) and the composed step is held to it bit for bit -- loss, per-position losses, every gradient, the
              parameters after clip + Adam.  It does NOT cover the five N = 512 products: dmi_gemm_nt_ln / dmi_gemm_nt_lnbwd launch
-             gemm_ntr_kernel<0, 5, 1|2|3> whatever `ntr` says, so both arms run the same fused kernels there;
+             gemm_ntr_kernel<0, 5, 1|2|3> whatever `ntr` says, so both arms run the same fused kernels there; nor the head's weight
+             gradient, which both arms run as the gang stream-K (deterministic; held to the 128x128 kernel by
+             test_kernels_gpu.py::test_gemm_tn_gang_stream_k: uncut stripes bit-identical, cut stripes the fp32 sum of two pieces);
       sep    [r06] fuse_ln = fuse_lnbwd = False: plain dmi_gemm_nt + dmi_layernorm_fwd / _bwd for those five products -- the composed
              B = 32 backward through gemm_ntr<0,5,2|3> at 256 blocks against something other than itself.  The fused forms sum their
              row reductions in another order (Y / dx within one bf16 ulp, which flips a few ReLU bits), so this arm is held to the bounds

@@ -63,7 +63,7 @@ def test_no_kernel_uses_scratch(usage):
 def test_two_blocks_per_cu_kernels_fit_two_waves_per_simd(usage):
     """launch_bounds(256, 2) kernels: 256 registers (VGPR + AGPR) per lane at most, reported occupancy >= 2; the dK/dV attention
     kernel is the one deliberate one-wave-per-SIMD kernel (252 + 256 registers)"""
-    two = [k for k in usage if re.search(r"gemm_nt8p_kernel|gemm_ntr_kernel|gemm_nt8_kernel|gemm_tn_kernel|gemm_tn_tail_kernel|conv_wgrad_tn_kernel|"
+    two = [k for k in usage if re.search(r"gemm_nt8p_kernel|gemm_ntr_kernel|gemm_nt8_kernel|gemm_tn_kernel|gemm_tn_tail_kernel|gemm_tn_wide_sk_kernel|conv_wgrad_tn_kernel|"
                                           r"conv_gemm_nt_kernel|attn_fwd_kernel|attn_fwd2_kernel|attn_bwd_dq_kernel", k)]
     assert len(two) >= 30, two
     for k in two:

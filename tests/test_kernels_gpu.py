@@ -625,6 +625,62 @@ def test_gemm_tn(tail, tn8, M, I, J):
         dh.set_option("tn8", 0)
 
 
+@pytest.mark.parametrize("reserve", [0, 16])
+@pytest.mark.parametrize("M,I,J,weighted", [(200, 512, 33288, True), (33, 512, 40000, False), (1000, 256, 66000, True), (75, 1024, 17000, False),
+                                            (500, 520, 28000, True), (4096, 512, 50816, True)])
+def test_gemm_tn_gang_stream_k(reserve, M, I, J, weighted):
+    """[r06] unsplit gradients with at least as many 256-column stripes as gangs (the head's shape class) run as a gang stream-K on
+    128 x 256 tiles (gemm_tn_wide_sk_kernel): against fp32, against the 128x128 kernel -- stripes no gang boundary cuts are BIT-IDENTICAL
+    (same k order), a cut stripe is the fp32 sum of its two pieces (<= 2 ulp of the accumulated magnitude from the one-chain sum) --,
+    run to run bit-identical (a two-addend atomic sum has no order), over NaN-filled outputs (the zeroing covers exactly the cut stripes),
+    with ragged I / J / M, the weighted bias sums, and with reserved CUs (another gang count)."""
+    g = torch.Generator().manual_seed(M + I + J)
+    X = torch.randn(M, I, generator=g).to(torch.bfloat16).to(DEV)
+    dY = torch.randn(M, J, generator=g).to(torch.bfloat16).to(DEV)
+    wv = (torch.rand(M, generator=g) + 0.5).to(torch.bfloat16).to(DEV) if weighted else None
+    w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
+
+    def run(wide):
+        dh.set_option("tn_wide", wide)
+        dW = torch.full((I, J), float("nan"), dtype=torch.float32, device=DEV)
+        db = torch.full((J,), float("nan"), dtype=torch.float32, device=DEV)
+        dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db, bias_weights=wv)
+        torch.cuda.synchronize()
+        return dW, db
+    dh.set_option("reserve_cus", reserve)
+    dh.set_option("tn_tail", 0)    # the reference arm: whole 128x128 tiles, no row-split tail stripe (which sums in another order)
+    try:
+        d0, b0 = run(0)
+        d1, b1 = run(1)
+        d2, b2 = run(1)
+    finally:
+        dh.set_option("tn_wide", 1)
+        dh.set_option("tn_tail", 1)
+        dh.set_option("reserve_cus", 0)
+    assert not torch.isnan(d1).any() and not torch.isnan(b1).any()
+    assert torch.equal(d1, d2) and torch.equal(b1, b2), "the gang stream-K must be deterministic"
+    ref = X.float().t() @ dY.float()
+    close(d1, ref, 2e-3, 2e-3 * math.sqrt(M), "gang stream-K vs fp32")
+    close(b1, (wv.float() @ dY.float()) if weighted else dY.float().sum(0), 1e-4, 1e-3 * math.sqrt(M), "gang stream-K bias sums")
+    # which stripes does a gang boundary cut?  (the library's plan: 2 blocks per CU less the reserved CUs, whole gangs per XCD)
+    wti, wtj, nsteps = (I + 127) // 128, (J + 255) // 256, (M + 31) // 32
+    gangs = (2 * ((256 - reserve) & ~7) // wti) & ~7
+    assert wtj >= gangs, "shape does not take the gang stream-K path"
+    U = wtj * nsteps
+    cut = torch.zeros(wtj, dtype=torch.bool)
+    for k in range(1, gangs):
+        b = U * k // gangs
+        if b % nsteps:
+            cut[b // nsteps] = True
+    assert 0 < int(cut.sum()) < wtj or nsteps == 1
+    colcut = cut.repeat_interleave(256)[:J].to(DEV)
+    assert torch.equal(d1[:, ~colcut], d0[:, ~colcut]), "uncut stripes must have the 128x128 kernel's bits"
+    assert torch.equal(b1[~colcut], b0[~colcut])
+    mag = (X.float().abs().t() @ dY.float().abs())
+    assert float(((d1 - d0).abs() / (mag + 1e-6)).max()) <= 2.5e-7, float(((d1 - d0).abs() / (mag + 1e-6)).max())
+    assert int((d1[:, colcut] != d0[:, colcut]).sum()) > 0 or nsteps == 1   # (the cut stripes really are two-piece sums)
+
+
 def test_gemm_tn_deferred_batch_reduce_is_bit_identical():
     """four split weight gradients (with / without bias) whose slab reduces are deferred and run as ONE launch == the same
     calls with their own reduce launches, bit for bit; an unsplit problem defers nothing."""
