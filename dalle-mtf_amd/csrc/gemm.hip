@@ -2809,6 +2809,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide_sk_kernel(TnArgs a, int g
   }
 }
 
+// several row-split gradients in one launch (gemm_tn_group_kernel) on the wide tile: where the union of the problems' 128 x 256 tiles
+// fills the block slots with no more row splits than each problem's own workspace holds slabs for (the two FFN gradients of a block:
+// 32 + 32 tiles x 8 splits -- alone, either needs 16 splits, twice the slabs and half as long blocks, and loses to the 128x128 tile)
+__global__ __launch_bounds__(256, 2) void gemm_tn_group_wide_kernel(TnGroup g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_tn[];
+  const int T = g.first_tile[g.n];
+  const int P = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = P / T, t = P - split * T;
+  TnArgs a = g.p[0];
+  int t0 = 0;
+  if (g.n > 1 && t >= g.first_tile[1]) { a = g.p[1]; t0 = g.first_tile[1]; }
+  if (g.n > 2 && t >= g.first_tile[2]) { a = g.p[2]; t0 = g.first_tile[2]; }
+  if (g.n > 3 && t >= g.first_tile[3]) { a = g.p[3]; t0 = g.first_tile[3]; }
+  int ti, tj;
+  tile_of_block(t - t0, a.tiles_i, a.tiles_j, ti, tj);
+  const int mb = split * a.m_per_split;
+  const int me = (mb + a.m_per_split < a.M) ? mb + a.m_per_split : a.M;
+  const int rows = me > mb ? me - mb : 0;
+  tn_tile_wide(a, smem_tn, ti, tj, mb, rows, a.C + (int64_t)split * a.slab_stride, a.J,
+               a.bias_part ? a.bias_part + (int64_t)split * a.J : nullptr, false);
+}
+
 // ---- 256x256-tile weight gradient (8 waves) ----------------------------------------------------------------------------
 // Same data path as tn_tile (natural-layout LDS tiles by LDS-DMA, hardware transpose reads), block tile 256 (I) x 256 (J),
 // 8 waves as 2 (I) x 4 (J) of 128 x 64 = 4 x 2 MFMA tiles; two stages x (X 64 x 256 | Y 64 x 256) bf16 = 128 KiB -> one
@@ -3131,13 +3153,33 @@ extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_
   int S = T >= 384 ? 1 : 512 / T;
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;
+  // [r06] the wide tile, if its plan fills the slots with splits every problem's workspace has slabs for
+  bool wide = false;
+  if (g_opt_tn_wide) {
+    int Tw = 0, smin = 1 << 30;
+    for (int k = 0; k < n; ++k) {
+      Tw += ((probs[k].I + TNW_TI - 1) / TNW_TI) * ((probs[k].J + TNW_TJ - 1) / TNW_TJ);
+      const int sk = tn_splits(M, probs[k].I, probs[k].J);
+      if (sk < smin) smin = sk;
+    }
+    int Sw = Tw >= 384 ? 1 : 512 / Tw;
+    if (Sw > max_s) Sw = max_s;
+    if (Sw >= 2 && Sw <= smin && Tw * Sw >= 448) {
+      wide = true; S = Sw; T = 0;
+      for (int k = 0; k < n; ++k) {
+        g.first_tile[k] = T;
+        T += ((probs[k].I + TNW_TI - 1) / TNW_TI) * ((probs[k].J + TNW_TJ - 1) / TNW_TJ);
+      }
+      for (int k = n; k <= TN_GROUP_MAX; ++k) g.first_tile[k] = T;
+    }
+  }
   dmi_reduce_item items[2 * TN_GROUP_MAX];
   int ni = 0;
   for (int k = 0; k < n; ++k) {
     const dmi_tn_problem& q = probs[k];
     TnArgs& a = g.p[k];
     a.X = q.X; a.Y = q.dY; a.M = M; a.I = q.I; a.J = q.J; a.ldx = q.ldx; a.ldy = q.ldy;
-    a.tiles_i = (q.I + 127) / 128; a.tiles_j = (q.J + 127) / 128;
+    a.tiles_i = (q.I + 127) / 128; a.tiles_j = wide ? (q.J + TNW_TJ - 1) / TNW_TJ : (q.J + 127) / 128;
     a.m_per_split = (int)round_up64((M + S - 1) / S, TN_BKM);
     float* slabs = (float*)q.workspace;
     const int64_t slab_bytes = (S > 1) ? round_up64((int64_t)S * q.I * q.J * 4, 256) : 0;
@@ -3154,8 +3196,13 @@ extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_
   }
   for (int k = n; k < TN_GROUP_MAX; ++k) g.p[k] = g.p[0];
   static bool attr_done = false;
-  if (!attr_done) { (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES); attr_done = true; }
-  gemm_tn_group_kernel<<<dim3(T * S), dim3(256), TN_LDS_BYTES, (hipStream_t)stream>>>(g);
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_group_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TNW_LDS_BYTES);
+    attr_done = true;
+  }
+  if (wide) gemm_tn_group_wide_kernel<<<dim3(T * S), dim3(256), TNW_LDS_BYTES, (hipStream_t)stream>>>(g);
+  else gemm_tn_group_kernel<<<dim3(T * S), dim3(256), TN_LDS_BYTES, (hipStream_t)stream>>>(g);
   DMI_CHECK_LAUNCH("gemm_tn_group");
   if (n_deferred) *n_deferred = 0;
   if (deferred && n_deferred) {

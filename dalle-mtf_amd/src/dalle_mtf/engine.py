@@ -315,6 +315,10 @@ class DalleEngine:
         self.hp.setdefault("dgrad_tail_split", os.environ.get("DALLE_DGRAD_TAIL", "1") != "0")
         self.hp.setdefault("defer_reduces", os.environ.get("DALLE_DEFER_REDUCES", "1") != "0")
         self.hp.setdefault("wgrad_pair", os.environ.get("DALLE_WGRAD_PAIR", "1") != "0")
+        # [r06] all FOUR weight gradients of a block in one launch, on 128 x 256 tiles (96 tiles x 5 row splits; the library picks the wide
+        # tile when the union fills the block slots within every problem's slab count): 335 -> 266 us per block in isolation
+        # (profiles/r06_tn_group_wide.log); needs the pair launch and the deferred reduces
+        self.hp.setdefault("wgrad_group4", os.environ.get("DALLE_WGRAD_GROUP4", "1") != "0")
         self.hp.setdefault("lnbwd_chain", os.environ.get("DALLE_LNBWD_CHAIN", "1") != "0")
         # [r05] LayerNorm backward fused into the two input-gradient products that feed a LayerNorm (dmi_gemm_nt_lnbwd: n_embd = 512,
         # full-row tiles): dxn is never written, 12 of the 13 ln_bwd launches of a dalle_example step disappear
@@ -692,15 +696,19 @@ class DalleEngine:
                 self._block_forward(l)
                 self._in_backward = False
             # FFN
-            self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
-                        dbias=self._gv(p + "mlp/mlp_linear_2/bias"), slot=0)
+            pair = self.hp["wgrad_pair"] and self.hp["defer_reduces"]
+            group4 = pair and self.hp["wgrad_group4"]    # (dxa, self.dh, dxb stay untouched until the group's launch behind the attention backward)
+            if not group4:
+                self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
+                            dbias=self._gv(p + "mlp/mlp_linear_2/bias"), slot=0)
             if self.use_relu_bits:
                 dh.gemm_nt_mask_bits(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, self.hbits[l])
             else:
                 dh.gemm_nt(dxa, d, self._w(p + "mlp/mlp_linear_2/kernel"), d, self.dh, 4 * d, M, 4 * d, d, dh.GEMM_RELU_MASK,
                            relu_src=self.h[l])
-            self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
-                        dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
+            if not group4:
+                self._wgrad(self.xn2[l], d, self.dh, 4 * d, self._gv(p + "mlp/mlp_linear_1/kernel"), M, d, 4 * d,
+                            dbias=self._gv(p + "mlp/mlp_linear_1/bias"), slot=1)
             chain = self.fuse_lnbwd and self.hp["lnbwd_chain"]     # ... and the out-projection's input gradient d_o = dxb . Wo^T in the same launch
             if self.fuse_lnbwd:
                 lnbwd(2 * l + 1, self.dh, 4 * d, self._w(p + "mlp/mlp_linear_1/kernel"), self.x1[l], self._w(p + "norm_2/g"), st[2], st[3],
@@ -711,7 +719,6 @@ class DalleEngine:
                 ln_bwd(2 * l + 1, self.dxn, self.x1[l], self._w(p + "norm_2/g"), st[2], st[3], dxa, dxb,
                        self._gv(p + "norm_2/g"), self._gv(p + "norm_2/b"))
             # attention
-            pair = self.hp["wgrad_pair"] and self.hp["defer_reduces"]
             if not pair:
                 self._wgrad(self.o[l], d, dxb, d, self._gv(p + "attn/o"), M, d, d,
                             dbias=self._gv(p + "attn/compute_output_bias/o_b"), slot=2)
@@ -719,10 +726,15 @@ class DalleEngine:
                 dh.gemm_nt(dxb, d, self._w(p + "attn/o"), d, self.d_o, d, M, d, d)
             dh.attention_bwd(self.qkv[l], self.o[l], self.d_o, self.lse[l], self.delta, self.dqkv, B, H, S)
             if pair:   # [r05] the out-projection and QKV kernels' gradients in ONE launch: 16 + 48 tiles fill the chip together
-                dh.gemm_tn_group([dict(X=self.o[l], ldx=d, dY=dxb, ldy=d, dW=self._gv(p + "attn/o"), I=d, J=d, ws=self.ws_blk[2],
-                                       dbias=self._gv(p + "attn/compute_output_bias/o_b")),
-                                  dict(X=self.xn1[l], ldx=d, dY=self.dqkv, ldy=3 * d, dW=self._gv(p + "attn/qkv"), I=d, J=3 * d,
-                                       ws=self.ws_blk[3])], M, deferred=self.deferred)
+                probs = [dict(X=self.o[l], ldx=d, dY=dxb, ldy=d, dW=self._gv(p + "attn/o"), I=d, J=d, ws=self.ws_blk[2],
+                              dbias=self._gv(p + "attn/compute_output_bias/o_b")),
+                         dict(X=self.xn1[l], ldx=d, dY=self.dqkv, ldy=3 * d, dW=self._gv(p + "attn/qkv"), I=d, J=3 * d, ws=self.ws_blk[3])]
+                if group4:   # [r06] ... and the two FFN gradients with them
+                    probs = [dict(X=self.h[l], ldx=4 * d, dY=dxa, ldy=d, dW=self._gv(p + "mlp/mlp_linear_2/kernel"), I=4 * d, J=d,
+                                  ws=self.ws_blk[0], dbias=self._gv(p + "mlp/mlp_linear_2/bias")),
+                             dict(X=self.xn2[l], ldx=d, dY=self.dh, ldy=4 * d, dW=self._gv(p + "mlp/mlp_linear_1/kernel"), I=d, J=4 * d,
+                                  ws=self.ws_blk[1], dbias=self._gv(p + "mlp/mlp_linear_1/bias"))] + probs
+                dh.gemm_tn_group(probs, M, deferred=self.deferred)
             else:
                 self._wgrad(self.xn1[l], d, self.dqkv, 3 * d, self._gv(p + "attn/qkv"), M, d, 3 * d, slot=3)
             if self.fuse_lnbwd:
