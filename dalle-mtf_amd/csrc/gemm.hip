@@ -3131,6 +3131,25 @@ extern "C" int dmi_reduce_slabs_batch(const dmi_reduce_item* items, int n, void*
 // Weight gradients that share M in one launch (see gemm_tn_group_kernel).  Every problem's workspace holds its own slabs
 // (dmi_gemm_tn_workspace_bytes(M, I, J) bytes suffice: the group never splits finer than the single launch would); the slab
 // reduces are appended to `deferred` (2 per problem at most) or, with deferred == NULL, run here as one batched launch.
+// row splits of the group's plan on 128 x 256 tiles, or 0 where the group stays on 128 x 128 tiles: the union of the wide tiles must
+// fill (>= 448 of) the 512 block slots with a split count >= 2 that every problem's own workspace has slabs for
+static int tn_group_wide_splits(const int* I, const int* J, int n, int M) {
+  if (!g_opt_tn_wide) return 0;
+  int Tw = 0, smin = 1 << 30;
+  for (int k = 0; k < n; ++k) {
+    Tw += ((I[k] + TNW_TI - 1) / TNW_TI) * ((J[k] + TNW_TJ - 1) / TNW_TJ);
+    const int sk = tn_splits(M, I[k], J[k]);
+    if (sk < smin) smin = sk;
+  }
+  const int max_s = (M + 4 * TN_BKM - 1) / (4 * TN_BKM);
+  int Sw = Tw >= 384 ? 1 : 512 / Tw;
+  if (Sw > max_s) Sw = max_s;
+  return (Sw >= 2 && Sw <= smin && Tw * Sw >= 448) ? Sw : 0;
+}
+extern "C" int dmi_gemm_tn_group_plan(const int* I, const int* J, int n, int M) {
+  if (!I || !J || n < 1 || n > TN_GROUP_MAX || M <= 0) return 0;
+  return tn_group_wide_splits(I, J, n, M);
+}
 extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_reduce_item* deferred, int* n_deferred, void* stream) {
   DMI_REQUIRE(probs && n >= 1 && n <= TN_GROUP_MAX && M > 0, "gemm_tn_group: 1..%d problems", TN_GROUP_MAX);
   TnGroup g;
@@ -3155,16 +3174,11 @@ extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_
   if (S < 1) S = 1;
   // [r06] the wide tile, if its plan fills the slots with splits every problem's workspace has slabs for
   bool wide = false;
-  if (g_opt_tn_wide) {
-    int Tw = 0, smin = 1 << 30;
-    for (int k = 0; k < n; ++k) {
-      Tw += ((probs[k].I + TNW_TI - 1) / TNW_TI) * ((probs[k].J + TNW_TJ - 1) / TNW_TJ);
-      const int sk = tn_splits(M, probs[k].I, probs[k].J);
-      if (sk < smin) smin = sk;
-    }
-    int Sw = Tw >= 384 ? 1 : 512 / Tw;
-    if (Sw > max_s) Sw = max_s;
-    if (Sw >= 2 && Sw <= smin && Tw * Sw >= 448) {
+  {
+    int Is[TN_GROUP_MAX], Js[TN_GROUP_MAX];
+    for (int k = 0; k < n; ++k) { Is[k] = probs[k].I; Js[k] = probs[k].J; }
+    const int Sw = tn_group_wide_splits(Is, Js, n, M);
+    if (Sw) {
       wide = true; S = Sw; T = 0;
       for (int k = 0; k < n; ++k) {
         g.first_tile[k] = T;

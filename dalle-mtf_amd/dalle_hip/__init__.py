@@ -71,6 +71,7 @@ def _declare(L):
         "dmi_gemm_tn_workspace_bytes": (L64, [I, I, I]),
         "dmi_gemm_tn": (I, [P, I, P, I, P, P, P, I, I, I, P, P, P, P]),
         "dmi_gemm_tn_group": (I, [P, I, I, P, P, P]),
+        "dmi_gemm_tn_group_plan": (I, [P, P, I, I]),
         "dmi_reduce_slabs_batch": (I, [P, I, P]),
         "dmi_colsum_workspace_bytes": (L64, [L64, I]),
         "dmi_colsum": (I, [P, I, P, L64, I, P, P]),
@@ -351,6 +352,13 @@ class TnProblem(ctypes.Structure):
     """dmi_tn_problem (include/dalle_hip.h)."""
     _fields_ = [("X", c_void_p), ("ldx", c_int), ("dY", c_void_p), ("ldy", c_int), ("dW", c_void_p), ("dbias", c_void_p),
                 ("bias_weights", c_void_p), ("I", c_int), ("J", c_int), ("workspace", c_void_p)]
+
+
+def gemm_tn_group_plan(shapes, M):
+    """row splits of the grouped launch of weight gradients with shapes [(I, J), ...] when it runs on 128 x 256 tiles, 0 otherwise"""
+    n = len(shapes)
+    Is, Js = (c_int * n)(*[s[0] for s in shapes]), (c_int * n)(*[s[1] for s in shapes])
+    return int(lib().dmi_gemm_tn_group_plan(Is, Js, n, M))
 
 
 def gemm_tn_group(problems, M, deferred: "DeferredReduces" = None):

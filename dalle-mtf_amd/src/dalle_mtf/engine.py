@@ -319,6 +319,10 @@ class DalleEngine:
         # tile when the union fills the block slots within every problem's slab count): 335 -> 266 us per block in isolation
         # (profiles/r06_tn_group_wide.log); needs the pair launch and the deferred reduces
         self.hp.setdefault("wgrad_group4", os.environ.get("DALLE_WGRAD_GROUP4", "1") != "0")
+        # (only where the library's plan for the four is the wide one: at n_embd = 1024 / 2048 the union is 384+ tiles, which whole
+        # 128 x 128 tiles of ONE launch would run in ragged residencies -- those shapes keep the separate launches)
+        self.wgrad_group4 = bool(self.hp["wgrad_group4"] and self.hp["wgrad_pair"] and self.hp["defer_reduces"]
+                                 and dh.gemm_tn_group_plan([(4 * d, d), (d, 4 * d), (d, d), (d, 3 * d)], M) > 0)
         self.hp.setdefault("lnbwd_chain", os.environ.get("DALLE_LNBWD_CHAIN", "1") != "0")
         # [r05] LayerNorm backward fused into the two input-gradient products that feed a LayerNorm (dmi_gemm_nt_lnbwd: n_embd = 512,
         # full-row tiles): dxn is never written, 12 of the 13 ln_bwd launches of a dalle_example step disappear
@@ -697,7 +701,7 @@ class DalleEngine:
                 self._in_backward = False
             # FFN
             pair = self.hp["wgrad_pair"] and self.hp["defer_reduces"]
-            group4 = pair and self.hp["wgrad_group4"]    # (dxa, self.dh, dxb stay untouched until the group's launch behind the attention backward)
+            group4 = pair and self.wgrad_group4    # (dxa, self.dh, dxb stay untouched until the group's launch behind the attention backward)
             if not group4:
                 self._wgrad(self.h[l], 4 * d, dxa, d, self._gv(p + "mlp/mlp_linear_2/kernel"), M, 4 * d, d,
                             dbias=self._gv(p + "mlp/mlp_linear_2/bias"), slot=0)

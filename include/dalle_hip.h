@@ -126,6 +126,11 @@ int dmi_reduce_slabs_batch(const dmi_reduce_item* items, int n, void* stream);
 typedef struct dmi_tn_problem { const uint16_t* X; int ldx; const uint16_t* dY; int ldy; float* dW; float* dbias;
                                 const uint16_t* bias_weights; int I; int J; void* workspace; } dmi_tn_problem;
 int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_reduce_item* deferred, int* n_deferred, void* stream);
+/* The group's plan for n problems of shapes I[k] x J[k] over M rows: the row-split count (>= 2) when the launch runs on 128 x 256
+ * tiles -- the union of those tiles fills the block slots with a split count every problem's own workspace has slabs for: all four
+ * gradients of an n_embd = 512 block, 96 tiles x 5 splits --, 0 when it stays on 128 x 128 tiles.  Callers group MORE problems per
+ * launch where this is non-zero (the engine: a block's two FFN gradients join the attention pair). */
+int dmi_gemm_tn_group_plan(const int* I, const int* J, int n, int M);
 
 /* column sum (bias gradients): out[N] fp32 = sum_m Y[m, 0..N) ; workspace dmi_colsum_workspace_bytes */
 int64_t dmi_colsum_workspace_bytes(int64_t M, int N);

@@ -51,7 +51,7 @@ def test_argument_errors_come_back_as_status_and_message():
 
 
 def test_option_hooks():
-    for name in ("nt4", "nt8", "tn8", "tn8_max_tiles", "tn_tail", "attn_xcd"):
+    for name in ("nt4", "nt8", "tn8", "tn8_max_tiles", "tn_tail", "tn_wide", "attn_xcd"):
         v = dh.get_option(name)
         assert v >= 0, name
         dh.set_option(name, v)                      # round trip
@@ -66,3 +66,21 @@ def test_workspace_queries_are_pure_host_functions():
     assert dh.lib().dmi_sort_tokens_workspace_bytes(40960) > 0
     assert dh.lib().dmi_gemm_nt_softmax_partials(50816) == 794
     assert dh.lib().dmi_layernorm_bwd_workspace_bytes(40960, 512) > 0
+
+
+def test_grouped_weight_gradient_plan():
+    """[r06] dmi_gemm_tn_group_plan (host arithmetic only): the row-split count when the grouped launch runs on 128 x 256 tiles, else 0.
+    The engine groups all four gradients of a block where this is non-zero (n_embd = 512: 96 tiles x 5 splits) and keeps the separate
+    launches elsewhere (n_embd = 1024 / 2048: the union is 384+ tiles, one unsplit launch would run ragged residencies)."""
+    four = lambda d: [(4 * d, d), (d, 4 * d), (d, d), (d, 3 * d)]   # noqa: E731
+    assert dh.gemm_tn_group_plan(four(512), 40960) == 5
+    assert dh.gemm_tn_group_plan(four(512), 2560) == 5
+    assert dh.gemm_tn_group_plan(four(512)[:2], 40960) == 8        # the FFN pair: the single launches' split count
+    assert dh.gemm_tn_group_plan(four(512)[2:], 40960) == 0        # out-projection + QKV: 16 splits > QKV's 10 slabs
+    assert dh.gemm_tn_group_plan(four(1024), 40960) == 0 and dh.gemm_tn_group_plan(four(2048), 8192) == 0
+    saved = dh.get_option("tn_wide")
+    dh.set_option("tn_wide", 0)
+    try:
+        assert dh.gemm_tn_group_plan(four(512), 40960) == 0
+    finally:
+        dh.set_option("tn_wide", saved)

@@ -442,11 +442,24 @@ def test_gemm_nt8p_persistent_tile_256x256(M, N, K, flags):
 @pytest.mark.parametrize("M,shapes", [(40960, [(512, 512, True), (512, 1536, False)]), (2560, [(512, 512, True), (512, 1536, False)]),
                                       (1000, [(136, 200, True), (264, 72, True), (128, 128, False)]), (300, [(2048, 512, True)]),
                                       (5000, [(512, 2048, True), (2048, 512, True), (512, 512, True), (512, 1536, False)])])
-def test_gemm_tn_group_matches_fp32(M, shapes):
-    """[r05] dmi_gemm_tn_group: several weight gradients over the same M rows in one launch (the out-projection + QKV pair of a block
+@pytest.mark.parametrize("wide", [1, 0])
+def test_gemm_tn_group_matches_fp32(M, shapes, wide):
+    """[r06] wide = 1: the library may run the group on 128 x 256 tiles (dmi_gemm_tn_group_plan > 0: the four-problem case here and
+    the FFN pair), wide = 0: always the 128 x 128 tiles.
+    [r05] dmi_gemm_tn_group: several weight gradients over the same M rows in one launch (the out-projection + QKV pair of a block
     at the benchmark shape, ragged tiles, one problem, four problems, split and unsplit plans), each vs the fp32 product of the same
     bf16 operands, bias gradients as column sums; and vs dmi_gemm_tn to fp32 summation order; deferred and immediate reduces agree
     bit for bit."""
+    dh.set_option("tn_wide", wide)
+    try:
+        _group_matches_fp32(M, shapes, wide)
+    finally:
+        dh.set_option("tn_wide", 1)
+
+
+def _group_matches_fp32(M, shapes, wide):
+    plan = dh.gemm_tn_group_plan([(I, J) for I, J, _ in shapes], M)
+    assert (plan > 0) == (wide == 1 and len(shapes) == 4 and M == 5000), plan
     probs, refs = [], []
     for k, (I, J, with_bias) in enumerate(shapes):
         X, dY = rnd(M, I, seed=10 + k), rnd(M, J, seed=20 + k)
@@ -623,6 +636,36 @@ def test_gemm_tn(tail, tn8, M, I, J):
     finally:
         dh.set_option("tn_tail", 1)
         dh.set_option("tn8", 0)
+
+
+def test_gemm_tn_group_wide_ffn_pair_is_bit_identical_to_two_launches():
+    """[r06] the two FFN gradients of a block as one grouped launch on 128 x 256 tiles: 32 + 32 tiles x 8 row splits -- the split count
+    of each single launch, and the wide tile keeps the k order (32-row chunks in row order), so the grouped launch has the single
+    launches' BITS (slab by slab); with the 128 x 128 group (64 + 64 tiles x 4 splits) only to summation order."""
+    M, d = 8192, 512
+    X2, dY2, X1, dY1 = rnd(M, 4 * d, seed=1).to(DEV), rnd(M, d, seed=2).to(DEV), rnd(M, d, seed=3).to(DEV), rnd(M, 4 * d, seed=4).to(DEV)
+    w2, w1 = ws(dh.gemm_tn_workspace_bytes(M, 4 * d, d)), ws(dh.gemm_tn_workspace_bytes(M, d, 4 * d))
+    single = []
+    for X, dY, I, J, w in ((X2, dY2, 4 * d, d, w2), (X1, dY1, d, 4 * d, w1)):
+        dW = torch.zeros(I, J, dtype=torch.float32, device=DEV); db = torch.zeros(J, dtype=torch.float32, device=DEV)
+        dh.gemm_tn(X, I, dY, J, dW, M, I, J, w, dbias=db)
+        single.append((dW, db))
+    assert dh.gemm_tn_group_plan([(4 * d, d), (d, 4 * d)], M) == 8
+    for wide in (1, 0):
+        dh.set_option("tn_wide", wide)
+        try:
+            probs = [dict(X=X2, ldx=4 * d, dY=dY2, ldy=d, dW=torch.full((4 * d, d), float("nan"), device=DEV), I=4 * d, J=d, ws=w2,
+                          dbias=torch.full((d,), float("nan"), device=DEV)),
+                     dict(X=X1, ldx=d, dY=dY1, ldy=4 * d, dW=torch.full((d, 4 * d), float("nan"), device=DEV), I=d, J=4 * d, ws=w1,
+                          dbias=torch.full((4 * d,), float("nan"), device=DEV))]
+            dh.gemm_tn_group(probs, M)
+        finally:
+            dh.set_option("tn_wide", 1)
+        for q, (dW, db) in zip(probs, single):
+            if wide:
+                assert torch.equal(q["dW"], dW) and torch.equal(q["dbias"], db)
+            else:
+                close(q["dW"], dW, 1e-4, 1e-4 * math.sqrt(M), "128x128 group vs single")
 
 
 @pytest.mark.parametrize("reserve", [0, 16])
