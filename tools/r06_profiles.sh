@@ -17,4 +17,6 @@ tools/pmc_kernel.sh ${R}_attn_p1 "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT
 tools/pmc_kernel.sh ${R}_attn_p2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE" attn > /dev/null 2>&1
 cat gpurun_out/${R}_attn_p1_pmc.txt gpurun_out/${R}_attn_p2_pmc.txt > gpurun_out/${R}_attn_pmc.txt 2>/dev/null
 tools/pmc_kernel.sh ${R}_head_p1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" head > /dev/null 2>&1
+tools/pmc_kernel.sh ${R}_tn_p1 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT" tn > /dev/null 2>&1
+python tools/experiments/r06_tn_group_wide.py 2>/dev/null | grep -v amdgpu > gpurun_out/${R}_tn_group_wide.log
 head -c 1200 gpurun_out/${R}_bench_n1.json; echo; head -40 gpurun_out/${R}_step_breakdown.txt; for m in vae_example vae_coco 1p3B dalle_coco; do python -c "import json;d=json.load(open('gpurun_out/${R}_bench_$m.json'));print('$m', d['ms_per_step'], d['roofline'].get('step_mfma_frac'))"; done; cat gpurun_out/${R}_attn_pmc.txt | head -30
