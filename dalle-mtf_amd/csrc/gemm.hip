@@ -3161,7 +3161,7 @@ extern "C" int dmi_gemm_tn_group(const dmi_tn_problem* probs, int n, int M, dmi_
     DMI_REQUIRE(q.I % 8 == 0 && q.J % 8 == 0 && q.ldx % 8 == 0 && q.ldy % 8 == 0 && q.ldx >= q.I && q.ldy >= q.J,
                 "gemm_tn_group: I, J, ldx, ldy must be multiples of 8 (problem %d: I=%d J=%d)", k, q.I, q.J);
     DMI_REQUIRE((((uintptr_t)q.X | (uintptr_t)q.dY | (uintptr_t)q.dW | (uintptr_t)q.workspace) & 15) == 0, "gemm_tn_group: 16-byte alignment required");
-    DMI_REQUIRE(!q.bias_weights || (q.dbias && ((uintptr_t)q.bias_weights & 3) == 0), "gemm_tn_group: bias_weights needs dbias and 4-byte alignment");
+    DMI_REQUIRE(!q.bias_weights || (q.dbias && ((uintptr_t)q.bias_weights & 3) == 0 && M % 2 == 0), "gemm_tn_group: bias_weights needs dbias, 4-byte alignment and an even M");
     DMI_REQUIRE((int64_t)TN_BKM * (q.ldx > q.ldy ? q.ldx : q.ldy) * 2 < 0x7fffffff, "gemm_tn_group: leading dimension too large");
     g.first_tile[k] = T;
     T += ((q.I + 127) / 128) * ((q.J + 127) / 128);
@@ -3234,7 +3234,8 @@ extern "C" int dmi_gemm_tn(const uint16_t* X, int ldx, const uint16_t* dY, int l
   DMI_REQUIRE(M > 0 && I % 8 == 0 && J % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= I && ldy >= J,
               "gemm_tn: I, J, ldx, ldy must be multiples of 8 (M=%d I=%d J=%d)", M, I, J);
   DMI_REQUIRE((((uintptr_t)X | (uintptr_t)dY | (uintptr_t)dW | (uintptr_t)workspace) & 15) == 0, "gemm_tn: 16-byte alignment required");
-  DMI_REQUIRE(!bias_weights || (dbias && ((uintptr_t)bias_weights & 3) == 0), "gemm_tn: bias_weights needs dbias and 4-byte alignment");
+  DMI_REQUIRE(!bias_weights || (dbias && ((uintptr_t)bias_weights & 3) == 0 && M % 2 == 0),
+              "gemm_tn: bias_weights needs dbias, 4-byte alignment and an even M (the weights travel as dwords: the last weight of an odd M would be range-checked away)");
   DMI_REQUIRE((int64_t)TN_BKM * (ldx > ldy ? ldx : ldy) * 2 < 0x7fffffff, "gemm_tn: leading dimension too large");
   hipStream_t st = (hipStream_t)stream;
   const bool use8 = tn8_eligible(M, I, J);

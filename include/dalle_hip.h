@@ -101,7 +101,8 @@ int dmi_gemm_nt_splitk(const uint16_t* A, int lda, const uint16_t* Bt, int ldb, 
                        int nsplit, const float* rowscale, void* workspace, void* stream);
 /* weight gradient: dW[I,J] (fp32, ld = J) = sum_m X[m,I] * dY[m,J]; deterministic split over m.
  * dbias (nullable): fp32 [J] = sum_m w[m] * dY[m, :] fused into the same pass (bias gradient of the dense layer), with
- * w = 1, or w = bias_weights (nullable bf16 [M]) for the fused-softmax head where dY holds unnormalised dlogits.
+ * w = 1, or w = bias_weights (nullable bf16 [M], 4-byte aligned, M even: DMI_ERR_INVALID otherwise) for the fused-softmax head
+ * where dY holds unnormalised dlogits.
  * workspace: dmi_gemm_tn_workspace_bytes(M, I, J).
  * Run-to-run bit-identical for every shape.  Unsplit gradients with at least as many 256-column stripes as the chip has gangs
  * of ceil(I / 128) block slots (the vocabulary projection's gradient) run as a gang stream-K on 128 x 256 tiles: a column

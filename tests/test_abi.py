@@ -48,6 +48,11 @@ def test_argument_errors_come_back_as_status_and_message():
     assert rc == -1 and "multiple of 8" in L.dmi_last_error_string().decode()
     with pytest.raises(dh.DalleHipError):
         dh._check(rc, "attention_fwd")
+    # [r06] weighted bias sums need an even M (the weights travel as dwords; found by tools/experiments/r06_stress_tn.py): refused before
+    # any launch -- the pointers below are never dereferenced
+    fake = ctypes.c_void_p(0x10000)
+    rc = L.dmi_gemm_tn(fake, 128, fake, 128, fake, fake, fake, 595, 128, 128, fake, None, None, None)
+    assert rc == -1 and "even M" in L.dmi_last_error_string().decode()
 
 
 def test_option_hooks():
