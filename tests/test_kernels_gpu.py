@@ -638,6 +638,42 @@ def test_gemm_tn(tail, tn8, M, I, J):
         dh.set_option("tn8", 0)
 
 
+@pytest.mark.parametrize("path", ["gang stream-K", "128x128 + tail", "128x128 whole", "256x256"])
+def test_gemm_tn_rows_beyond_2GiB(path):
+    """[r06] The weight gradient of the vocabulary projection at the BENCHMARK batch: dY = 40 960 rows x 50 816 columns of bf16 = 4.16 GB, i.e.
+    every row from 21 130 on lies more than 2 GiB into the operand.  Rounds 1-5 accumulated the row step in 32-bit per-lane buffer offsets
+    under a descriptor clipped to 2^31 - 1 bytes, so those rows were range-checked to ZERO and the head's weight / bias gradient came from
+    52 % of the tokens -- unseen, because every oracle comparison runs at <= 2 sequences.  Here only rows past that point (and three before
+    it) are non-zero in X, and the bias weights are non-zero only there: every path must reproduce their contribution exactly."""
+    M, I, J = 40960, 256, 50816     # (I >= 256: the workspace then also covers the forced 256x256 plan)
+    g = torch.Generator().manual_seed(5)
+    hot = torch.tensor([5, 21000, 21129, 21130, 21131, 30000, 30063, 40959])
+    X = torch.zeros(M, I, dtype=torch.bfloat16, device=DEV)
+    X[hot.to(DEV)] = torch.randn(len(hot), I, generator=g).to(torch.bfloat16).to(DEV)
+    Y = torch.empty(M, J, dtype=torch.bfloat16, device=DEV)
+    for r0 in range(0, M, 4096):     # (row-dependent values, generated in pieces: 4 GB of bf16)
+        Y[r0:r0 + 4096] = (torch.randn(4096, 1, generator=g) * 0.5 + torch.randn(1, J, generator=g) * 0.25).to(torch.bfloat16).to(DEV)
+    wv = torch.zeros(M, dtype=torch.bfloat16, device=DEV)
+    wv[hot.to(DEV)] = (torch.rand(len(hot), generator=g) + 0.5).to(torch.bfloat16).to(DEV)
+    ref = X[hot.to(DEV)].float().t() @ Y[hot.to(DEV)].float()
+    rb = wv[hot.to(DEV)].float() @ Y[hot.to(DEV)].float()
+    w = ws(dh.gemm_tn_workspace_bytes(M, I, J))
+    opts = {"gang stream-K": dict(tn_wide=1, tn_tail=1, tn8=0), "128x128 + tail": dict(tn_wide=0, tn_tail=1, tn8=0),
+            "128x128 whole": dict(tn_wide=0, tn_tail=0, tn8=0), "256x256": dict(tn_wide=0, tn_tail=1, tn8=2)}[path]
+    for k, v in opts.items():
+        dh.set_option(k, v)
+    try:
+        dW = torch.full((I, J), float("nan"), device=DEV)
+        db = torch.full((J,), float("nan"), device=DEV)
+        dh.gemm_tn(X, I, Y, J, dW, M, I, J, w, dbias=db, bias_weights=wv)
+        torch.cuda.synchronize()
+    finally:
+        dh.set_option("tn_wide", 1); dh.set_option("tn_tail", 1); dh.set_option("tn8", 0)
+    assert float(ref.abs().max()) > 1.0
+    close(dW, ref, 1e-5, 1e-4, f"gemm_tn {path}: rows beyond 2 GiB")
+    close(db, rb, 1e-5, 1e-4, f"gemm_tn {path}: weighted bias sums beyond 2 GiB")
+
+
 def test_gemm_tn_group_wide_ffn_pair_is_bit_identical_to_two_launches():
     """[r06] the two FFN gradients of a block as one grouped launch on 128 x 256 tiles: 32 + 32 tiles x 8 row splits -- the split count
     of each single launch, and the wide tile keeps the k order (32-row chunks in row order), so the grouped launch has the single
