@@ -674,6 +674,32 @@ def test_gemm_tn_rows_beyond_2GiB(path):
     close(db, rb, 1e-5, 1e-4, f"gemm_tn {path}: weighted bias sums beyond 2 GiB")
 
 
+def test_head_forward_and_input_gradient_rows_beyond_2GiB():
+    """[r06] The same question for the other two kernels that touch the 4.16-GB E = exp(logits) matrix at the benchmark batch -- the
+    vocabulary projection that writes it and the input gradient that reads it (both NT kernels with per-tile descriptor bases, which is why
+    they were right all along): rows on both sides of the 2-GiB line against fp32."""
+    M, K, Vp = 40960, 512, 50816
+    g = torch.Generator().manual_seed(9)
+    X = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    Wt = (torch.randn(Vp, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    bias = (torch.randn(Vp, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    E = torch.empty(M, Vp, dtype=torch.bfloat16, device=DEV)
+    part = torch.empty(dh.gemm_nt_softmax_partials(Vp), M, dtype=torch.float32, device=DEV)
+    dh.gemm_nt_softmax(X, K, Wt, K, bias, None, E, Vp, part, M, Vp, K)
+    rows = torch.tensor([0, 21129, 21130, 21131, 30000, 40959], device=DEV)
+    ref = torch.exp(X[rows].float() @ Wt.float().t() + bias.float())
+    close(E[rows], ref, 1.0e-2, 1e-6, "vocabulary projection rows beyond 2 GiB")
+    close(part[:, rows].sum(0), ref.sum(1), 2e-3, 1e-3, "row sums beyond 2 GiB")
+    # input gradient dX = rowscale * (E . W): W = [K, Vp]
+    W = Wt.t().contiguous()
+    rs = (torch.rand(M, generator=g) + 0.5).to(DEV)
+    dX = torch.full((M, K), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dh.gemm_nt(E, Vp, W, Vp, dX, K, M, K, Vp, dh.GEMM_ROWSCALE, rowscale=rs)
+    refd = (E[rows].float() @ W.float().t()) * rs[rows, None]
+    close(dX[rows], refd, 1.6e-2, 2e-2 * float(refd.abs().max()), "head input gradient rows beyond 2 GiB")
+    assert not torch.isnan(dX.float()).any()
+
+
 def test_gemm_tn_group_wide_ffn_pair_is_bit_identical_to_two_launches():
     """[r06] the two FFN gradients of a block as one grouped launch on 128 x 256 tiles: 32 + 32 tiles x 8 row splits -- the split count
     of each single launch, and the wide tile keeps the k order (32-row chunks in row order), so the grouped launch has the single
