@@ -554,7 +554,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt2_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const int r = lane & 31, h = lane >> 5;
 
   int tm, tn;
   tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
@@ -692,7 +691,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt4_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const int r = lane & 31, h = lane >> 5;
 
   int tm, tn;
   tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
@@ -797,7 +795,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 2, wn = wid & 3;
-  const int r = lane & 31, h = lane >> 5;
 
   int tm, tn;
   tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
@@ -1253,11 +1250,7 @@ __device__ __forceinline__ void epilogue_lnbwd(const GemmArgs& a, f32x4 (&acc)[R
   const __amdgpu_buffer_rsrc_t rmu = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_mean + m0), 0, (a.M - m0) * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.ln_rstd + m0), 0, (a.M - m0) * 4, 0x00020000);
   const int r0 = wm * (RM / 2) + c16;                      // this lane's row of row tile 0 (row tile t: + 16 t)
-  const int vo0 = (r0 * 512 + ncolw + 4 * g16) * 2;        // byte offset of (that row, column ncolw + 4 g); row tile t: + 16 KB t
   float* prow = a.ln_part + (int64_t)(blockIdx.x * 2 + wm) * 1024;
-  auto ld8 = [&](const __amdgpu_buffer_rsrc_t rsrc, int voff, int imm) {
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, imm, 0));
-  };
   auto lo = [](unsigned w) { return __uint_as_float(w << 16); };
   auto hi = [](unsigned w) { return __uint_as_float(w & 0xffff0000u); };
   // dy = bf16(acc) and x are kept PACKED (80 + 80 registers; the three passes unpack what they touch).  x and dres are fetched as the
@@ -2335,7 +2328,7 @@ __device__ __forceinline__ void tn_tile(const TnArgs& a, const ConvGeom* cg, cha
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wi = wid >> 1, wj = wid & 1;
-  const int h = lane >> 5, g4 = lane >> 4, l16 = lane & 15;
+  const int g4 = lane >> 4, l16 = lane & 15;
 
   const int i0 = ti * 128, j0 = tj * 128;
   const int nt = (rows + TN_BKM - 1) / TN_BKM;
@@ -3356,7 +3349,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_nt_kernel(GemmArgs a, ConvGe
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid >> 1, wn = wid & 1;
-  const int r = lane & 31, h = lane >> 5;
 
   int tm, tn;
   tile_of_block(xcd_remap(blockIdx.x, gridDim.x), a.tiles_m, a.tiles_n, tm, tn);
