@@ -397,6 +397,10 @@ def main():
                          "traffic_source": tsrc, "algorithmic_bytes": algo_bytes,
                          "traffic_unit": "bytes/launch (PMC: FETCH_SIZE x2 + WRITE_SIZE, L2-side counters incl. Infinity-Cache hits)",
                          "launch_ms": k_avg, "launches_timed": len(k_ms),
+                         # what else holds this launch below the matrix-pipe bound (DESIGN §4 "[r04] What bounds the short-K products"):
+                         # K = 512 gives a 256x256 tile 8 k-steps per 128 KB of exponentiated output, the epilogue (v_exp_f32 at a quarter
+                         # rate, ~13 B/clk/CU of output stores = 4.2 GB per launch) runs with the matrix pipe idle
+                         "also_bound_by": "epilogue: exp at quarter VALU rate + 4.16 GB of output stores per launch (~28 % of a tile's life)",
                          "step_mfma_frac": train_flops_step_gpu / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS,
                          "step_tflops_per_gpu": train_flops_step_gpu / (ms * 1e-3) / 1e12},
         }
