@@ -334,6 +334,44 @@ def test_benchmark_batch_gradients_equal_the_sum_of_the_two_sequence_gradients()
     assert all(v <= 1e-3 for v in head.values()), head   # measured 2.9e-5 (kernel), 5.8e-5 (bias)
 
 
+@pytest.mark.parametrize("n_embd,n_heads,n_layers,image_vocab,B", [(2048, 16, 2, 512, 32), (1024, 8, 2, 2048, 16)])
+def test_secondary_widths_batch_gradients_equal_the_sum_of_the_two_sequence_gradients(n_embd, n_heads, n_layers, image_vocab, B):
+    """[r06] The same size-independent property at the widths of the other two transformer configurations and THEIR per-GPU batches
+    (1.3B dimensions at B = 32: the 4.16-GB dY again, the FFN gradients on the gang stream-K with 8 / 32 gangs; dalle_coco's width at
+    B = 16), two blocks deep: gradient of the batch == sum of the gradients of its pairs of sequences.  (The pairs are what the
+    width-specific oracle tests cover: test_1p3b_two_layer_step_vs_oracles, tests/test_dalle_step_gpu.py.)"""
+    from oracle import dalle_oracle as do
+    from src.dalle_mtf.engine import DalleEngine
+    tokens = torch.from_numpy(do.assemble_tokens(do.synthetic_captions(B, 256, 50258, seed=3),
+                                                 do.synthetic_image_tokens(B, 1024, image_vocab, seed=4), 50258)).cuda()
+
+    def make(b):
+        eng = DalleEngine(n_embd, n_layers, n_heads, 50258, image_vocab, 256, 1024, batch_size=b, global_batch_size=B,
+                          hparams=dict(lr=1e-3, train_steps=100000, warmup_steps=3000, gradient_clipping=1.0))
+        eng.init_params(seed=77)
+        return eng
+    big = make(B)
+    big.forward(tokens, need_grad=True)
+    big.backward(allreduce=False)
+    torch.cuda.synchronize()
+    gb = big.export_reference(big.g)
+    del big
+    torch.cuda.empty_cache()
+    small = make(2)
+    acc = None
+    for i in range(0, B, 2):
+        small.forward(tokens[i:i + 2].contiguous(), need_grad=True)
+        small.backward(allreduce=False)
+        torch.cuda.synchronize()
+        gs = small.export_reference(small.g)
+        acc = {k: v.astype(np.float64) for k, v in gs.items()} if acc is None else {k: acc[k] + gs[k] for k in acc}
+    del small
+    torch.cuda.empty_cache()
+    worst = max((float(np.linalg.norm(gb[k] - acc[k]) / (np.linalg.norm(acc[k]) + 1e-30)), k) for k in gb)
+    print(f"n_embd {n_embd} B = {B}: gradient vs the sum of the B = 2 gradients, worst tensor", worst, flush=True)
+    assert worst[0] <= 5e-3, worst
+
+
 def _trajectory(start, steps=10, seed=4321):
     """`steps` free-running optimizer steps at the exact dalle_example architecture on one B = 1 batch, engine and fp32 CPU oracle each
     carrying their OWN parameters and Adam slots from identical initial weights; schedule position `start` of configs/dalle_example.json
