@@ -7,7 +7,7 @@ sys.path[:0] = [os.path.join(ROOT, "dalle-mtf_amd")]
 import torch
 import dalle_hip as dh
 DEV = "cuda"
-rng = random.Random(11)
+rng = random.Random(int(os.environ.get("STRESS_SEED", "11")))
 def rnd(*shape, seed=0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g).to(torch.bfloat16).to(DEV)
