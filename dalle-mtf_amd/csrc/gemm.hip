@@ -2567,8 +2567,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_group_kernel(TnGroup g) {
 // moves 24 KB for the same 2.1 MFLOP (32 rows x (128 + 256) columns), reads 24 transposed fragments per 32 MFMAs instead of 32, and
 // keeps everything else: two blocks per CU (2 x 48 KB LDS, 128 accumulator registers), one barrier per 32 MFMAs per wave, the same
 // source-side swizzle (per 256-byte segment of a row), the same bias path and the same k order (32-row chunks in row order: a whole
-// stripe has the 128x128 kernel's bits).  Measured where whole tiles fill whole residencies (M = 40960, I = 512, J = 65536): 2578 ->
-// 2063 us = 1066 -> 1332 TFLOP/s; the transposed shape (256 x 128) 5 % behind it; on the row-split gradients of the layers (32 tiles x 16
+// stripe has the 128x128 kernel's bits).  Measured where whole tiles fill whole residencies (M = 40960, I = 512, J = 65536): 2880 ->
+// 2397 us = 955 -> 1147 TFLOP/s (with every row read: see TnStream); the transposed shape (256 x 128) 5 % behind it; on the row-split gradients of the layers (32 tiles x 16
 // splits instead of 64 x 8) slower (88 -> 97 us: twice the slabs, half as long blocks) -- those stay on the 128x128 tile
 // (profiles/r06_tn_wide.log).
 #define TNW_BKM 32
@@ -2736,7 +2736,7 @@ __device__ __forceinline__ void tn_tile_wide(const TnArgs& a, char* smem_tn, int
   }
   // store: tile (i, j), reg e -> row 16 i + 4 g + e ; column 16 j + c
   // (Whole pieces staged through wave-private LDS strips and stored as 16-byte pieces of 512-byte row segments -- 32 store instructions per
-  // wave instead of 128 -- measured NEUTRAL: 1727 vs 1728 us on the head, profiles/r06_tn_wide.log.  Removed.)
+  // wave instead of 128 -- measured NEUTRAL: 1727 vs 1728 us on the head (before the TnStream fix), profiles/r06_tn_wide.log.  Removed.)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -2800,7 +2800,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_wide_sk_kernel(TnArgs a, int g
   // The gang walks its range ROTATED: from the first stripe boundary inside it to its end, then the leading partial stripe.  A range is
   // (tail of a stripe | whole stripes | head of a stripe) and all ranges are equally long, so every gang works on row step t of some
   // stripe at time t (phase 0) until its leading tail, which all gangs reach at the same time and walk with ONE common phase: at any
-  // moment the XCD's gangs read two row ranges of X, not sixteen (in range order each gang has its own phase: 1844 vs 1730 us).
+  // moment the XCD's gangs read two row ranges of X, not sixteen (in range order each gang has its own phase: 1844 vs 1730 us, measured before the TnStream fix).
   int ub = ((g0 + nsteps - 1) / nsteps) * nsteps;
   if (ub > g1) ub = g1;
   for (int part = 0; part < 2; ++part) {
